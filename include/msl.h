@@ -1,0 +1,197 @@
+/*
+ * msl.h -- C ABI of the MI355X-native RGB-D front end (ORB extractor + surfel fusion).
+ *
+ * This is the drop-in boundary for ManhattanSLAM's two hot-path classes.  The reference has no
+ * FFI layer; the interfaces replaced are C++ class members, cited per entry point below
+ * (paths relative to the reference repository):
+ *
+ *   ORB_SLAM2::ORBextractor::ORBextractor(...)        include/ORBextractor.h:46-47, src/ORBextractor.cc:412-468
+ *   ORB_SLAM2::ORBextractor::operator()(...)          include/ORBextractor.h:54-56, src/ORBextractor.cc:813-870
+ *   ORB_SLAM2::ORBextractor::Get*Scale*()             include/ORBextractor.h:58-80
+ *   SurfelFusion::SurfelFusion(...)                   include/SurfelFusion.h:127-129, src/SurfelFusion.cpp:29-38
+ *   SurfelFusion::fuseInitializeMap(...)              include/SurfelFusion.h:131-138, src/SurfelFusion.cpp:40-73
+ *   ORB_SLAM2::SurfelMapping::fuseMap(...)            src/SurfelMapping.cpp:353-392   (slot refill / tail compaction)
+ *
+ * All entry points are extern "C", take plain pointers and sizes, never throw, and return
+ * MSL_OK (0) or a negative msl_status; msl_last_error() gives a thread-local message.
+ * Every handle owns its HIP stream and scratch; a handle is used by one thread at a time
+ * (same rule as the reference objects) but the calling thread may change between calls
+ * (src/Frame.cc:100 spawns a fresh std::thread per frame) -- the device is re-bound on entry.
+ *
+ * There is NO CPU fallback: creation fails with MSL_ERR_NO_DEVICE when no gfx950 device is
+ * usable.  The CPU oracle under oracle/ is test infrastructure and is not linked here.
+ */
+#ifndef MSL_H
+#define MSL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSL_API __attribute__((visibility("default")))
+
+typedef enum msl_status {
+    MSL_OK = 0,
+    MSL_ERR_INVALID = -1,      /* bad argument / unsupported geometry            */
+    MSL_ERR_NO_DEVICE = -2,    /* no usable HIP device (no CPU fallback exists)  */
+    MSL_ERR_HIP = -3,          /* a HIP runtime call failed                      */
+    MSL_ERR_CAPACITY = -4,     /* caller-provided output capacity too small      */
+    MSL_ERR_OVERFLOW = -5      /* an internal device-side bound was exceeded     */
+} msl_status;
+
+typedef enum msl_mem {
+    MSL_MEM_HOST = 0,          /* pointer is ordinary host memory                */
+    MSL_MEM_DEVICE = 1         /* pointer is device memory on the handle's GPU   */
+} msl_mem;
+
+/* Same layout as cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct msl_keypoint {
+    float x, y;
+    float size;
+    float angle;      /* degrees, [0,360) */
+    float response;   /* FAST-9/16 corner score */
+    int32_t octave;
+    int32_t class_id; /* always -1 */
+} msl_keypoint;
+
+/* Same layout as the reference `struct Surfel` (include/Surfel.h:28-37), 56 bytes. */
+typedef struct msl_surfel {
+    float px, py, pz;
+    float nx, ny, nz;
+    float size;
+    float color;
+    int32_t r, g, b;
+    float weight;
+    int32_t updateTimes;
+    int32_t lastUpdate;
+} msl_surfel;
+
+/* Same layout as SurfelFusion::SuperpixelSeed (include/SurfelFusion.h:46-58), 64 bytes.
+ * Only used by the debug accessors that let the parity tests look at intermediate stages. */
+typedef struct msl_seed {
+    float x, y;
+    float size;
+    float normX, normY, normZ;
+    float posX, posY, posZ;
+    float viewCos;
+    float meanDepth;
+    float meanIntensity;
+    int32_t r, g, b;
+    uint8_t fused, stable, use, _pad;
+} msl_seed;
+
+MSL_API const char *msl_last_error(void);
+MSL_API const char *msl_version(void);
+/* Number of usable gfx950 devices (0 if none / HIP unavailable). */
+MSL_API int msl_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * ORB extractor
+ * ---------------------------------------------------------------------------------------- */
+typedef struct msl_orb msl_orb;
+
+/* Replaces ORBextractor::ORBextractor (src/ORBextractor.cc:412-468).  max_width/max_height bound
+ * the frame size, max_batch the number of frames one msl_orb_extract_batch call may carry. */
+MSL_API msl_orb *msl_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                                int minThFAST, int max_width, int max_height, int max_batch,
+                                int device);
+MSL_API void msl_orb_destroy(msl_orb *h);
+
+/* Scale tables of include/ORBextractor.h:58-80; each out array holds nlevels floats (NULL = skip). */
+MSL_API int msl_orb_scale_tables(const msl_orb *h, float *scaleFactors, float *invScaleFactors,
+                                 float *levelSigma2, float *invLevelSigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:433-445). */
+MSL_API int msl_orb_features_per_level(const msl_orb *h, int32_t *out);
+/* Upper bound on keypoints per frame: nfeatures + 2*nlevels (src/ORBextractor.cc:691-696). */
+MSL_API int msl_orb_capacity(const msl_orb *h);
+MSL_API int msl_orb_levels(const msl_orb *h);
+
+/* Replaces ORBextractor::operator() (src/ORBextractor.cc:813-870) for one CV_8UC1 frame held in
+ * host memory.  stride is in bytes.  On return *n_out keypoints (level order 0..L-1, in-level
+ * order = quadtree list order) and n_out*32 descriptor bytes are in the caller's host buffers.
+ * An empty image (width==0||height==0||gray==NULL) returns MSL_OK with *n_out = 0 (:815-816). */
+MSL_API int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride,
+                            msl_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
+
+/* Frame-batched variant (throughput path).  Frame f starts at gray + f*frame_stride.  Outputs for
+ * frame f are written at kps + f*cap, desc32 + f*cap*32, n_out[f].  in_mem/out_mem say whether
+ * the input / the three output pointers are host or device memory.  With device outputs the
+ * call is asynchronous on the handle's stream: use msl_orb_sync() before reading. */
+MSL_API int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int width,
+                                  int height, size_t row_stride, size_t frame_stride,
+                                  msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
+                                  int32_t *n_out, msl_mem out_mem);
+MSL_API int msl_orb_sync(msl_orb *h);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
+MSL_API int msl_orb_set_stream(msl_orb *h, void *hip_stream);
+
+/* Debug accessors for the parity tests (host output, synchronous, after an extract call):
+ * pyramid level image of frame f (unpadded, tightly packed w*h), its blurred version, and the
+ * FAST candidates handed to the quadtree (x,y in level pixel coords, response), in order. */
+MSL_API int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out);
+MSL_API int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out);
+MSL_API int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys /*3 ints each*/,
+                                     int cap, int *n_out);
+/* Per-kernel timing: when enabled, every launch is bracketed by HIP events on the handle's
+ * stream; msl_orb_profile_read returns accumulated milliseconds and launch counts per kernel. */
+#define MSL_ORB_NKERNELS 6
+MSL_API int msl_orb_profile_enable(msl_orb *h, int on);
+MSL_API int msl_orb_profile_read(msl_orb *h, float *ms /*[MSL_ORB_NKERNELS]*/,
+                                 int32_t *launches /*[MSL_ORB_NKERNELS]*/);
+MSL_API const char *msl_orb_kernel_name(int k);
+
+/* ------------------------------------------------------------------------------------------
+ * Surfel fusion
+ * ---------------------------------------------------------------------------------------- */
+typedef struct msl_sf msl_sf;
+
+/* Replaces SurfelFusion::SurfelFusion (src/SurfelFusion.cpp:29-38). */
+MSL_API msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy,
+                              float fuseFar, float fuseNear, int device);
+MSL_API void msl_sf_destroy(msl_sf *h);
+
+/* Host-vector mode == SurfelFusion::fuseInitializeMap (src/SurfelFusion.cpp:40-73).
+ * gray: CV_8UC1 w*h; depth: CV_32FC1 metres; member: CV_32SC1 (w/2)*(h/2), -1 = no plane; strides
+ * in bytes; pose = Twc as column-major 4x4 (Eigen::Matrix4f storage).  `local` (n_local surfels)
+ * is updated in place; new surfels are written to new_out (<= (w/8)*(h/8)), count in *n_new. */
+MSL_API int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride,
+                        const float *depth, size_t depth_stride, const int32_t *member,
+                        size_t member_stride, const float pose_colmajor[16], msl_surfel *local,
+                        size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new);
+
+/* Device-resident map mode: the live surfel map stays in HBM between keyframes. */
+MSL_API int msl_sf_map_reserve(msl_sf *h, size_t capacity);
+MSL_API int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n);
+MSL_API int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out);
+MSL_API int msl_sf_map_size(msl_sf *h, size_t *n_out);
+
+/* fuseInitializeMap + the SurfelMapping::fuseMap slot refill / tail compaction
+ * (src/SurfelMapping.cpp:353-392) on the resident map.  Image pointers may be host or device
+ * (img_mem).  Asynchronous on the handle's stream; msl_sf_sync() (or map_size/download) waits.
+ * counters_out (may be NULL; host) receives after sync {n_live_before, n_new, n_deleted, n_updated,
+ * n_live_after}; pass it to msl_sf_last_counters instead to stay asynchronous. */
+MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8_t *gray,
+                                 size_t gray_stride, const float *depth, size_t depth_stride,
+                                 const int32_t *member, size_t member_stride, msl_mem img_mem,
+                                 const float pose_colmajor[16]);
+MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]);
+MSL_API int msl_sf_sync(msl_sf *h);
+MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
+
+/* Debug accessors (host output, synchronous): superpixel seeds and the pixel->seed index map
+ * as left by the last fuse call. */
+MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
+MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
+
+#define MSL_SF_NKERNELS 12
+MSL_API int msl_sf_profile_enable(msl_sf *h, int on);
+MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);
+MSL_API const char *msl_sf_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSL_H */

@@ -1,0 +1,10 @@
+"""MI355X-native RGB-D front end for ManhattanSLAM: ORB extractor + surfel fusion.
+
+The product is the C-ABI shared library ``libmsl.so`` (hand-written HIP for gfx950, see
+``include/msl.h``); this package is the thin Python host mirror of the reference's two
+entry classes, used by the tests and ``bench.py``.  There is no CPU fallback: importing the
+compute classes without the built library, or constructing them without an MI355X, raises.
+"""
+from ._lib import lib, MslError, KEYPOINT_DTYPE, SURFEL_DTYPE, SEED_DTYPE, device_count  # noqa: F401
+from .orb import ORBextractor  # noqa: F401
+from .surfel import SurfelFusion, SurfelMap  # noqa: F401

@@ -1,0 +1,103 @@
+"""ctypes binding of include/msl.h.  Fails loudly when libmsl.so has not been built."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsl.so")
+
+
+class MslError(RuntimeError):
+    pass
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+SURFEL_DTYPE = np.dtype([("px", "<f4"), ("py", "<f4"), ("pz", "<f4"), ("nx", "<f4"), ("ny", "<f4"),
+                         ("nz", "<f4"), ("size", "<f4"), ("color", "<f4"), ("r", "<i4"), ("g", "<i4"),
+                         ("b", "<i4"), ("weight", "<f4"), ("updateTimes", "<i4"), ("lastUpdate", "<i4")])
+SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<f4"), ("normY", "<f4"),
+                       ("normZ", "<f4"), ("posX", "<f4"), ("posY", "<f4"), ("posZ", "<f4"),
+                       ("viewCos", "<f4"), ("meanDepth", "<f4"), ("meanIntensity", "<f4"), ("r", "<i4"),
+                       ("g", "<i4"), ("b", "<i4"), ("fused", "u1"), ("stable", "u1"), ("use", "u1"),
+                       ("_pad", "u1")])
+assert KEYPOINT_DTYPE.itemsize == 28 and SURFEL_DTYPE.itemsize == 56 and SEED_DTYPE.itemsize == 64
+
+MSL_MEM_HOST, MSL_MEM_DEVICE = 0, 1
+
+# name -> (restype, argtypes); every symbol include/msl.h declares
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "msl_last_error": (C.c_char_p, []),
+    "msl_version": (C.c_char_p, []),
+    "msl_device_count": (_i, []),
+    "msl_orb_create": (_vp, [_i, _f, _i, _i, _i, _i, _i, _i, _i]),
+    "msl_orb_destroy": (None, [_vp]),
+    "msl_orb_scale_tables": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "msl_orb_features_per_level": (_i, [_vp, _vp]),
+    "msl_orb_capacity": (_i, [_vp]),
+    "msl_orb_levels": (_i, [_vp]),
+    "msl_orb_extract": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _vp]),
+    "msl_orb_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp, _vp, _i, _vp, _i]),
+    "msl_orb_sync": (_i, [_vp]),
+    "msl_orb_set_stream": (_i, [_vp, _vp]),
+    "msl_orb_debug_level_size": (_i, [_vp, _i, _vp, _vp]),
+    "msl_orb_debug_level": (_i, [_vp, _i, _i, _i, _vp]),
+    "msl_orb_debug_candidates": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "msl_orb_profile_enable": (_i, [_vp, _i]),
+    "msl_orb_profile_read": (_i, [_vp, _vp, _vp]),
+    "msl_orb_kernel_name": (C.c_char_p, [_i]),
+    "msl_sf_create": (_vp, [_i, _i, _f, _f, _f, _f, _f, _f, _i]),
+    "msl_sf_destroy": (None, [_vp]),
+    "msl_sf_fuse": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "msl_sf_map_reserve": (_i, [_vp, _sz]),
+    "msl_sf_map_upload": (_i, [_vp, _vp, _sz]),
+    "msl_sf_map_download": (_i, [_vp, _vp, _sz, _vp]),
+    "msl_sf_map_size": (_i, [_vp, _vp]),
+    "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
+    "msl_sf_last_counters": (_i, [_vp, _vp]),
+    "msl_sf_sync": (_i, [_vp]),
+    "msl_sf_set_stream": (_i, [_vp, _vp]),
+    "msl_sf_debug_seeds": (_i, [_vp, _vp]),
+    "msl_sf_debug_index": (_i, [_vp, _vp]),
+    "msl_sf_profile_enable": (_i, [_vp, _i]),
+    "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),
+    "msl_sf_kernel_name": (C.c_char_p, [_i]),
+}
+MSL_ORB_NKERNELS = 6
+MSL_SF_NKERNELS = 12
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise MslError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C manhattanslam_amd/csrc). There is no CPU fallback.")
+    dll = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(dll, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    return dll
+
+
+lib = _load()
+
+
+def check(rc, what="msl call"):
+    if rc != 0:
+        raise MslError(f"{what} failed ({rc}): {lib.msl_last_error().decode()}")
+
+
+def device_count():
+    return int(lib.msl_device_count())
+
+
+def ptr(a):
+    """void* of a numpy array (host) or anything exposing data_ptr() (torch device tensor)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return C.c_void_p(a.data_ptr())
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,95 @@
+// msl_common.h -- shared host/device helpers for the gfx950 front-end library (internal).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/msl.h"
+
+namespace msl {
+
+// ---- error plumbing --------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+#define MSL_HIP_TRY(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            ::msl::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,     \
+                             __LINE__);                                                           \
+            return MSL_ERR_HIP;                                                                   \
+        }                                                                                         \
+    } while (0)
+
+int bind_device(int device);  // hipSetDevice + gfx950 check; returns msl_status
+
+// Event-pair profiler: one (start, stop) pair per launch, drained at sync points.
+struct KernelProfiler {
+    bool on = false;
+    int nk = 0;
+    float ms[16] = {0};
+    int32_t launches[16] = {0};
+    struct Pair { hipEvent_t a, b; int k; };
+    Pair *pairs = nullptr;
+    int npairs = 0, cap = 0;
+    void begin(int k, hipStream_t s);
+    void end(hipStream_t s);
+    void drain();  // requires the stream to be idle
+    void destroy();
+};
+
+// ---- device helpers --------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
+// s_wave must hold >= 17 unsigned. Returns the exclusive prefix; *total gets the block sum.
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *s_wave, unsigned *total) {
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned inc = wave_incl_scan(v);
+    __syncthreads();  // protect s_wave reuse
+    if (lane_id() == 63) s_wave[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned run = 0;
+        for (int i = 0; i < nw; i++) { unsigned t = s_wave[i]; s_wave[i] = run; run += t; }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    *total = s_wave[16];
+    return s_wave[w] + inc - v;
+}
+
+// In-place inclusive scan of an LDS array (len elements) by the whole block.
+template <typename T>
+__device__ __forceinline__ void block_scan_array_incl(T *arr, int len, unsigned *s_wave) {
+    const int nt = blockDim.x;
+    const int per = (len + nt - 1) / nt;
+    const int b = threadIdx.x * per, e = min(b + per, len);
+    unsigned sum = 0;
+    for (int i = b; i < e; i++) sum += arr[i];
+    unsigned tot;
+    unsigned base = block_excl_scan(sum, s_wave, &tot);
+    for (int i = b; i < e; i++) { base += arr[i]; arr[i] = (T)base; }
+    __syncthreads();
+}
+
+#endif  // __HIPCC__
+
+}  // namespace msl

@@ -1,0 +1,1063 @@
+// msl_orb.hip -- ORB extractor for gfx950 (MI355X): kernels + C ABI.
+//
+// Replaces ORB_SLAM2::ORBextractor (reference src/ORBextractor.cc).  Frame-batched pipeline, all
+// integer/byte work, HBM/L2-bound; no MFMA (nothing here is a contraction).  Per batch of B frames:
+//
+//   k_resize   x(L-1)  level l <- level l-1, OpenCV 11-bit fixed-point bilinear   (:872-893, cv::resize)
+//   k_fast     x1      one workgroup per 30-px FAST cell: LDS-staged tile, FAST-9/16 score,
+//                      in-cell 3x3 NMS, iniTh->minTh fallback, ordered ballot compaction (:745-780)
+//   k_octree   x1      one workgroup per (frame, level): quadtree distribution, LDS resident (:531-721)
+//   k_blur     x1      7x7 sigma-2 fixed-point separable Gaussian, LDS tile             (:851-852)
+//   k_describe x1      one wave per keypoint: IC_Angle + steered BRIEF-256, output assembly
+//                                                                      (:75-149, :470-475, :829-869)
+//
+// Float expressions that feed a rounding (angle, rotated pattern coordinates) are written in the
+// reference's order and this file is compiled with -ffp-contract=off.
+
+#include "msl_common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+using namespace msl;
+
+namespace {
+
+constexpr int ML = 12;          // max pyramid levels
+constexpr int MAXCELL = 64;     // max FAST cell extent (pixels)
+constexpr int MAXNODE = 1024;   // max quadtree list length per level
+constexpr int OCT_NT = 512;     // threads of the quadtree workgroup
+
+struct LevelDev {
+    int w, h, pitch;
+    unsigned off;       // byte offset inside one frame's pyramid store (levels >= 1)
+    unsigned boff;      // byte offset inside one frame's blurred store
+    int nCols, nRows, wCell, hCell;
+    int cellBase, nCells;
+    int keyBase, keyCap;
+    int quota;
+    int nIni; float hX;
+    float scale; int patch;
+    unsigned xtabOff, ytabOff;  // element offsets into the resize tables
+    int tileBase, tilesX, tilesY;  // blur tiling
+};
+
+struct CellDev {
+    short level, x0, y0, cw, ch, _pad;
+    unsigned keyOff;  // first key slot of the cell (frame relative)
+};
+
+struct ResizeTap { short s0, s1, c0, c1; };
+
+struct OrbDev {
+    int nlevels, iniTh, minTh;
+    int cellsPerFrame, keysPerFrame, selCap, outCap, blurTiles;
+    unsigned long long pyrStride, blurStride;
+    LevelDev lv[ML];
+    int umax[16];
+    const uint8_t *in; unsigned long long inRowStride, inFrameStride;
+    uint8_t *pyr, *blur;
+    const CellDev *cells;
+    const ResizeTap *taps;
+    uint32_t *cellCnt, *cellKeys, *keys;
+    uint16_t *knode;
+    uint32_t *sel; int *nsel, *ncand;
+    msl_keypoint *kps; uint8_t *desc; int *nout; int *err;
+};
+
+__constant__ int8_t c_pattern[1024] = {
+#include "../../include/msl_orb_pattern.inc"
+};
+
+__device__ __forceinline__ const uint8_t *level_ptr(const OrbDev &P, int frame, int l, int &pitch) {
+    if (l == 0) { pitch = (int)P.inRowStride; return P.in + (size_t)frame * P.inFrameStride; }
+    pitch = P.lv[l].pitch;
+    return P.pyr + (size_t)frame * P.pyrStride + P.lv[l].off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_resize: level l from level l-1.  One thread per output pixel; taps come from host-built tables
+// so the coefficient arithmetic (double -> float -> cvRound) is the host's.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(OrbDev P, int l) {
+    const int frame = blockIdx.z;
+    const LevelDev &D = P.lv[l];
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= D.w || dy >= D.h) return;
+    int sp;
+    const uint8_t *src = level_ptr(P, frame, l - 1, sp);
+    const ResizeTap tx = P.taps[D.xtabOff + dx], ty = P.taps[D.ytabOff + dy];
+    const uint8_t *r0 = src + (size_t)ty.s0 * sp, *r1 = src + (size_t)ty.s1 * sp;
+    const int h0 = r0[tx.s0] * tx.c0 + r0[tx.s1] * tx.c1;
+    const int h1 = r1[tx.s0] * tx.c0 + r1[tx.s1] * tx.c1;
+    int v = (((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    P.pyr[(size_t)frame * P.pyrStride + D.off + (size_t)dy * D.pitch + dx] = (uint8_t)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fast: one workgroup (256 threads) per FAST cell.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int fast_score16(const uint8_t *t, int tp) {
+    // t points at the centre pixel inside the LDS tile (pitch tp)
+    const int v = t[0];
+    int d[16];
+    d[0] = v - t[3 * tp];          d[1] = v - t[3 * tp + 1];   d[2] = v - t[2 * tp + 2];   d[3] = v - t[tp + 3];
+    d[4] = v - t[3];               d[5] = v - t[-tp + 3];      d[6] = v - t[-2 * tp + 2];  d[7] = v - t[-3 * tp + 1];
+    d[8] = v - t[-3 * tp];         d[9] = v - t[-3 * tp - 1];  d[10] = v - t[-2 * tp - 2]; d[11] = v - t[-tp - 3];
+    d[12] = v - t[-3];             d[13] = v - t[tp - 3];      d[14] = v - t[2 * tp - 2];  d[15] = v - t[3 * tp - 1];
+    // a = max over the 16 nine-arcs of min(d), b = min over arcs of max(d)  (score = max(a, -b) - 1)
+    int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+    int a = -256, b = 256;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
+        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        a = max(a, lo9);
+        b = min(b, hi9);
+    }
+    return max(a, -b) - 1;
+}
+
+__global__ __launch_bounds__(256) void k_fast(OrbDev P) {
+    __shared__ uint8_t s_tile[(MAXCELL + 6) * (MAXCELL + 8)];
+    __shared__ uint8_t s_score[(MAXCELL + 2) * (MAXCELL + 2)];
+    __shared__ uint8_t s_flag[MAXCELL * MAXCELL];
+    __shared__ unsigned s_wave[17];
+    __shared__ unsigned s_cnt[2];
+
+    const int frame = blockIdx.y;
+    const CellDev C = P.cells[blockIdx.x];
+    const int tid = threadIdx.x;
+    uint32_t *cnt_out = P.cellCnt + (size_t)frame * P.cellsPerFrame + blockIdx.x;
+    const int cw = C.cw, ch = C.ch;
+    if (cw <= 0 || ch <= 0) { if (tid == 0) *cnt_out = 0; return; }
+    int pitch;
+    const uint8_t *img = level_ptr(P, frame, C.level, pitch);
+
+    // stage (cw+6) x (ch+6) pixels: rows y0-3.., cols x0-3..
+    const int tw = cw + 6, th = ch + 6, tp = (tw + 3) & ~3;
+    for (int i = tid; i < tw * th; i += 256) {
+        const int r = i / tw, c = i - r * tw;
+        s_tile[r * tp + c] = img[(size_t)(C.y0 - 3 + r) * pitch + (C.x0 - 3 + c)];
+    }
+    const int sp = cw + 2;
+    for (int i = tid; i < sp * (ch + 2); i += 256) s_score[i] = 0;
+    if (tid < 2) s_cnt[tid] = 0;
+    __syncthreads();
+    const int npx = cw * ch;
+    for (int i = tid; i < npx; i += 256) {
+        const int r = i / cw, c = i - r * cw;
+        int s = fast_score16(&s_tile[(r + 3) * tp + c + 3], tp);
+        s_score[(r + 1) * sp + c + 1] = (uint8_t)max(s, 0);
+    }
+    __syncthreads();
+    // NMS + threshold flags: bit0 = kept at iniTh, bit1 = kept at minTh
+    unsigned c_ini = 0, c_min = 0;
+    for (int i = tid; i < npx; i += 256) {
+        const int r = i / cw, c = i - r * cw;
+        const uint8_t *q = &s_score[(r + 1) * sp + c + 1];
+        const int s = q[0];
+        const bool lm = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] &&
+                        s > q[sp - 1] && s > q[sp] && s > q[sp + 1];
+        const int f = lm ? ((s >= P.iniTh ? 1 : 0) | (s >= P.minTh ? 2 : 0)) : 0;
+        s_flag[i] = (uint8_t)f;
+        c_ini += f & 1;
+        c_min += (f >> 1) & 1;
+    }
+    if (c_ini) atomicAdd(&s_cnt[0], c_ini);
+    if (c_min) atomicAdd(&s_cnt[1], c_min);
+    __syncthreads();
+    const int bit = s_cnt[0] ? 1 : 2;  // fallback to minTh when nothing survives at iniTh (:766-769)
+    const unsigned total = s_cnt[0] ? s_cnt[0] : s_cnt[1];
+    if (tid == 0) *cnt_out = total;
+    if (total == 0) return;
+    // ordered compaction, row-major inside the cell
+    uint32_t *out = P.cellKeys + (size_t)frame * P.keysPerFrame + C.keyOff;
+    unsigned base = 0;
+    for (int i0 = 0; i0 < npx; i0 += 256) {
+        const int i = i0 + tid;
+        const unsigned f = (i < npx && (s_flag[i] & bit)) ? 1u : 0u;
+        unsigned tot;
+        const unsigned pos = block_excl_scan(f, s_wave, &tot);
+        if (f) {
+            const int r = i / cw, c = i - r * cw;
+            const unsigned kx = C.x0 + c - 16, ky = C.y0 + r - 16;  // border-frame coordinates (:773-774)
+            out[base + pos] = kx | (ky << 12) | ((unsigned)s_score[(r + 1) * sp + c + 1] << 24);
+        }
+        base += tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_octree: DistributeOctTree for one (frame, level).  The reference's std::list semantics are
+// expressed with prefix sums: after a full round the list is [children of the expanded nodes, last
+// expanded first, each as n4,n3,n2,n1] ++ [the one-key nodes in their old order]; in "careful"
+// mode nodes are expanded largest first (ties: later created first) until the list reaches N.
+// Keys never move: each keeps the list position of its node; the winner per final node is the
+// max-response key, earliest in input order on ties.
+// ---------------------------------------------------------------------------------------------
+struct Rect { short x0, y0, x1, y1; };
+
+__device__ __forceinline__ int quadrant(const Rect r, int x, int y) {
+    const int mx = r.x0 + ((r.x1 - r.x0 + 1) >> 1), my = r.y0 + ((r.y1 - r.y0 + 1) >> 1);
+    return (x < mx ? 0 : 1) + (y < my ? 0 : 2);
+}
+__device__ __forceinline__ Rect child_rect(const Rect r, int q) {
+    const short mx = r.x0 + ((r.x1 - r.x0 + 1) >> 1), my = r.y0 + ((r.y1 - r.y0 + 1) >> 1);
+    Rect c;
+    c.x0 = (q & 1) ? mx : r.x0; c.x1 = (q & 1) ? r.x1 : mx;
+    c.y0 = (q & 2) ? my : r.y0; c.y1 = (q & 2) ? r.y1 : my;
+    return c;
+}
+
+__global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
+    __shared__ Rect s_rect[2][MAXNODE];
+    __shared__ unsigned s_cnt[2][MAXNODE];
+    __shared__ short s_crank[2][MAXNODE];     // creation rank among the nodes recorded for careful mode, -1 = none
+    __shared__ unsigned s_cc[4 * MAXNODE];    // child key counts
+    __shared__ unsigned short s_F[4 * MAXNODE];  // scan of "child exists"
+    __shared__ unsigned short s_G[4 * MAXNODE];  // scan of "child expandable"
+    __shared__ unsigned short s_L[MAXNODE];      // scan of kept old nodes
+    __shared__ unsigned short s_order[MAXNODE];  // careful mode: sorted candidates
+    __shared__ unsigned short s_rankOf[MAXNODE]; // careful mode: node -> sorted rank (0xFFFF = not a candidate)
+    __shared__ unsigned s_wave[17];
+    __shared__ int s_misc[8];
+
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const LevelDev &G = P.lv[level];
+    const int N = G.quota;
+    uint32_t *keys = P.keys + (size_t)frame * P.keysPerFrame + G.keyBase;
+    uint16_t *knode = P.knode + (size_t)frame * P.keysPerFrame + G.keyBase;
+    int *nsel = P.nsel + frame * P.nlevels + level;
+    uint32_t *sel = P.sel + ((size_t)frame * P.nlevels + level) * P.selCap;
+
+    // ---- gather the cell lists in cell order (vToDistributeKeys, :757-779) ----
+    const uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cellsPerFrame + G.cellBase;
+    const uint32_t *cellKeys = P.cellKeys + (size_t)frame * P.keysPerFrame;
+    unsigned n = 0;
+    {
+        unsigned carry = 0;
+        for (int c0 = 0; c0 < G.nCells; c0 += OCT_NT) {
+            const int c = c0 + tid;
+            const unsigned cnt = c < G.nCells ? cellCnt[c] : 0;
+            unsigned tot;
+            const unsigned off = carry + block_excl_scan(cnt, s_wave, &tot);
+            if (cnt) {
+                const uint32_t *src = cellKeys + P.cells[G.cellBase + c].keyOff;
+                for (unsigned i = 0; i < cnt; i++) keys[off + i] = src[i];
+            }
+            carry += tot;
+        }
+        n = carry;
+    }
+    if (tid == 0) P.ncand[frame * P.nlevels + level] = (int)n;
+    __syncthreads();
+    if (n == 0) { if (tid == 0) *nsel = 0; return; }
+
+    // ---- root nodes (:536-572) ----
+    int cur = 0, S = 0;
+    const int H = G.h - 32;
+    for (int i = tid; i < MAXNODE; i += OCT_NT) { s_cnt[0][i] = 0; s_crank[0][i] = -1; }
+    __syncthreads();
+    for (unsigned k = tid; k < n; k += OCT_NT) {
+        const unsigned key = keys[k];
+        const int ini = (int)((float)(key & 0xFFF) / G.hX);
+        atomicAdd(&s_cnt[0][ini], 1u);
+        knode[k] = (uint16_t)ini;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int s = 0;
+        for (int i = 0; i < G.nIni; i++) {
+            const unsigned c = s_cnt[0][i];
+            s_L[i] = (unsigned short)s;
+            if (c) {
+                Rect r; r.x0 = (short)(int)(G.hX * (float)i); r.x1 = (short)(int)(G.hX * (float)(i + 1)); r.y0 = 0; r.y1 = (short)H;
+                s_rect[1][s] = r; s_cnt[1][s] = c; s_crank[1][s] = -1;
+                s++;
+            }
+        }
+        s_misc[0] = s;
+    }
+    __syncthreads();
+    S = s_misc[0];
+    for (unsigned k = tid; k < n; k += OCT_NT) knode[k] = s_L[knode[k]];
+    cur = 1;
+    __syncthreads();
+
+    bool careful = false;
+    // ---- full rounds (:580-640) ----
+    while (true) {
+        const int prevS = S;
+        Rect *rect = s_rect[cur]; unsigned *cnt = s_cnt[cur];
+        Rect *nrect = s_rect[cur ^ 1]; unsigned *ncnt = s_cnt[cur ^ 1]; short *ncrank = s_crank[cur ^ 1];
+        for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
+        __syncthreads();
+        for (unsigned k = tid; k < n; k += OCT_NT) {
+            const int i = knode[k];
+            if (cnt[i] > 1) {
+                const unsigned key = keys[k];
+                atomicAdd(&s_cc[4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF)], 1u);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < 4 * S; j += OCT_NT) {
+            const unsigned c = cnt[j >> 2] > 1 ? s_cc[j] : 0;
+            s_F[j] = c > 0; s_G[j] = c > 1;
+        }
+        for (int i = tid; i < S; i += OCT_NT) s_L[i] = cnt[i] == 1;
+        __syncthreads();
+        block_scan_array_incl(s_F, 4 * S, s_wave);
+        block_scan_array_incl(s_G, 4 * S, s_wave);
+        block_scan_array_incl(s_L, S, s_wave);
+        const int Ctot = s_F[4 * S - 1], nToExpand = s_G[4 * S - 1], Ltot = s_L[S - 1];
+        const int S2 = Ctot + Ltot;
+        if (S2 > MAXNODE) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        for (int j = tid; j < 4 * S; j += OCT_NT) {
+            const unsigned c = cnt[j >> 2] > 1 ? s_cc[j] : 0;
+            if (c) {
+                const int pos = Ctot - s_F[j];
+                nrect[pos] = child_rect(rect[j >> 2], j & 3);
+                ncnt[pos] = c;
+                ncrank[pos] = c > 1 ? (short)(s_G[j] - 1) : (short)-1;
+            }
+        }
+        for (int i = tid; i < S; i += OCT_NT)
+            if (cnt[i] == 1) {
+                const int pos = Ctot + s_L[i] - 1;
+                nrect[pos] = rect[i]; ncnt[pos] = 1; ncrank[pos] = -1;
+            }
+        for (unsigned k = tid; k < n; k += OCT_NT) {
+            const int i = knode[k];
+            if (cnt[i] > 1) {
+                const unsigned key = keys[k];
+                const int j = 4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF);
+                knode[k] = (uint16_t)(Ctot - s_F[j]);
+            } else {
+                knode[k] = (uint16_t)(Ctot + s_L[i] - 1);
+            }
+        }
+        __syncthreads();
+        cur ^= 1; S = S2;
+        if (S >= N || S == prevS) break;
+        if (S + 3 * nToExpand > N) { careful = true; break; }
+    }
+
+    // ---- careful mode (:641-700) ----
+    while (careful) {
+        const int prevS = S;
+        Rect *rect = s_rect[cur]; unsigned *cnt = s_cnt[cur]; short *crank = s_crank[cur];
+        Rect *nrect = s_rect[cur ^ 1]; unsigned *ncnt = s_cnt[cur ^ 1]; short *ncrank = s_crank[cur ^ 1];
+        for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
+        for (int i = tid; i < S; i += OCT_NT) s_rankOf[i] = 0xFFFF;
+        __syncthreads();
+        for (unsigned k = tid; k < n; k += OCT_NT) {
+            const int i = knode[k];
+            if (crank[i] >= 0) {
+                const unsigned key = keys[k];
+                atomicAdd(&s_cc[4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF)], 1u);
+            }
+        }
+        __syncthreads();
+        // rank = number of candidates that sort before: larger (size, creation rank) first
+        int m = 0;
+        for (int i = tid; i < S; i += OCT_NT) {
+            if (crank[i] < 0) continue;
+            const unsigned long long me = ((unsigned long long)cnt[i] << 16) | (unsigned)crank[i];
+            int r = 0;
+            for (int i2 = 0; i2 < S; i2++)
+                if (crank[i2] >= 0 && (((unsigned long long)cnt[i2] << 16) | (unsigned)crank[i2]) > me) r++;
+            s_order[r] = (unsigned short)i;
+            s_rankOf[i] = (unsigned short)r;
+        }
+        if (tid == 0) s_misc[1] = 0;
+        __syncthreads();
+        {
+            int local = 0;
+            for (int i = tid; i < S; i += OCT_NT) local += crank[i] >= 0;
+            if (local) atomicAdd(&s_misc[1], local);
+        }
+        __syncthreads();
+        m = s_misc[1];
+        if (m == 0) break;  // nothing to expand: size unchanged -> finish
+        // growth prefix in sorted order -> number of expansions J
+        for (int r = tid; r < m; r += OCT_NT) {
+            const int i = s_order[r];
+            s_L[r] = (unsigned short)((s_cc[4 * i] > 0) + (s_cc[4 * i + 1] > 0) + (s_cc[4 * i + 2] > 0) + (s_cc[4 * i + 3] > 0));
+        }
+        if (tid == 0) s_misc[2] = m;
+        __syncthreads();
+        block_scan_array_incl(s_L, m, s_wave);   // s_L[r] = sum of child counts of the first r+1 expansions
+        for (int r = tid; r < m; r += OCT_NT)
+            if (S + (int)s_L[r] - (r + 1) >= N) atomicMin(&s_misc[2], r + 1);
+        __syncthreads();
+        const int J = s_misc[2];
+        // children of the J expanded nodes, flat index jj = 4*r + q in sorted order
+        for (int jj = tid; jj < 4 * J; jj += OCT_NT) {
+            const unsigned c = s_cc[4 * s_order[jj >> 2] + (jj & 3)];
+            s_F[jj] = c > 0; s_G[jj] = c > 1;
+        }
+        __syncthreads();
+        for (int i = tid; i < S; i += OCT_NT) s_L[i] = !(s_rankOf[i] < J);
+        __syncthreads();
+        block_scan_array_incl(s_F, 4 * J, s_wave);
+        block_scan_array_incl(s_G, 4 * J, s_wave);
+        block_scan_array_incl(s_L, S, s_wave);
+        const int Ctot = s_F[4 * J - 1];
+        const int S2 = Ctot + (S - J);
+        if (S2 > MAXNODE) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        for (int jj = tid; jj < 4 * J; jj += OCT_NT) {
+            const int i = s_order[jj >> 2];
+            const unsigned c = s_cc[4 * i + (jj & 3)];
+            if (c) {
+                const int pos = Ctot - s_F[jj];
+                nrect[pos] = child_rect(rect[i], jj & 3);
+                ncnt[pos] = c;
+                ncrank[pos] = c > 1 ? (short)(s_G[jj] - 1) : (short)-1;
+            }
+        }
+        for (int i = tid; i < S; i += OCT_NT)
+            if (!(s_rankOf[i] < J)) {
+                const int pos = Ctot + s_L[i] - 1;
+                nrect[pos] = rect[i]; ncnt[pos] = cnt[i]; ncrank[pos] = -1;
+            }
+        for (unsigned k = tid; k < n; k += OCT_NT) {
+            const int i = knode[k];
+            const int r = s_rankOf[i];
+            if (r < J) {
+                const unsigned key = keys[k];
+                const int jj = 4 * r + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF);
+                knode[k] = (uint16_t)(Ctot - s_F[jj]);
+            } else {
+                knode[k] = (uint16_t)(Ctot + s_L[i] - 1);
+            }
+        }
+        __syncthreads();
+        cur ^= 1; S = S2;
+        if (S >= N || S == prevS) break;
+    }
+
+    // ---- keep the best key of every node (:703-718) ----
+    unsigned *best = s_cc;
+    for (int i = tid; i < S; i += OCT_NT) best[i] = 0;
+    __syncthreads();
+    for (unsigned k = tid; k < n; k += OCT_NT)
+        atomicMax(&best[knode[k]], (keys[k] & 0xFF000000u) | (0xFFFFFFu - k));
+    __syncthreads();
+    if (S > P.selCap) { if (tid == 0) { atomicExch(P.err, 2); *nsel = 0; } return; }
+    for (int i = tid; i < S; i += OCT_NT) sel[i] = keys[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+    if (tid == 0) *nsel = S;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_blur: GaussianBlur 7x7 sigma 2 (integer kernel {18,34,49,55,49,34,18}, >>16 with rounding),
+// reflect-101 on the level's own borders.  Tile 64 x 32 outputs per workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int BT_W = 64, BT_H = 32;
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_blur(OrbDev P) {
+    __shared__ uint8_t s_in[(BT_H + 6) * (BT_W + 8)];
+    __shared__ unsigned short s_row[(BT_H + 6) * BT_W];
+    const int frame = blockIdx.y, tid = threadIdx.x;
+    int l = 0;
+    while (l + 1 < P.nlevels && (int)blockIdx.x >= P.lv[l + 1].tileBase) l++;
+    const LevelDev &D = P.lv[l];
+    const int t = blockIdx.x - D.tileBase;
+    const int tx0 = (t % D.tilesX) * BT_W, ty0 = (t / D.tilesX) * BT_H;
+    int pitch;
+    const uint8_t *img = level_ptr(P, frame, l, pitch);
+    constexpr int IP = BT_W + 8;
+    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
+        const int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
+        const int y = reflect101(ty0 + r - 3, D.h), x = reflect101(tx0 + c - 3, D.w);
+        s_in[r * IP + c] = img[(size_t)y * pitch + x];
+    }
+    __syncthreads();
+    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
+        const int r = i / BT_W, c = i - r * BT_W;
+        const uint8_t *p = &s_in[r * IP + c];
+        s_row[i] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    }
+    __syncthreads();
+    uint8_t *out = P.blur + (size_t)frame * P.blurStride + D.boff;
+    for (int i = tid; i < BT_H * BT_W; i += 256) {
+        const int r = i / BT_W, c = i - r * BT_W;
+        const int x = tx0 + c, y = ty0 + r;
+        if (x >= D.w || y >= D.h) continue;
+        const unsigned short *p = &s_row[r * BT_W + c];
+        const int acc = 18 * (p[0] + p[6 * BT_W]) + 34 * (p[BT_W] + p[5 * BT_W]) + 49 * (p[2 * BT_W] + p[4 * BT_W]) + 55 * p[3 * BT_W];
+        out[(size_t)y * D.pitch + x] = (uint8_t)min((acc + 32768) >> 16, 255);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_describe: one wave per selected keypoint: IC_Angle, pinned sincos, steered BRIEF, output.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Pinned replacement for cosf/sinf at src/ORBextractor.cc:108 (DESIGN.md "pinned sincos").
+__device__ __forceinline__ void sincos_pinned(float angle, float *s_out, float *c_out) {
+    const double x = (double)angle;
+    const double kd = floor(x * 6.36619772367581382433e-01 + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * 1.57079632673412561417e+00) - kd * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double v = z * r;
+    const double sr = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sn = r + v * (S1 + z * sr);
+    const double cr = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double cs = 1.0 - (0.5 * z - z * cr);
+    double s, c;
+    switch (k & 3) {
+        case 0: s = sn; c = cs; break;
+        case 1: s = cs; c = -sn; break;
+        case 2: s = -sn; c = -cs; break;
+        default: s = -cs; c = sn; break;
+    }
+    *s_out = (float)s;
+    *c_out = (float)c;
+}
+
+__global__ __launch_bounds__(256) void k_describe(OrbDev P) {
+    const int frame = blockIdx.z, level = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int *nsel = P.nsel + frame * P.nlevels;
+    if (blockIdx.x == 0 && level == 0 && threadIdx.x == 0) {
+        int tot = 0;
+        for (int l = 0; l < P.nlevels; l++) tot += nsel[l];
+        P.nout[frame] = min(tot, P.outCap);
+        if (tot > P.outCap) atomicExch(P.err, 3);
+    }
+    if (idx >= nsel[level]) return;
+    int outIdx = idx;
+    for (int l = 0; l < level; l++) outIdx += nsel[l];
+    if (outIdx >= P.outCap) return;
+    const LevelDev &D = P.lv[level];
+    const unsigned key = P.sel[((size_t)frame * P.nlevels + level) * P.selCap + idx];
+    const int x = (int)(key & 0xFFF) + 16, y = (int)((key >> 12) & 0xFFF) + 16;  // :793-794
+    const int score = key >> 24;
+    int pitch;
+    const uint8_t *img = level_ptr(P, frame, level, pitch);
+    // IC_Angle (:75-99): m10 = sum u*I, m01 = sum v*I over the circular patch
+    int m10 = 0, m01 = 0;
+    {
+        const int u = (lane & 31) - 15;
+        const int au = u < 0 ? -u : u;
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int v = -15 + 2 * it + (lane >> 5);
+            const int av = v < 0 ? -v : v;
+            if (av <= 15 && au <= 15 && au <= P.umax[av]) {
+                const int val = img[(size_t)(y + v) * pitch + x + u];
+                m10 += u * val;
+                m01 += v * val;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            m10 += __shfl_xor(m10, d, 64);
+            m01 += __shfl_xor(m01, d, 64);
+        }
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+    const float factorPI = (float)(M_PI / 180.f);
+    float a, b;
+    sincos_pinned(angle * factorPI, &b, &a);
+    // steered BRIEF (:104-149): lane handles test pairs 4*lane .. 4*lane+3
+    const uint8_t *bl = P.blur + (size_t)frame * P.blurStride + D.boff + (size_t)y * D.pitch + x;
+    unsigned nib = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int8_t *pp = &c_pattern[(4 * lane + j) * 4];
+        const float x0 = (float)pp[0], y0 = (float)pp[1], x1 = (float)pp[2], y1 = (float)pp[3];
+        const int r0 = __float2int_rn(x0 * b + y0 * a), c0 = __float2int_rn(x0 * a - y0 * b);
+        const int r1 = __float2int_rn(x1 * b + y1 * a), c1 = __float2int_rn(x1 * a - y1 * b);
+        const int t0 = bl[r0 * D.pitch + c0], t1 = bl[r1 * D.pitch + c1];
+        nib |= (t0 < t1 ? 1u : 0u) << j;
+    }
+    unsigned w = nib | (__shfl_down(nib, 1, 64) << 4);
+    w |= __shfl_down(w, 2, 64) << 8;
+    w |= __shfl_down(w, 4, 64) << 16;
+    msl_keypoint *kp = P.kps + (size_t)frame * P.outCap + outIdx;
+    uint32_t *dsc = (uint32_t *)(P.desc + ((size_t)frame * P.outCap + outIdx) * 32);
+    if ((lane & 7) == 0) dsc[lane >> 3] = w;
+    if (lane == 0) {
+        float fx = (float)x, fy = (float)y;
+        if (level != 0) { fx *= D.scale; fy *= D.scale; }  // :861-866
+        kp->x = fx; kp->y = fy; kp->size = (float)D.patch; kp->angle = angle;
+        kp->response = (float)score; kp->octave = level; kp->class_id = -1;
+    }
+}
+
+// =============================================================================================
+// Host side
+// =============================================================================================
+inline int cv_round_f(float v) { return (int)lrintf(v); }
+inline int cv_round_d(double v) { return (int)lrint(v); }
+inline int cv_floor_d(double v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
+
+enum { KID_RESIZE = 0, KID_FAST, KID_OCTREE, KID_BLUR, KID_DESCRIBE, KID_COPY };
+const char *kKernelNames[MSL_ORB_NKERNELS] = {"k_resize", "k_fast", "k_octree", "k_blur", "k_describe", "copy"};
+
+}  // namespace
+
+struct msl_orb {
+    int device = 0;
+    int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, maxW = 0, maxH = 0, maxBatch = 0;
+    double scaleFactor = 0;
+    std::vector<float> scale, invScale, sigma2, invSigma2;
+    std::vector<int> perLevel;
+    int umax[16];
+    // geometry is built for one frame size at a time (rebuilt if the size changes)
+    int geomW = 0, geomH = 0;
+    OrbDev dev{};
+    hipStream_t stream = nullptr; bool ownStream = true;
+    // device allocations
+    uint8_t *d_in = nullptr; size_t inPitch = 0;
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr;
+    CellDev *d_cells = nullptr; ResizeTap *d_taps = nullptr;
+    uint32_t *d_cellCnt = nullptr, *d_cellKeys = nullptr, *d_keys = nullptr; uint16_t *d_knode = nullptr;
+    uint32_t *d_sel = nullptr; int *d_nsel = nullptr, *d_ncand = nullptr;
+    msl_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_nout = nullptr; int *d_err = nullptr;
+    int *h_err = nullptr;  // pinned
+    int lastFrames = 0;
+    KernelProfiler prof;
+};
+
+namespace {
+
+void free_geometry(msl_orb *h) {
+    auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(h->d_in); F(h->d_pyr); F(h->d_blur); F(h->d_cells); F(h->d_taps); F(h->d_cellCnt); F(h->d_cellKeys);
+    F(h->d_keys); F(h->d_knode); F(h->d_sel); F(h->d_nsel); F(h->d_ncand); F(h->d_kps); F(h->d_desc); F(h->d_nout);
+    h->geomW = h->geomH = 0;
+}
+
+// Level sizes, FAST cell grid, quadtree roots, resize taps, blur tiling for a w x h frame.
+int build_geometry(msl_orb *h, int W, int H) {
+    if (h->geomW == W && h->geomH == H) return MSL_OK;
+    free_geometry(h);
+    OrbDev &D = h->dev;
+    memset(&D, 0, sizeof(D));
+    const int L = h->nlevels, B = h->maxBatch;
+    D.nlevels = L; D.iniTh = h->iniTh; D.minTh = h->minTh;
+    for (int i = 0; i < 16; i++) D.umax[i] = h->umax[i];
+    std::vector<CellDev> cells;
+    std::vector<ResizeTap> taps;
+    size_t pyrOff = 0, blurOff = 0;
+    unsigned keyOff = 0;
+    int tileBase = 0, maxQuota = 0;
+    for (int l = 0; l < L; l++) {
+        LevelDev &G = D.lv[l];
+        const float s = h->invScale[l];
+        G.w = cv_round_f((float)W * s); G.h = cv_round_f((float)H * s);    // src/ORBextractor.cc:875
+        G.pitch = (G.w + 63) & ~63;
+        G.scale = h->scale[l];
+        G.patch = (int)(31 * h->scale[l]);                                  // :788
+        G.quota = h->perLevel[l];
+        maxQuota = std::max(maxQuota, G.quota);
+        if (l > 0) { G.off = (unsigned)pyrOff; pyrOff += (size_t)G.pitch * G.h; }
+        G.boff = (unsigned)blurOff; blurOff += (size_t)G.pitch * G.h;
+        // FAST cell grid (:728-743)
+        const int minB = 16, maxBX = G.w - 16, maxBY = G.h - 16;
+        const float width = (float)(maxBX - minB), height = (float)(maxBY - minB);
+        const float Wc = 30;
+        G.nCols = (int)(width / Wc); G.nRows = (int)(height / Wc);
+        if (G.nCols < 1 || G.nRows < 1) {
+            set_error("level %d (%dx%d) is too small for the 30-px FAST grid", l, G.w, G.h);
+            return MSL_ERR_INVALID;
+        }
+        G.wCell = (int)ceilf(width / G.nCols); G.hCell = (int)ceilf(height / G.nRows);
+        if (G.wCell > MAXCELL || G.hCell > MAXCELL || G.w > 4095 + 16 || G.h > 4095 + 16) {
+            set_error("unsupported level geometry %dx%d (cell %dx%d)", G.w, G.h, G.wCell, G.hCell);
+            return MSL_ERR_INVALID;
+        }
+        G.cellBase = (int)cells.size(); G.nCells = G.nRows * G.nCols;
+        G.keyBase = (int)keyOff;
+        for (int i = 0; i < G.nRows; i++)
+            for (int j = 0; j < G.nCols; j++) {
+                // view = rows [iniY,maxY) x cols [iniX,maxX); cv::FAST computes its inner 3-px-inset region
+                const float iniY = (float)(minB + i * G.hCell), iniX = (float)(minB + j * G.wCell);
+                float maxY = iniY + G.hCell + 6, maxX = iniX + G.wCell + 6;
+                CellDev c{}; c.level = (short)l; c.keyOff = keyOff;
+                const bool skip = (iniY >= maxBY - 3) || (iniX >= maxBX - 6);
+                if (maxY > maxBY) maxY = (float)maxBY;
+                if (maxX > maxBX) maxX = (float)maxBX;
+                const int cw = (int)maxX - (int)iniX - 6, chh = (int)maxY - (int)iniY - 6;
+                if (!skip && cw > 0 && chh > 0) {
+                    c.x0 = (short)((int)iniX + 3); c.y0 = (short)((int)iniY + 3); c.cw = (short)cw; c.ch = (short)chh;
+                    keyOff += (unsigned)(((cw + 1) / 2) * ((chh + 1) / 2));  // strict 3x3 maxima are non-adjacent
+                }
+                cells.push_back(c);
+            }
+        G.keyCap = (int)keyOff - G.keyBase;
+        if (G.keyCap >= (1 << 24)) { set_error("level too large"); return MSL_ERR_INVALID; }
+        // quadtree roots (:536-552)
+        G.nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
+        if (G.nIni < 1) { set_error("unsupported aspect ratio (nIni = 0)"); return MSL_ERR_INVALID; }
+        G.hX = (float)(maxBX - minB) / G.nIni;
+        if (std::max(G.quota, 4 * G.nIni) + 2 > MAXNODE) { set_error("per-level quota %d exceeds %d", G.quota, MAXNODE - 2); return MSL_ERR_INVALID; }
+        // blur tiles
+        G.tilesX = (G.w + BT_W - 1) / BT_W; G.tilesY = (G.h + BT_H - 1) / BT_H;
+        G.tileBase = tileBase; tileBase += G.tilesX * G.tilesY;
+        // resize taps (cv::resize INTER_LINEAR 8U tables)
+        if (l > 0) {
+            const int sw = D.lv[l - 1].w, sh = D.lv[l - 1].h;
+            const double scale_x = 1. / ((double)G.w / sw), scale_y = 1. / ((double)G.h / sh);
+            G.xtabOff = (unsigned)taps.size();
+            for (int dx = 0; dx < G.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = cv_floor_d(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                ResizeTap t;
+                t.s0 = (short)sx; t.s1 = (short)std::min(sx + 1, sw - 1);
+                t.c0 = (short)std::min(std::max(cv_round_f((1.f - fx) * 2048), -32768), 32767);
+                t.c1 = (short)std::min(std::max(cv_round_f(fx * 2048), -32768), 32767);
+                if (sx + 1 >= sw) { t.c0 = 2048; t.c1 = 0; }
+                taps.push_back(t);
+            }
+            G.ytabOff = (unsigned)taps.size();
+            for (int dy = 0; dy < G.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = cv_floor_d(fy);
+                fy -= sy;
+                ResizeTap t;
+                t.s0 = (short)std::min(std::max(sy, 0), sh - 1); t.s1 = (short)std::min(std::max(sy + 1, 0), sh - 1);
+                t.c0 = (short)std::min(std::max(cv_round_f((1.f - fy) * 2048), -32768), 32767);
+                t.c1 = (short)std::min(std::max(cv_round_f(fy * 2048), -32768), 32767);
+                taps.push_back(t);
+            }
+        }
+    }
+    D.cellsPerFrame = (int)cells.size();
+    D.keysPerFrame = (int)keyOff;
+    D.selCap = maxQuota + 2;
+    D.outCap = h->nfeatures + 2 * L;
+    D.blurTiles = tileBase;
+    D.pyrStride = (pyrOff + 255) & ~(size_t)255;
+    D.blurStride = (blurOff + 255) & ~(size_t)255;
+    h->inPitch = (size_t)((W + 63) & ~63);
+
+    MSL_HIP_TRY(hipMalloc(&h->d_in, h->inPitch * H * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_pyr, std::max<size_t>(D.pyrStride, 256) * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_blur, D.blurStride * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_cells, sizeof(CellDev) * cells.size()));
+    MSL_HIP_TRY(hipMalloc(&h->d_taps, sizeof(ResizeTap) * std::max<size_t>(taps.size(), 1)));
+    MSL_HIP_TRY(hipMalloc(&h->d_cellCnt, sizeof(uint32_t) * cells.size() * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_cellKeys, sizeof(uint32_t) * (size_t)keyOff * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_keys, sizeof(uint32_t) * (size_t)keyOff * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_knode, sizeof(uint16_t) * (size_t)keyOff * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_sel, sizeof(uint32_t) * (size_t)D.selCap * L * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_nsel, sizeof(int) * L * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_ncand, sizeof(int) * L * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_kps, sizeof(msl_keypoint) * (size_t)D.outCap * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_desc, (size_t)32 * D.outCap * B));
+    MSL_HIP_TRY(hipMalloc(&h->d_nout, sizeof(int) * B));
+    MSL_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDev) * cells.size(), hipMemcpyHostToDevice));
+    if (!taps.empty())
+        MSL_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
+    D.pyr = h->d_pyr; D.blur = h->d_blur; D.cells = h->d_cells; D.taps = h->d_taps;
+    D.cellCnt = h->d_cellCnt; D.cellKeys = h->d_cellKeys; D.keys = h->d_keys; D.knode = h->d_knode;
+    D.sel = h->d_sel; D.nsel = h->d_nsel; D.ncand = h->d_ncand; D.err = h->d_err;
+    h->geomW = W; h->geomH = H;
+    return MSL_OK;
+}
+
+// Launch the whole pipeline for n frames whose pixels are already on the device.
+int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t frameStride, int n,
+                    msl_keypoint *d_kps, uint8_t *d_desc, int *d_nout) {
+    OrbDev P = h->dev;
+    P.in = d_gray; P.inRowStride = rowStride; P.inFrameStride = frameStride;
+    P.kps = d_kps; P.desc = d_desc; P.nout = d_nout;
+    hipStream_t s = h->stream;
+    const int L = h->nlevels;
+    for (int l = 1; l < L; l++) {
+        const LevelDev &G = P.lv[l];
+        h->prof.begin(KID_RESIZE, s);
+        hipLaunchKernelGGL(k_resize, dim3((G.w + 63) / 64, (G.h + 3) / 4, n), dim3(256), 0, s, P, l);
+        h->prof.end(s);
+    }
+    h->prof.begin(KID_FAST, s);
+    hipLaunchKernelGGL(k_fast, dim3(P.cellsPerFrame, n), dim3(256), 0, s, P);
+    h->prof.end(s);
+    h->prof.begin(KID_OCTREE, s);
+    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), 0, s, P);
+    h->prof.end(s);
+    h->prof.begin(KID_BLUR, s);
+    hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);
+    h->prof.end(s);
+    h->prof.begin(KID_DESCRIBE, s);
+    hipLaunchKernelGGL(k_describe, dim3((P.selCap + 3) / 4, L, n), dim3(256), 0, s, P);
+    h->prof.end(s);
+    MSL_HIP_TRY(hipGetLastError());
+    h->lastFrames = n;
+    return MSL_OK;
+}
+
+int check_device_error(msl_orb *h) {
+    MSL_HIP_TRY(hipMemcpyAsync(h->h_err, h->d_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prof.drain();
+    if (*h->h_err) {
+        const int e = *h->h_err;
+        (void)hipMemsetAsync(h->d_err, 0, sizeof(int), h->stream);
+        set_error("device-side bound exceeded in ORB pipeline (code %d)", e);
+        return MSL_ERR_OVERFLOW;
+    }
+    return MSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniThFAST, int minThFAST, int max_width,
+                        int max_height, int max_batch, int device) {
+    if (nfeatures < 1 || nlevels < 1 || nlevels > ML || !(scaleFactorF > 1.0f) || iniThFAST < 1 || iniThFAST > 255 ||
+        minThFAST < 1 || minThFAST > 255 || max_width < 1 || max_height < 1 || max_batch < 1) {
+        set_error("msl_orb_create: invalid argument");
+        return nullptr;
+    }
+    if (bind_device(device) != MSL_OK) return nullptr;
+    msl_orb *h = new msl_orb;
+    h->device = device; h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = iniThFAST; h->minTh = minThFAST;
+    h->maxW = max_width; h->maxH = max_height; h->maxBatch = max_batch;
+    h->scaleFactor = scaleFactorF;  // include/ORBextractor.h:97 keeps it as double
+    // scale tables and per-level quotas, src/ORBextractor.cc:416-445
+    h->scale.resize(nlevels); h->sigma2.resize(nlevels); h->invScale.resize(nlevels); h->invSigma2.resize(nlevels);
+    h->scale[0] = 1.0f; h->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        h->scale[i] = (float)(h->scale[i - 1] * h->scaleFactor);
+        h->sigma2[i] = h->scale[i] * h->scale[i];
+    }
+    for (int i = 0; i < nlevels; i++) { h->invScale[i] = 1.0f / h->scale[i]; h->invSigma2[i] = 1.0f / h->sigma2[i]; }
+    h->perLevel.resize(nlevels);
+    const float factor = (float)(1.0f / h->scaleFactor);
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        h->perLevel[level] = cv_round_f(nDesired);
+        sum += h->perLevel[level];
+        nDesired *= factor;
+    }
+    h->perLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+    // circular patch row ends, :453-467
+    {
+        int v, v0;
+        const int vmax = cv_floor_d(15 * sqrtf(2.f) / 2 + 1), vmin = cv_ceil_d(15 * sqrtf(2.f) / 2);
+        for (v = 0; v < 16; v++) h->umax[v] = 0;
+        for (v = 0; v <= vmax; ++v) h->umax[v] = cv_round_d(sqrt(225.0 - v * v));
+        for (v = 15, v0 = 0; v >= vmin; --v) {
+            while (h->umax[v0] == h->umax[v0 + 1]) ++v0;
+            h->umax[v] = v0;
+            ++v0;
+        }
+    }
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&h->d_err, sizeof(int)) != hipSuccess || hipMemset(h->d_err, 0, sizeof(int)) != hipSuccess ||
+        hipHostMalloc(&h->h_err, sizeof(int)) != hipSuccess) {
+        set_error("msl_orb_create: HIP resource allocation failed");
+        msl_orb_destroy(h);
+        return nullptr;
+    }
+    h->prof.nk = MSL_ORB_NKERNELS;
+    if (build_geometry(h, max_width, max_height) != MSL_OK) { msl_orb_destroy(h); return nullptr; }
+    return h;
+}
+
+void msl_orb_destroy(msl_orb *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->prof.destroy();
+    free_geometry(h);
+    if (h->d_err) (void)hipFree(h->d_err);
+    if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->stream && h->ownStream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int msl_orb_scale_tables(const msl_orb *h, float *sf, float *isf, float *s2, float *is2) {
+    if (!h) return MSL_ERR_INVALID;
+    for (int i = 0; i < h->nlevels; i++) {
+        if (sf) sf[i] = h->scale[i];
+        if (isf) isf[i] = h->invScale[i];
+        if (s2) s2[i] = h->sigma2[i];
+        if (is2) is2[i] = h->invSigma2[i];
+    }
+    return MSL_OK;
+}
+int msl_orb_features_per_level(const msl_orb *h, int32_t *out) {
+    if (!h || !out) return MSL_ERR_INVALID;
+    for (int i = 0; i < h->nlevels; i++) out[i] = h->perLevel[i];
+    return MSL_OK;
+}
+int msl_orb_capacity(const msl_orb *h) { return h ? h->nfeatures + 2 * h->nlevels : MSL_ERR_INVALID; }
+int msl_orb_levels(const msl_orb *h) { return h ? h->nlevels : MSL_ERR_INVALID; }
+
+int msl_orb_set_stream(msl_orb *h, void *hip_stream) {
+    if (!h) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->ownStream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream; h->ownStream = false;
+    return MSL_OK;
+}
+
+int msl_orb_sync(msl_orb *h) {
+    if (!h) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    return check_device_error(h);
+}
+
+int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int width, int height, size_t row_stride,
+                          size_t frame_stride, msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
+                          int32_t *n_out, msl_mem out_mem) {
+    if (!h || !n_out || n_frames < 0) { set_error("msl_orb_extract_batch: invalid argument"); return MSL_ERR_INVALID; }
+    if (n_frames == 0) return MSL_OK;
+    if (!gray || width == 0 || height == 0) {  // empty image: silent return (src/ORBextractor.cc:815-816)
+        if (out_mem == MSL_MEM_HOST) for (int f = 0; f < n_frames; f++) n_out[f] = 0;
+        else { MSL_HIP_TRY(hipSetDevice(h->device)); MSL_HIP_TRY(hipMemsetAsync(n_out, 0, sizeof(int) * n_frames, h->stream)); }
+        return MSL_OK;
+    }
+    if (n_frames > h->maxBatch || width > h->maxW || height > h->maxH || row_stride < (size_t)width || !kps || !desc32) {
+        set_error("msl_orb_extract_batch: frame %dx%d x%d exceeds the handle's limits (%dx%d x%d) or bad pointers", width,
+                  height, n_frames, h->maxW, h->maxH, h->maxBatch);
+        return MSL_ERR_INVALID;
+    }
+    const int outCap = h->nfeatures + 2 * h->nlevels;
+    if (cap < outCap) { set_error("msl_orb_extract_batch: cap %d < required %d", cap, outCap); return MSL_ERR_CAPACITY; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = build_geometry(h, width, height);
+    if (rc != MSL_OK) return rc;
+    const uint8_t *d_gray = gray; size_t rs = row_stride, fs = frame_stride;
+    if (in_mem == MSL_MEM_HOST) {
+        h->prof.begin(KID_COPY, h->stream);
+        for (int f = 0; f < n_frames; f++)
+            MSL_HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * h->inPitch * height, h->inPitch, gray + (size_t)f * frame_stride,
+                                         row_stride, width, height, hipMemcpyHostToDevice, h->stream));
+        h->prof.end(h->stream);
+        d_gray = h->d_in; rs = h->inPitch; fs = h->inPitch * height;
+    }
+    if (out_mem == MSL_MEM_DEVICE && cap == outCap) {
+        return launch_pipeline(h, d_gray, rs, fs, n_frames, kps, desc32, n_out);
+    }
+    rc = launch_pipeline(h, d_gray, rs, fs, n_frames, h->d_kps, h->d_desc, h->d_nout);
+    if (rc != MSL_OK) return rc;
+    const hipMemcpyKind kind = out_mem == MSL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    MSL_HIP_TRY(hipMemcpyAsync(n_out, h->d_nout, sizeof(int) * n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(kps, sizeof(msl_keypoint) * cap, h->d_kps, sizeof(msl_keypoint) * outCap,
+                                 sizeof(msl_keypoint) * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(desc32, (size_t)32 * cap, h->d_desc, (size_t)32 * outCap, (size_t)32 * outCap, n_frames, kind,
+                                 h->stream));
+    if (out_mem == MSL_MEM_HOST) return check_device_error(h);
+    return MSL_OK;
+}
+
+int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride, msl_keypoint *kps,
+                    uint8_t *desc32, int cap, int *n_out) {
+    if (!n_out) { set_error("msl_orb_extract: n_out is NULL"); return MSL_ERR_INVALID; }
+    int32_t n = 0;
+    const int rc = msl_orb_extract_batch(h, gray, 1, width, height, stride, stride * (size_t)height, MSL_MEM_HOST, kps, desc32,
+                                         cap, &n, MSL_MEM_HOST);
+    *n_out = n;
+    return rc;
+}
+
+int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out) {
+    if (!h || level < 0 || level >= h->nlevels) return MSL_ERR_INVALID;
+    *w = h->dev.lv[level].w; *h_out = h->dev.lv[level].h;
+    return MSL_OK;
+}
+
+int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out) {
+    if (!h || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) return MSL_ERR_INVALID;
+    if (level == 0 && !blurred) { set_error("level 0 is the caller's image"); return MSL_ERR_INVALID; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    const LevelDev &G = h->dev.lv[level];
+    const uint8_t *src = blurred ? h->d_blur + (size_t)frame * h->dev.blurStride + G.boff
+                                 : h->d_pyr + (size_t)frame * h->dev.pyrStride + G.off;
+    MSL_HIP_TRY(hipMemcpy2D(out, G.w, src, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
+    return MSL_OK;
+}
+
+int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys, int cap, int *n_out) {
+    if (!h || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    int n = 0;
+    MSL_HIP_TRY(hipMemcpy(&n, h->d_ncand + frame * h->nlevels + level, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (n > cap) return MSL_ERR_CAPACITY;
+    std::vector<uint32_t> k(n);
+    if (n) MSL_HIP_TRY(hipMemcpy(k.data(), h->d_keys + (size_t)frame * h->dev.keysPerFrame + h->dev.lv[level].keyBase,
+                                 sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        xys[3 * i] = (int)(k[i] & 0xFFF) + 16; xys[3 * i + 1] = (int)((k[i] >> 12) & 0xFFF) + 16; xys[3 * i + 2] = (int)(k[i] >> 24);
+    }
+    return MSL_OK;
+}
+
+int msl_orb_profile_enable(msl_orb *h, int on) {
+    if (!h) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prof.drain();
+    h->prof.on = on != 0;
+    for (int i = 0; i < 16; i++) { h->prof.ms[i] = 0; h->prof.launches[i] = 0; }
+    return MSL_OK;
+}
+int msl_orb_profile_read(msl_orb *h, float *ms, int32_t *launches) {
+    if (!h) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    h->prof.drain();
+    for (int i = 0; i < MSL_ORB_NKERNELS; i++) { if (ms) ms[i] = h->prof.ms[i]; if (launches) launches[i] = h->prof.launches[i]; }
+    return MSL_OK;
+}
+const char *msl_orb_kernel_name(int k) { return (k >= 0 && k < MSL_ORB_NKERNELS) ? kKernelNames[k] : ""; }
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""ctypes access to oracle/libmsl_oracle.so -- the CPU checker.  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+OLIB = os.path.join(ODIR, "libmsl_oracle.so")
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+SURFEL_DTYPE = np.dtype([("px", "<f4"), ("py", "<f4"), ("pz", "<f4"), ("nx", "<f4"), ("ny", "<f4"),
+                         ("nz", "<f4"), ("size", "<f4"), ("color", "<f4"), ("r", "<i4"), ("g", "<i4"),
+                         ("b", "<i4"), ("weight", "<f4"), ("updateTimes", "<i4"), ("lastUpdate", "<i4")])
+SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<f4"), ("normY", "<f4"),
+                       ("normZ", "<f4"), ("posX", "<f4"), ("posY", "<f4"), ("posZ", "<f4"),
+                       ("viewCos", "<f4"), ("meanDepth", "<f4"), ("meanIntensity", "<f4"), ("r", "<i4"),
+                       ("g", "<i4"), ("b", "<i4"), ("fused", "u1"), ("stable", "u1"), ("use", "u1"),
+                       ("_pad", "u1")])
+
+
+def build():
+    srcs = [os.path.join(ODIR, f) for f in ("orb_oracle.cpp", "surfel_oracle.cpp", "Makefile")]
+    if not os.path.exists(OLIB) or any(os.path.getmtime(s) > os.path.getmtime(OLIB) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
+    return OLIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    def __init__(self, dll):
+        self.dll = dll
+        d = dll
+        d.mslo_orb_create.restype = C.c_void_p
+        d.mslo_orb_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        d.mslo_orb_destroy.argtypes = [C.c_void_p]
+        d.mslo_orb_tables.argtypes = [C.c_void_p] * 7
+        d.mslo_orb_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        d.mslo_orb_level_size.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        d.mslo_orb_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        d.mslo_orb_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        d.mslo_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        d.mslo_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        d.mslo_gaussian_kernel.argtypes = [C.c_void_p]
+        d.mslo_fast_view.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        d.mslo_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        d.mslo_fast_atan2.restype = C.c_float
+        d.mslo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        d.mslo_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        d.mslo_ic_angle.restype = C.c_float
+        d.mslo_ic_angle.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        d.mslo_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+
+    # ---- ORB ----
+    def orb_create(self, nfeatures=1000, scale=1.2, nlevels=8, ini=20, mn=7):
+        return OracleOrb(self, nfeatures, scale, nlevels, ini, mn)
+
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        self.dll.mslo_resize_linear_u8(_p(src), src.shape[1], src.shape[0], _p(dst), dw, dh)
+        return dst
+
+    def blur(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros_like(src)
+        self.dll.mslo_gaussian_blur7(_p(src), src.shape[1], src.shape[0], _p(dst))
+        return dst
+
+    def gaussian_kernel(self):
+        k = np.zeros(7, np.int32)
+        self.dll.mslo_gaussian_kernel(_p(k))
+        return k
+
+    def fast(self, img, threshold):
+        img = np.ascontiguousarray(img, np.uint8)
+        out = np.zeros((img.size, 3), np.int32)
+        n = self.dll.mslo_fast_view(_p(img), img.shape[1], img.shape[0], threshold, _p(out), out.shape[0])
+        assert n >= 0
+        return out[:n].copy()
+
+    def octree(self, xyr, minX, maxX, minY, maxY, N):
+        xyr = np.ascontiguousarray(xyr, np.float32)
+        out = np.zeros((max(N + 8, 4 * 8), 3), np.float32)
+        n = self.dll.mslo_distribute_octree(_p(xyr), len(xyr), minX, maxX, minY, maxY, N, _p(out), out.shape[0])
+        assert n >= 0
+        return out[:n].copy()
+
+    def fast_atan2(self, y, x):
+        return float(self.dll.mslo_fast_atan2(float(y), float(x)))
+
+    def sincos(self, a):
+        s, c = C.c_float(), C.c_float()
+        self.dll.mslo_sincos(float(a), C.byref(s), C.byref(c))
+        return s.value, c.value
+
+    def ic_angle(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return float(self.dll.mslo_ic_angle(_p(img), img.shape[1], img.shape[0], x, y))
+
+    def descriptor(self, blurred, x, y, angle):
+        blurred = np.ascontiguousarray(blurred, np.uint8)
+        d = np.zeros(32, np.uint8)
+        self.dll.mslo_orb_descriptor(_p(blurred), blurred.shape[1], blurred.shape[0], x, y, float(angle), _p(d))
+        return d
+
+
+class OracleOrb:
+    def __init__(self, o, nfeatures, scale, nlevels, ini, mn):
+        self.o = o
+        self.nlevels = nlevels
+        self.cap = nfeatures + 2 * nlevels
+        self.h = o.dll.mslo_orb_create(nfeatures, scale, nlevels, ini, mn)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.o.dll.mslo_orb_destroy(self.h)
+            self.h = None
+
+    def tables(self):
+        t = [np.zeros(self.nlevels, np.float32) for _ in range(4)]
+        per = np.zeros(self.nlevels, np.int32)
+        umax = np.zeros(16, np.int32)
+        self.o.dll.mslo_orb_tables(self.h, *[_p(a) for a in t], _p(per), _p(umax))
+        return t + [per, umax]
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        kps = np.zeros(self.cap, KEYPOINT_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = self.o.dll.mslo_orb_extract(self.h, _p(img), img.shape[1], img.shape[0], img.strides[0], _p(kps), _p(desc), self.cap)
+        assert n >= 0
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self.o.dll.mslo_orb_level_size(self.h, level, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        rc = self.o.dll.mslo_orb_level(self.h, level, int(blurred), _p(out))
+        assert rc == 0
+        return out
+
+    def candidates(self, level, cap=1 << 20):
+        out = np.zeros((cap, 3), np.int32)
+        n = self.o.dll.mslo_orb_candidates(self.h, level, _p(out), cap)
+        assert n >= 0
+        return out[:n].copy()
+
+
+_cached = None
+
+
+def load():
+    global _cached
+    if _cached is None:
+        _cached = Oracle(C.CDLL(build()))
+    return _cached

@@ -1,0 +1,101 @@
+"""GPU parity: HIP ORB extractor (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_same(kg, dg, ko, do):
+    assert len(kg) == len(ko), (len(kg), len(ko))
+    for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+        a, b = kg[f], ko[f]
+        assert np.array_equal(a.view(np.int32) if a.dtype.kind == "f" else a,
+                              b.view(np.int32) if b.dtype.kind == "f" else b), f
+    if len(kg):
+        assert np.array_equal(dg, do)
+    else:
+        assert dg is None or len(dg) == 0
+
+
+@pytest.fixture(scope="module")
+def gpu_orb():
+    from manhattanslam_amd import ORBextractor
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=640, max_height=480, max_batch=8)
+    yield ex
+    ex.close()
+
+
+def test_stages_match_oracle(gpu_orb, oracle):
+    """Pyramid levels, FAST candidates (order included) and blurred levels are byte-identical."""
+    from manhattanslam_amd import synth
+    img = synth.orb_frame()
+    oex = oracle.orb_create()
+    ko, do = oex.extract(img)
+    kg, dg = gpu_orb(img)
+    for l in range(8):
+        if l > 0:
+            assert np.array_equal(gpu_orb.debug_level(0, l), oex.level(l)), f"pyramid level {l}"
+        assert np.array_equal(gpu_orb.debug_candidates(0, l), oex.candidates(l)), f"candidates level {l}"
+        assert np.array_equal(gpu_orb.debug_level(0, l, blurred=True), oex.level(l, blurred=True)), f"blur level {l}"
+    _assert_same(kg, dg, ko, do)
+
+
+@pytest.mark.parametrize("seed_off", [1, 2, 3])
+def test_full_extract_bit_exact(gpu_orb, oracle, seed_off):
+    from manhattanslam_amd import synth
+    img = synth.orb_frame(synth.ORB_SEED + seed_off)
+    ko, do = oracle.orb_create().extract(img)
+    kg, dg = gpu_orb(img)
+    _assert_same(kg, dg, ko, do)
+    assert len(kg) >= 1000
+
+
+def test_batch_matches_single(gpu_orb, oracle):
+    from manhattanslam_amd import synth
+    imgs = synth.orb_frames(8, seed=77)
+    res = gpu_orb.extract_batch(imgs)
+    oex = oracle.orb_create()
+    for f in range(8):
+        ko, do = oex.extract(imgs[f])
+        _assert_same(res[f][0], res[f][1], ko, do)
+
+
+def test_edge_cases(gpu_orb, oracle):
+    # constant image: no corners at all -> zero keypoints, descriptors released
+    flat = np.full((480, 640), 90, np.uint8)
+    k, d = gpu_orb(flat)
+    assert len(k) == 0 and d is None
+    # empty image: silent return (src/ORBextractor.cc:815-816)
+    k, d = gpu_orb(np.zeros((0, 0), np.uint8))
+    assert len(k) == 0 and d is None
+    # pure noise: far more candidates than quota on every level
+    rng = np.random.default_rng(5)
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    ko, do = oracle.orb_create().extract(noise)
+    kg, dg = gpu_orb(noise)
+    _assert_same(kg, dg, ko, do)
+    # strided input (row stride > width)
+    big = np.zeros((480, 700), np.uint8)
+    from manhattanslam_amd import synth
+    big[:, :640] = synth.orb_frame(1234)
+    view = big[:, :640]
+    ko, do = oracle.orb_create().extract(np.ascontiguousarray(view))
+    kg, dg = gpu_orb(view)
+    _assert_same(kg, dg, ko, do)
+
+
+def test_other_sizes_and_params(oracle):
+    """Smaller frame, fewer features/levels, other thresholds."""
+    from manhattanslam_amd import ORBextractor, synth
+    img = synth.orb_frame(42, 400, 304)
+    ex = ORBextractor(500, 1.2, 6, 25, 9, max_width=400, max_height=304)
+    ko, do = oracle.orb_create(500, 1.2, 6, 25, 9).extract(img)
+    kg, dg = ex(img)
+    _assert_same(kg, dg, ko, do)
+    ex.close()
+    img = synth.orb_frame(43, 1280, 960)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=1280, max_height=960)
+    ko, do = oracle.orb_create().extract(img)
+    kg, dg = ex(img)
+    _assert_same(kg, dg, ko, do)
+    ex.close()
