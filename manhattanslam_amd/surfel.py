@@ -1,9 +1,119 @@
-"""Host mirror of SurfelFusion (reference include/SurfelFusion.h:43-139) -- filled in with the kernels."""
+"""Host mirror of SurfelFusion (reference include/SurfelFusion.h:43-139) and of the
+SurfelMapping::fuseMap step (src/SurfelMapping.cpp:353-392) on a device-resident map."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import (MSL_MEM_DEVICE, MSL_MEM_HOST, MSL_SF_NKERNELS, SEED_DTYPE, SURFEL_DTYPE, MslError, check, lib, ptr)
+
+
+def _pose16(pose):
+    """Accepts a 4x4 matrix (row-major numpy, Twc) or a flat column-major float32[16]."""
+    pose = np.asarray(pose, np.float32)
+    if pose.shape == (4, 4):
+        pose = pose.T.reshape(16)  # Eigen::Matrix4f storage is column-major
+    assert pose.shape == (16,)
+    return np.ascontiguousarray(pose)
 
 
 class SurfelFusion:
-    pass
+    """Same constructor arguments as the reference class (src/SurfelFusion.cpp:29-38)."""
+
+    def __init__(self, width, height, fx, fy, cx, cy, fuseFar, fuseNear, device=0):
+        self._h = lib.msl_sf_create(int(width), int(height), float(fx), float(fy), float(cx), float(cy), float(fuseFar),
+                                    float(fuseNear), int(device))
+        if not self._h:
+            raise MslError("msl_sf_create failed: " + lib.msl_last_error().decode())
+        self.width, self.height = int(width), int(height)
+        self.nseeds = (self.width // 8) * (self.height // 8)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.msl_sf_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- SurfelFusion::fuseInitializeMap, host-vector mode ----
+    def fuseInitializeMap(self, referenceFrameIndex, inputImage, inputDepth, inputPlaneMembershipImg, pose, localSurfels):
+        """Updates `localSurfels` (structured SURFEL_DTYPE array) in place and returns the new surfels."""
+        g = inputImage if inputImage.strides[1] == 1 else np.ascontiguousarray(inputImage)
+        d = inputDepth if inputDepth.strides[1] == 4 else np.ascontiguousarray(inputDepth)
+        m = inputPlaneMembershipImg if inputPlaneMembershipImg.strides[1] == 4 else np.ascontiguousarray(inputPlaneMembershipImg)
+        assert g.dtype == np.uint8 and d.dtype == np.float32 and m.dtype == np.int32
+        assert localSurfels.dtype == SURFEL_DTYPE and localSurfels.flags.c_contiguous
+        new = np.zeros(self.nseeds, SURFEL_DTYPE)
+        n_new = C.c_size_t(0)
+        p = _pose16(pose)
+        check(lib.msl_sf_fuse(self._h, int(referenceFrameIndex), ptr(g), g.strides[0], ptr(d), d.strides[0], ptr(m), m.strides[0],
+                              ptr(p), ptr(localSurfels) if len(localSurfels) else None, len(localSurfels), ptr(new), len(new),
+                              C.byref(n_new)), "msl_sf_fuse")
+        return new[:n_new.value].copy()
+
+    # ---- device-resident map ----
+    def map_reserve(self, cap):
+        check(lib.msl_sf_map_reserve(self._h, int(cap)), "msl_sf_map_reserve")
+
+    def map_upload(self, surfels):
+        surfels = np.ascontiguousarray(surfels, SURFEL_DTYPE)
+        check(lib.msl_sf_map_upload(self._h, ptr(surfels) if len(surfels) else None, len(surfels)), "msl_sf_map_upload")
+
+    def map_size(self):
+        n = C.c_size_t(0)
+        check(lib.msl_sf_map_size(self._h, C.byref(n)), "msl_sf_map_size")
+        return n.value
+
+    def map_download(self):
+        n = self.map_size()
+        out = np.zeros(n, SURFEL_DTYPE)
+        got = C.c_size_t(0)
+        check(lib.msl_sf_map_download(self._h, ptr(out) if n else None, n, C.byref(got)), "msl_sf_map_download")
+        return out[:got.value]
+
+    def fuse_resident(self, referenceFrameIndex, gray, depth, member, pose, device=False, strides=None):
+        """fuseInitializeMap + fuseMap compaction on the resident map; asynchronous."""
+        if strides is None:
+            strides = (gray.stride(0) if device else gray.strides[0], (depth.stride(0) * 4) if device else depth.strides[0],
+                       (member.stride(0) * 4) if device else member.strides[0])
+        p = _pose16(pose)
+        check(lib.msl_sf_fuse_resident(self._h, int(referenceFrameIndex), ptr(gray), strides[0], ptr(depth), strides[1], ptr(member),
+                                       strides[2], MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(p)), "msl_sf_fuse_resident")
+
+    def counters(self):
+        c = np.zeros(5, np.int64)
+        check(lib.msl_sf_last_counters(self._h, ptr(c)), "msl_sf_last_counters")
+        return dict(zip(("n_live_before", "n_new", "n_deleted", "n_updated", "n_live_after"), (int(v) for v in c)))
+
+    def sync(self):
+        check(lib.msl_sf_sync(self._h), "msl_sf_sync")
+
+    def set_stream(self, hip_stream):
+        check(lib.msl_sf_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # ---- debug / profiling ----
+    def debug_seeds(self):
+        out = np.zeros(self.nseeds, SEED_DTYPE)
+        check(lib.msl_sf_debug_seeds(self._h, ptr(out)))
+        return out
+
+    def debug_index(self):
+        out = np.zeros((self.height, self.width), np.int32)
+        check(lib.msl_sf_debug_index(self._h, ptr(out)))
+        return out
+
+    def profile_enable(self, on=True):
+        check(lib.msl_sf_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms = np.zeros(MSL_SF_NKERNELS, np.float32)
+        cnt = np.zeros(MSL_SF_NKERNELS, np.int32)
+        check(lib.msl_sf_profile_read(self._h, ptr(ms), ptr(cnt)))
+        return {lib.msl_sf_kernel_name(k).decode(): (float(ms[k]), int(cnt[k])) for k in range(MSL_SF_NKERNELS)}
 
 
-class SurfelMap:
-    pass
+class SurfelMap(SurfelFusion):
+    """SurfelFusion plus the resident local-surfel vector: `fuseMap` mirrors
+    SurfelMapping::fuseMap(image, depth, planeMembershipImg, pose, referenceIndex)."""
+
+    def fuseMap(self, image, depth, planeMembershipImg, pose, referenceIndex, device=False):
+        self.fuse_resident(referenceIndex, image, depth, planeMembershipImg, pose, device=device)

@@ -1,1 +1,566 @@
-// placeholder, filled in below
+// surfel_oracle.cpp -- CPU restatement of ManhattanSLAM's SurfelFusion + SurfelMapping::fuseMap.
+// TEST INFRASTRUCTURE ONLY (see orb_oracle.cpp header): never linked into the product.
+//
+// PARITY UNPINNED: the reference has no tests or golden vectors and needs OpenCV + Eigen (absent
+// from this image), so it cannot be built here.  This file follows src/SurfelFusion.cpp and
+// src/SurfelMapping.cpp:353-392 statement by statement, keeping every float/double promotion of the
+// original expressions.  Pinned semantics where the reference is racy or
+// undefined:
+//   * updatePixels: pixels are visited in global raster order (the THREAD_NUM row bands one after
+//     another); the `stable` flag is read and cleared in that order.
+//   * updateSeeds: the THREAD_NUM=10 seed chunks are kept; inside a chunk the first used, unstable
+//     seed that owns no pixel ends the chunk (`return` at src/SurfelFusion.cpp:473-474).
+//   * SuperpixelSeed members never written by initializeSeedsKernel start as 0.
+//   * image.at<cv::Vec3b>() on the 1-channel image = three bytes at flat offset row*stride + 3*col,
+//     0 beyond the end of the buffer.
+//   * an argmin of -1 in updatePixels (all candidate costs >= 1e6; UB in the reference) leaves the
+//     pixel untouched.
+//   * Eigen 4x4 inverses (float pose, double Hessian) = adjugate / determinant, products accumulate
+//     column by column left to right.
+//   * unqualified fabs() on floats = std::fabs(float).
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../include/msl.h"
+
+namespace {
+
+const int ITERATION_NUM = 3, THREAD_NUM = 10, SP_SIZE = 8;   // include/SurfelFusion.h:33-35
+const double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE = 0.5, DISPARITY_ERROR = 4.0,
+             MIN_TOLERATE_DIFF = 0.1;                          // :36-41 (double literals)
+
+typedef msl_seed Seed;
+typedef msl_surfel Surfel;
+
+// adjugate/determinant 4x4 inverse, column-major storage m[c*4+r]
+template <typename T>
+void inverse4(const T *m, T *inv) {
+    auto M = [&](int r, int c) -> T { return m[c * 4 + r]; };
+    auto det3 = [&](int r0, int r1, int r2, int c0, int c1, int c2) -> T {
+        return M(r0, c0) * (M(r1, c1) * M(r2, c2) - M(r1, c2) * M(r2, c1)) -
+               M(r0, c1) * (M(r1, c0) * M(r2, c2) - M(r1, c2) * M(r2, c0)) +
+               M(r0, c2) * (M(r1, c0) * M(r2, c1) - M(r1, c1) * M(r2, c0));
+    };
+    T cof[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            int rr[3], cc[3], k = 0;
+            for (int i = 0; i < 4; i++) if (i != r) rr[k++] = i;
+            k = 0;
+            for (int i = 0; i < 4; i++) if (i != c) cc[k++] = i;
+            T d = det3(rr[0], rr[1], rr[2], cc[0], cc[1], cc[2]);
+            cof[r][c] = ((r + c) & 1) ? -d : d;
+        }
+    T det = ((M(0, 0) * cof[0][0] + M(0, 1) * cof[0][1]) + M(0, 2) * cof[0][2]) + M(0, 3) * cof[0][3];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) inv[c * 4 + r] = cof[c][r] / det;  // inverse = adj / det, adj = cof^T
+}
+
+struct Fusion {
+    int W, H, spW, spH;
+    float fx, fy, cx, cy, fuseFar, fuseNear;
+    const uint8_t *gray = nullptr; size_t gstride = 0, gbytes = 0;
+    const float *depthp = nullptr; size_t dstride = 0;     // in floats
+    const int32_t *member = nullptr; size_t mstride = 0;   // in ints
+    std::vector<double> spaceMap;
+    std::vector<float> normMap;
+    std::vector<Seed> seeds;
+    std::vector<int> index;
+
+    Fusion(int w, int h, float fx_, float fy_, float cx_, float cy_, float far_, float near_)
+        : W(w), H(h), spW(w / SP_SIZE), spH(h / SP_SIZE), fx(fx_), fy(fy_), cx(cx_), cy(cy_), fuseFar(far_), fuseNear(near_) {
+        seeds.resize((size_t)spW * spH);
+        index.resize((size_t)W * H);
+        spaceMap.resize((size_t)W * H * 3);
+        normMap.resize((size_t)W * H * 3);
+    }
+
+    uint8_t img(int y, int x) const { return gray[(size_t)y * gstride + x]; }
+    float depth(int y, int x) const { return depthp[(size_t)y * dstride + x]; }
+    float depth_flat(int idx) const { return depthp[(size_t)(idx / W) * dstride + (idx % W)]; }
+    int plane(int y, int x) const { return member[(size_t)y * mstride + x]; }
+    void vec3b(float row, float col, int &r, int &g, int &b) const {  // image.at<cv::Vec3b>(row, col)
+        const size_t off = (size_t)(int)row * gstride + 3 * (size_t)(int)col;
+        r = off < gbytes ? gray[off] : 0;
+        g = off + 1 < gbytes ? gray[off + 1] : 0;
+        b = off + 2 < gbytes ? gray[off + 2] : 0;
+    }
+
+    void project(float x, float y, float z, float &u, float &v) const {  // :75-78
+        u = x * fx / z + cx;
+        v = y * fy / z + cy;
+    }
+    void backProject(float u, float v, float d, double &x, double &y, double &z) const {  // :80-85
+        x = (u - cx) / fx * d;
+        y = (v - cy) / fy * d;
+        z = d;
+    }
+    static float getWeight(float d) { return (float)std::min(1.0 / d / d, 1.0); }  // :87-89
+
+    // ---- :528-584 ----
+    void initializeSeeds() {
+        for (int seedI = 0; seedI < (int)seeds.size(); seedI++) {
+            const int spX = seedI % spW, spY = seedI / spW;
+            int imageX = spX * SP_SIZE + SP_SIZE / 2, imageY = spY * SP_SIZE + SP_SIZE / 2;
+            imageX = imageX < (W - 1) ? imageX : (W - 1);
+            imageY = imageY < (H - 1) ? imageY : (H - 1);
+            if (plane(imageY / 2, imageX / 2) != -1) { seeds[seedI].use = 0; continue; }
+            Seed s;
+            memset(&s, 0, sizeof(s));
+            s.use = 1;
+            s.x = (float)imageX; s.y = (float)imageY;
+            vec3b((float)imageY, (float)imageX, s.r, s.g, s.b);
+            s.meanIntensity = img(imageY, imageX);
+            s.fused = 0; s.stable = 0;
+            s.meanDepth = depth(imageY, imageX);
+            if (s.meanDepth < 0.01) {
+                int xb = spX * SP_SIZE + SP_SIZE / 2 - SP_SIZE, yb = spY * SP_SIZE + SP_SIZE / 2 - SP_SIZE;
+                int xe = xb + SP_SIZE * 2, ye = yb + SP_SIZE * 2;
+                xb = xb > 0 ? xb : 0; yb = yb > 0 ? yb : 0;
+                xe = xe < W - 1 ? xe : W - 1; ye = ye < H - 1 ? ye : H - 1;
+                bool found = false;
+                for (int j = yb; j < ye && !found; j++)
+                    for (int i = xb; i < xe; i++) {
+                        const float d = depth(j, i);
+                        if (d > 0.01) { s.meanDepth = d; found = true; break; }
+                    }
+            }
+            seeds[seedI] = s;
+        }
+    }
+
+    // ---- :333-355 ----
+    bool calculateCost(float &nodepthCost, float &depthCost, float pixelIntensity, float pixelInverseDepth, int x, int y,
+                       int spX, int spY) const {
+        const Seed &s = seeds[spY * spW + spX];
+        nodepthCost = 0;
+        float dist = (s.x - x) * (s.x - x) + (s.y - y) * (s.y - y);
+        nodepthCost += dist / ((SP_SIZE / 2) * (SP_SIZE / 2));
+        float intensityDiff = (s.meanIntensity - pixelIntensity);
+        nodepthCost = (float)(nodepthCost + intensityDiff * intensityDiff / 100.0);
+        depthCost = nodepthCost;
+        if (s.meanDepth > 0 && pixelInverseDepth > 0) {
+            float inverseDepthDiff = (float)(1.0 / s.meanDepth - pixelInverseDepth);
+            depthCost = (float)(depthCost + inverseDepthDiff * inverseDepthDiff * 400.0);
+            return true;
+        }
+        return false;
+    }
+
+    // ---- :357-415, raster order ----
+    void updatePixels() {
+        for (int rowI = 0; rowI < H; rowI++)
+            for (int colI = 0; colI < W; colI++) {
+                if (plane(rowI / 2, colI / 2) != -1) continue;
+                if (seeds[index[rowI * W + colI]].stable) continue;
+                float myIntensity = img(rowI, colI);
+                float myInvDepth = 0.0;
+                if (depth(rowI, colI) > 0.01) myInvDepth = (float)(1.0 / depth(rowI, colI));
+                const int baseSpX = colI / SP_SIZE, baseSpY = rowI / SP_SIZE;
+                float minDistDepth = 1e6, minDistNodepth = 1e6;
+                int minSpIndexDepth = -1, minSpIndexNodepth = -1;
+                bool allHasDepth = true;
+                for (int checkI = -1; checkI <= 1; checkI++)
+                    for (int checkJ = -1; checkJ <= 1; checkJ++) {
+                        const int checkSpX = baseSpX + checkI, checkSpY = baseSpY + checkJ;
+                        const int distSpX = std::abs(checkSpX * SP_SIZE + SP_SIZE / 2 - colI);
+                        const int distSpY = std::abs(checkSpY * SP_SIZE + SP_SIZE / 2 - rowI);
+                        if (distSpX < SP_SIZE && distSpY < SP_SIZE && checkSpX >= 0 && checkSpX < spW && checkSpY >= 0 &&
+                            checkSpY < spH) {
+                            float distDepth, distNodepth;
+                            allHasDepth &= calculateCost(distNodepth, distDepth, myIntensity, myInvDepth, colI, rowI, checkSpX,
+                                                         checkSpY);
+                            if (distDepth < minDistDepth) { minDistDepth = distDepth; minSpIndexDepth = checkSpY * spW + checkSpX; }
+                            if (distNodepth < minDistNodepth) { minDistNodepth = distNodepth; minSpIndexNodepth = checkSpY * spW + checkSpX; }
+                        }
+                    }
+                const int pick = allHasDepth ? minSpIndexDepth : minSpIndexNodepth;
+                if (pick < 0) continue;  // pinned: UB in the reference
+                index[rowI * W + colI] = pick;
+                seeds[pick].stable = 0;
+            }
+    }
+
+    // ---- :428-515, THREAD_NUM chunks with the early `return` ----
+    void updateSeeds() {
+        const int total = (int)seeds.size(), step = total / THREAD_NUM;
+        for (int thread = 0; thread < THREAD_NUM; thread++) {
+            const int beginIndex = step * thread;
+            const int endIndex = thread == THREAD_NUM - 1 ? total : beginIndex + step;
+            for (int seedI = beginIndex; seedI < endIndex; seedI++) {
+                Seed &S = seeds[seedI];
+                if (!S.use) continue;
+                if (S.stable) continue;
+                const int spX = seedI % spW, spY = seedI / spW;
+                int xb = spX * SP_SIZE + SP_SIZE / 2 - SP_SIZE, yb = spY * SP_SIZE + SP_SIZE / 2 - SP_SIZE;
+                int xe = xb + SP_SIZE * 2, ye = yb + SP_SIZE * 2;
+                xb = xb > 0 ? xb : 0; yb = yb > 0 ? yb : 0;
+                xe = xe < W - 1 ? xe : W - 1; ye = ye < H - 1 ? ye : H - 1;
+                float sumX = 0, sumY = 0, sumIntensity = 0.0, sumIntensityNum = 0.0, sumDepth = 0.0, sumDepthNum = 0.0;
+                std::vector<float> depthVector;
+                for (int j = yb; j < ye; j++)
+                    for (int i = xb; i < xe; i++) {
+                        if (index[j * W + i] == seedI) {
+                            sumX += i; sumY += j;
+                            sumIntensityNum = (float)(sumIntensityNum + 1.0);
+                            sumIntensity += img(j, i);
+                            const float d = depth(j, i);
+                            if (d > 0.1) { depthVector.push_back(d); sumDepth += d; sumDepthNum = (float)(sumDepthNum + 1.0); }
+                        }
+                    }
+                if (sumIntensityNum == 0) break;  // `return`: ends this thread's chunk
+                sumIntensity /= sumIntensityNum; sumX /= sumIntensityNum; sumY /= sumIntensityNum;
+                const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
+                S.meanIntensity = sumIntensity; S.x = sumX; S.y = sumY;
+                vec3b(sumY, sumX, S.r, S.g, S.b);
+                float updateDiff = std::fabs(preIntensity - sumIntensity) + std::fabs(preX - sumX) + std::fabs(preY - sumY);
+                if (updateDiff < 0.2) S.stable = 1;
+                if (sumDepthNum > 0) {
+                    float meanDepth = sumDepth / sumDepthNum;
+                    float sumA, sumB;
+                    for (int newtonI = 0; newtonI < 5; newtonI++) {
+                        sumA = sumB = 0;
+                        for (size_t p = 0; p < depthVector.size(); p++) {
+                            float residual = meanDepth - depthVector[p];
+                            if (residual < HUBER_RANGE && residual > -HUBER_RANGE) { sumA += 2 * residual; sumB += 2; }
+                            else sumA = (float)(sumA + (residual > 0 ? HUBER_RANGE : -1 * HUBER_RANGE));
+                        }
+                        float deltaDepth = (float)(-sumA / (sumB + 10.0));
+                        meanDepth = meanDepth + deltaDepth;
+                        if (deltaDepth < 0.01 && deltaDepth > -0.01) break;
+                    }
+                    S.meanDepth = meanDepth;
+                } else {
+                    S.meanDepth = 0.0;
+                }
+            }
+        }
+    }
+
+    // ---- :597-613 ----
+    void calculateSpaces() {
+        for (int rowI = 0; rowI < H; rowI++)
+            for (int colI = 0; colI < W; colI++) {
+                const int i = rowI * W + colI;
+                double x, y, z;
+                backProject((float)colI, (float)rowI, depth(rowI, colI), x, y, z);
+                spaceMap[i * 3] = x; spaceMap[i * 3 + 1] = y; spaceMap[i * 3 + 2] = z;
+            }
+    }
+
+    // ---- :615-661 ----
+    void calculatePixelsNorms() {
+        for (int rowI = 1; rowI < H - 1; rowI++)
+            for (int colI = 1; colI < W - 1; colI++) {
+                const int i = rowI * W + colI;
+                float myX = (float)spaceMap[i * 3], myY = (float)spaceMap[i * 3 + 1], myZ = (float)spaceMap[i * 3 + 2];
+                float rightX = (float)spaceMap[i * 3 + 3], rightY = (float)spaceMap[i * 3 + 4], rightZ = (float)spaceMap[i * 3 + 5];
+                float downX = (float)spaceMap[i * 3 + W * 3], downY = (float)spaceMap[i * 3 + W * 3 + 1],
+                      downZ = (float)spaceMap[i * 3 + W * 3 + 2];
+                if (myZ < 0.1 || rightZ < 0.1 || downZ < 0.1) continue;
+                rightX = rightX - myX; rightY = rightY - myY; rightZ = rightZ - myZ;
+                downX = downX - myX; downY = downY - myY; downZ = downZ - myZ;
+                float normX = rightY * downZ - rightZ * downY;
+                float normY = rightZ * downX - rightX * downZ;
+                float normZ = rightX * downY - rightY * downX;
+                float normLength = std::sqrt(normX * normX + normY * normY + normZ * normZ);
+                normX /= normLength; normY /= normLength; normZ /= normLength;
+                float viewAngle = (normX * myX + normY * myY + normZ * myZ) / std::sqrt(myX * myX + myY * myY + myZ * myZ);
+                if (viewAngle > -MAX_ANGLE_COS && viewAngle < MAX_ANGLE_COS) continue;
+                normMap[i * 3] = normX; normMap[i * 3 + 1] = normY; normMap[i * 3 + 2] = normZ;
+            }
+    }
+
+    // ---- :91-165 ----
+    static void getHuberNorm(float &nx, float &ny, float &nz, float &nb, std::vector<float> &points) {
+        const int pointNum = (int)points.size() / 3;
+        float sumX = 0.0, sumY = 0.0, sumZ = 0.0;
+        for (int i = 0; i < pointNum; i++) { sumX += points[i * 3]; sumY += points[i * 3 + 1]; sumZ += points[i * 3 + 2]; }
+        sumX /= pointNum; sumY /= pointNum; sumZ /= pointNum;
+        nb = 0;
+        for (int i = 0; i < pointNum; i++) { points[i * 3] -= sumX; points[i * 3 + 1] -= sumY; points[i * 3 + 2] -= sumZ; }
+        for (int gnI = 0; gnI < 5; gnI++) {
+            double hessian[16] = {0};  // column-major, symmetric
+            double jacobian[4] = {0};
+            auto Hm = [&](int r, int c) -> double & { return hessian[c * 4 + r]; };
+            for (int i = 0; i < pointNum; i++) {
+                const float px = points[i * 3], py = points[i * 3 + 1], pz = points[i * 3 + 2];
+                float residual = px * nx + py * ny + pz * nz + nb;
+                if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
+                    jacobian[0] += 2 * residual * px; jacobian[1] += 2 * residual * py; jacobian[2] += 2 * residual * pz;
+                    jacobian[3] += 2 * residual;
+                    Hm(0, 0) += 2 * px * px; Hm(0, 1) += 2 * px * py; Hm(0, 2) += 2 * px * pz; Hm(0, 3) += 2 * px;
+                    Hm(1, 0) += 2 * py * px; Hm(1, 1) += 2 * py * py; Hm(1, 2) += 2 * py * pz; Hm(1, 3) += 2 * py;
+                    Hm(2, 0) += 2 * pz * px; Hm(2, 1) += 2 * pz * py; Hm(2, 2) += 2 * pz * pz; Hm(2, 3) += 2 * pz;
+                    Hm(3, 0) += 2 * px; Hm(3, 1) += 2 * py; Hm(3, 2) += 2 * pz; Hm(3, 3) += 2;
+                } else if (residual >= HUBER_RANGE) {
+                    jacobian[0] += HUBER_RANGE * px; jacobian[1] += HUBER_RANGE * py; jacobian[2] += HUBER_RANGE * pz;
+                    jacobian[3] += HUBER_RANGE;
+                } else if (residual <= -1 * HUBER_RANGE) {
+                    jacobian[0] += -1 * HUBER_RANGE * px; jacobian[1] += -1 * HUBER_RANGE * py; jacobian[2] += -1 * HUBER_RANGE * pz;
+                    jacobian[3] += -1 * HUBER_RANGE;
+                }
+            }
+            Hm(0, 0) += 5; Hm(1, 1) += 5; Hm(2, 2) += 5; Hm(3, 3) += 5;
+            double inv[16];
+            inverse4<double>(hessian, inv);
+            double upd[4];
+            for (int r = 0; r < 4; r++)
+                upd[r] = ((inv[0 * 4 + r] * jacobian[0] + inv[1 * 4 + r] * jacobian[1]) + inv[2 * 4 + r] * jacobian[2]) +
+                         inv[3 * 4 + r] * jacobian[3];
+            nx = (float)(nx - upd[0]); ny = (float)(ny - upd[1]); nz = (float)(nz - upd[2]); nb = (float)(nb - upd[3]);
+        }
+        nb = nb - (nx * sumX + ny * sumY + nz * sumZ);
+        float normLength = std::sqrt(nx * nx + ny * ny + nz * nz);
+        nx /= normLength; ny /= normLength; nz /= normLength; nb /= normLength;
+    }
+
+    // ---- :663-773 ----
+    void calculateSpDepthNorms() {
+        const int total = (int)index.size();
+        for (int seedI = 0; seedI < (int)seeds.size(); seedI++) {
+            Seed &S = seeds[seedI];
+            const int spX = seedI % spW, spY = seedI / spW;
+            const int xb = spX * SP_SIZE + SP_SIZE / 2 - SP_SIZE, yb = spY * SP_SIZE + SP_SIZE / 2 - SP_SIZE;
+            std::vector<float> pixelDepth, pixelNorms, pixelPositions, pixelInlierPositions;
+            float validDepthNum = 0, maxDist = 0;
+            for (int j = yb; j < yb + SP_SIZE * 2; j++)
+                for (int i = xb; i < xb + SP_SIZE * 2; i++) {
+                    const int pixelIndex = j * W + i;
+                    if (pixelIndex < 0 || pixelIndex >= total) continue;
+                    if (index[pixelIndex] == seedI) {
+                        float xDiff = i - S.x, yDiff = j - S.y;
+                        float dist = xDiff * xDiff + yDiff * yDiff;
+                        if (dist > maxDist) maxDist = dist;
+                        float myDepth = depth_flat(pixelIndex);
+                        if (myDepth > 0.05) {
+                            pixelDepth.push_back(myDepth);
+                            pixelNorms.push_back(normMap[pixelIndex * 3]); pixelNorms.push_back(normMap[pixelIndex * 3 + 1]);
+                            pixelNorms.push_back(normMap[pixelIndex * 3 + 2]);
+                            validDepthNum += 1;
+                            pixelPositions.push_back((float)spaceMap[pixelIndex * 3]); pixelPositions.push_back((float)spaceMap[pixelIndex * 3 + 1]);
+                            pixelPositions.push_back((float)spaceMap[pixelIndex * 3 + 2]);
+                        }
+                    }
+                }
+            if (validDepthNum < 16) continue;
+            float meanDepth = S.meanDepth;
+            float normX = 0.0, normY = 0.0, normZ = 0.0, normB = 0.0;
+            float inlierNum = 0;
+            for (size_t p = 0; p < pixelDepth.size(); p++) {
+                float residual = meanDepth - pixelDepth[p];
+                if (residual < HUBER_RANGE && residual > -HUBER_RANGE) {
+                    normX += pixelNorms[p * 3]; normY += pixelNorms[p * 3 + 1]; normZ += pixelNorms[p * 3 + 2];
+                    inlierNum += 1;
+                    pixelInlierPositions.push_back(pixelPositions[p * 3]); pixelInlierPositions.push_back(pixelPositions[p * 3 + 1]);
+                    pixelInlierPositions.push_back(pixelPositions[p * 3 + 2]);
+                }
+            }
+            if (inlierNum / pixelDepth.size() < 0.8) continue;
+            float normLength = std::sqrt(normX * normX + normY * normY + normZ * normZ);
+            normX = normX / normLength; normY = normY / normLength; normZ = normZ / normLength;
+            getHuberNorm(normX, normY, normZ, normB, pixelInlierPositions);
+            double avgX, avgY, avgZ;
+            backProject(S.x, S.y, meanDepth, avgX, avgY, avgZ);
+            {
+                float k = (float)(-1 * (avgX * normX + avgY * normY + avgZ * normZ) - normB);
+                avgX += k * normX; avgY += k * normY; avgZ += k * normZ;
+                meanDepth = (float)avgZ;
+            }
+            float viewCos = (float)(-1.0 * (normX * avgX + normY * avgY + normZ * avgZ) / std::sqrt(avgX * avgX + avgY * avgY + avgZ * avgZ));
+            if (viewCos < 0) { viewCos = (float)(viewCos * -1.0); normX = (float)(normX * -1.0); normY = (float)(normY * -1.0); normZ = (float)(normZ * -1.0); }
+            S.normX = normX; S.normY = normY; S.normZ = normZ;
+            S.posX = (float)avgX; S.posY = (float)avgY; S.posZ = (float)avgZ;
+            S.meanDepth = meanDepth; S.viewCos = viewCos; S.size = std::sqrt(maxDist);
+        }
+    }
+
+    // ---- :805-817 ----
+    void generateSuperPixels() {
+        memset(seeds.data(), 0, seeds.size() * sizeof(Seed));
+        std::fill(index.begin(), index.end(), 0);
+        std::fill(normMap.begin(), normMap.end(), 0.f);
+        initializeSeeds();
+        for (int it = 0; it < ITERATION_NUM; it++) { updatePixels(); updateSeeds(); }
+        calculateSpaces();
+        calculatePixelsNorms();
+        calculateSpDepthNorms();
+    }
+
+    // ---- :167-283 ----
+    void fuseSurfels(int referenceFrameIndex, const float *pose, const float *invPose, Surfel *local, size_t n) {
+        auto mul4 = [](const float *m, const float v[4], float out[4]) {
+            for (int r = 0; r < 4; r++) out[r] = ((m[r] * v[0] + m[4 + r] * v[1]) + m[8 + r] * v[2]) + m[12 + r] * v[3];
+        };
+        auto mul3 = [](const float *m, const float v[3], float out[3]) {
+            for (int r = 0; r < 3; r++) out[r] = (m[r] * v[0] + m[4 + r] * v[1]) + m[8 + r] * v[2];
+        };
+        for (size_t i = 0; i < n; i++) {
+            Surfel &L = local[i];
+            if (referenceFrameIndex - L.lastUpdate > 5 && L.updateTimes < 5) { L.updateTimes = 0; continue; }
+            if (L.updateTimes == 0) continue;
+            float pw[4] = {L.px, L.py, L.pz, 1.0f}, pc[4];
+            mul4(invPose, pw, pc);
+            if (pc[2] < fuseNear || pc[2] > fuseFar) continue;
+            float nw[3] = {L.nx, L.ny, L.nz}, nc[3];
+            mul3(invPose, nw, nc);
+            float projectU, projectV;
+            project(pc[0], pc[1], pc[2], projectU, projectV);
+            int pUInt = (int)(projectU + 0.5), pVInt = (int)(projectV + 0.5);
+            if (pUInt < 1 || pUInt > W - 2 || pVInt < 1 || pVInt > H - 2) continue;
+            if (pc[2] < depth(pVInt, pUInt) - 1.0) { L.updateTimes = 0; continue; }
+            const int spIndex = index[pVInt * W + pUInt];
+            Seed &S = seeds[spIndex];
+            if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
+            if (S.viewCos < MAX_ANGLE_COS) continue;
+            float cameraF = (float)((std::fabs(fx) + std::fabs(fy)) / 2.0);
+            float tolerateDiff = (float)(pc[2] * pc[2] / (BASELINE * cameraF) * DISPARITY_ERROR);
+            tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
+            if (pc[2] < S.meanDepth - tolerateDiff) continue;
+            if (pc[2] > S.meanDepth + tolerateDiff) continue;
+            float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
+            if (normDiffCos < MAX_ANGLE_COS) { L.updateTimes = 0; continue; }
+            float oldWeight = L.weight;
+            float newWeight = getWeight(S.meanDepth);
+            float sumWeight = oldWeight + newWeight;
+            float spPC[4] = {S.posX, S.posY, S.posZ, 1.0f}, spPW[4];
+            mul4(pose, spPC, spPW);
+            float fusedPx = (L.px * oldWeight + newWeight * spPW[0]) / sumWeight;
+            float fusedPy = (L.py * oldWeight + newWeight * spPW[1]) / sumWeight;
+            float fusedPz = (L.pz * oldWeight + newWeight * spPW[2]) / sumWeight;
+            float fusedNx = nc[0] * oldWeight + newWeight * S.normX;
+            float fusedNy = nc[1] * oldWeight + newWeight * S.normY;
+            float fusedNz = nc[2] * oldWeight + newWeight * S.normZ;
+            double newNormLength = std::sqrt(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
+            fusedNx = (float)(fusedNx / newNormLength); fusedNy = (float)(fusedNy / newNormLength); fusedNz = (float)(fusedNz / newNormLength);
+            float newNormC[3] = {fusedNx, fusedNy, fusedNz}, newNormW[3];
+            mul3(pose, newNormC, newNormW);
+            L.px = fusedPx; L.py = fusedPy; L.pz = fusedPz;
+            L.r = S.r; L.g = S.g; L.b = S.b;
+            L.nx = newNormW[0]; L.ny = newNormW[1]; L.nz = newNormW[2];
+            L.weight = sumWeight;
+            L.color = S.meanIntensity;
+            float newSize = S.size * std::fabs(S.meanDepth / (cameraF * S.viewCos));
+            if (newSize < L.size) L.size = newSize;
+            L.lastUpdate = referenceFrameIndex;
+            L.updateTimes += 1;
+            S.fused = 1;
+        }
+    }
+
+    // ---- :285-331 ----
+    void initializeSurfels(int referenceFrameIndex, const float *pose, std::vector<Surfel> &out) {
+        out.clear();
+        for (size_t i = 0; i < seeds.size(); i++) {
+            const Seed &S = seeds[i];
+            if (S.meanDepth == 0) continue;
+            if (S.fused) continue;
+            if (S.viewCos < MAX_ANGLE_COS) continue;
+            const float pcv[4] = {S.posX, S.posY, S.posZ, 1.0f}, ncv[3] = {S.normX, S.normY, S.normZ};
+            if (ncv[0] == 0 && ncv[1] == 0 && ncv[2] == 0) continue;
+            float pw[4], nw[3];
+            for (int r = 0; r < 4; r++) pw[r] = ((pose[r] * pcv[0] + pose[4 + r] * pcv[1]) + pose[8 + r] * pcv[2]) + pose[12 + r] * pcv[3];
+            for (int r = 0; r < 3; r++) nw[r] = (pose[r] * ncv[0] + pose[4 + r] * ncv[1]) + pose[8 + r] * ncv[2];
+            Surfel e;
+            e.px = pw[0]; e.py = pw[1]; e.pz = pw[2];
+            e.r = S.r; e.g = S.g; e.b = S.b;
+            e.nx = nw[0]; e.ny = nw[1]; e.nz = nw[2];
+            float cameraF = (float)((std::fabs(fx) + std::fabs(fy)) / 2.0);
+            e.size = S.size * std::fabs(S.meanDepth / (cameraF * S.viewCos));
+            e.color = S.meanIntensity;
+            float md = S.meanDepth;
+            e.weight = getWeight(md);
+            e.updateTimes = 1;
+            e.lastUpdate = referenceFrameIndex;
+            out.push_back(e);
+        }
+    }
+
+    // ---- :40-73 ----
+    void fuseInitializeMap(int ref, const uint8_t *g, size_t gs, const float *d, size_t ds, const int32_t *m, size_t ms,
+                           const float *pose, Surfel *local, size_t n_local, std::vector<Surfel> &newSurfels) {
+        gray = g; gstride = gs; gbytes = gs * (size_t)H;
+        depthp = d; dstride = ds / sizeof(float);
+        member = m; mstride = ms / sizeof(int32_t);
+        generateSuperPixels();
+        float invPose[16];
+        inverse4<float>(pose, invPose);
+        fuseSurfels(ref, pose, invPose, local, n_local);
+        initializeSurfels(ref, pose, newSurfels);
+    }
+};
+
+// SurfelMapping::fuseMap slot refill + tail compaction (src/SurfelMapping.cpp:366-391)
+void fuse_map_compact(std::vector<Surfel> &local, const std::vector<Surfel> &newSurfels) {
+    std::vector<int> deletedIndex;
+    for (int i = 0; i < (int)local.size(); i++)
+        if (local[i].updateTimes == 0) deletedIndex.push_back(i);
+    for (size_t i = 0; i < newSurfels.size(); i++) {
+        if (newSurfels[i].updateTimes != 0) {
+            if (!deletedIndex.empty()) { local[deletedIndex.back()] = newSurfels[i]; deletedIndex.pop_back(); }
+            else local.push_back(newSurfels[i]);
+        }
+    }
+    while (!deletedIndex.empty()) {
+        local[deletedIndex.back()] = local.back();
+        deletedIndex.pop_back();
+        local.pop_back();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+struct mslo_sf {
+    Fusion f;
+    std::vector<Surfel> map;  // resident-map emulation
+    mslo_sf(int w, int h, float fx, float fy, float cx, float cy, float far_, float near_) : f(w, h, fx, fy, cx, cy, far_, near_) {}
+};
+
+#define MSLO_API __attribute__((visibility("default")))
+
+MSLO_API mslo_sf *mslo_sf_create(int w, int h, float fx, float fy, float cx, float cy, float far_, float near_) {
+    return new mslo_sf(w, h, fx, fy, cx, cy, far_, near_);
+}
+MSLO_API void mslo_sf_destroy(mslo_sf *h) { delete h; }
+
+// SurfelFusion::fuseInitializeMap: local updated in place, returns number of new surfels (or -1)
+MSLO_API long mslo_sf_fuse(mslo_sf *h, int ref, const uint8_t *gray, size_t gstride, const float *depth, size_t dstride,
+                           const int32_t *member, size_t mstride, const float *pose, msl_surfel *local, size_t n_local,
+                           msl_surfel *new_out, size_t new_cap) {
+    std::vector<Surfel> nw;
+    h->f.fuseInitializeMap(ref, gray, gstride, depth, dstride, member, mstride, pose, local, n_local, nw);
+    if (nw.size() > new_cap) return -1;
+    if (!nw.empty()) memcpy(new_out, nw.data(), nw.size() * sizeof(Surfel));
+    return (long)nw.size();
+}
+
+// resident-map emulation: fuseInitializeMap + SurfelMapping::fuseMap compaction
+MSLO_API void mslo_sf_map_set(mslo_sf *h, const msl_surfel *s, size_t n) { h->map.assign(s, s + n); }
+MSLO_API size_t mslo_sf_map_size(mslo_sf *h) { return h->map.size(); }
+MSLO_API void mslo_sf_map_get(mslo_sf *h, msl_surfel *out) { if (!h->map.empty()) memcpy(out, h->map.data(), h->map.size() * sizeof(Surfel)); }
+MSLO_API long mslo_sf_fuse_map(mslo_sf *h, int ref, const uint8_t *gray, size_t gstride, const float *depth, size_t dstride,
+                               const int32_t *member, size_t mstride, const float *pose) {
+    std::vector<Surfel> nw;
+    h->f.fuseInitializeMap(ref, gray, gstride, depth, dstride, member, mstride, pose, h->map.data(), h->map.size(), nw);
+    fuse_map_compact(h->map, nw);
+    return (long)nw.size();
+}
+MSLO_API void mslo_sf_seeds(mslo_sf *h, msl_seed *out) { memcpy(out, h->f.seeds.data(), h->f.seeds.size() * sizeof(Seed)); }
+MSLO_API void mslo_sf_index(mslo_sf *h, int32_t *out) { memcpy(out, h->f.index.data(), h->f.index.size() * sizeof(int)); }
+
+// stand-alone compaction on caller arrays; local must have room for n_local + n_new; returns new size
+MSLO_API size_t mslo_fuse_map_compact(msl_surfel *local, size_t n_local, const msl_surfel *nw, size_t n_new) {
+    std::vector<Surfel> l(local, local + n_local), n(nw, nw + n_new);
+    fuse_map_compact(l, n);
+    if (!l.empty()) memcpy(local, l.data(), l.size() * sizeof(Surfel));
+    return l.size();
+}
+MSLO_API void mslo_inverse4f(const float *m, float *inv) { inverse4<float>(m, inv); }
+
+}  // extern "C"

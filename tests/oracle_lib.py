@@ -160,3 +160,76 @@ def load():
     if _cached is None:
         _cached = Oracle(C.CDLL(build()))
     return _cached
+
+
+# ------------------------------------------------------------------------------------------------
+# Surfel fusion
+# ------------------------------------------------------------------------------------------------
+class OracleSurfel:
+    def __init__(self, w, h, fx, fy, cx, cy, far=30.0, near=0.5):
+        self.o = load()
+        d = self.o.dll
+        d.mslo_sf_create.restype = C.c_void_p
+        d.mslo_sf_create.argtypes = [C.c_int, C.c_int] + [C.c_float] * 6
+        d.mslo_sf_destroy.argtypes = [C.c_void_p]
+        d.mslo_sf_fuse.restype = C.c_long
+        d.mslo_sf_fuse.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        d.mslo_sf_map_set.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        d.mslo_sf_map_size.restype = C.c_size_t
+        d.mslo_sf_map_size.argtypes = [C.c_void_p]
+        d.mslo_sf_map_get.argtypes = [C.c_void_p, C.c_void_p]
+        d.mslo_sf_fuse_map.restype = C.c_long
+        d.mslo_sf_fuse_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_void_p]
+        d.mslo_sf_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        d.mslo_sf_index.argtypes = [C.c_void_p, C.c_void_p]
+        d.mslo_fuse_map_compact.restype = C.c_size_t
+        d.mslo_fuse_map_compact.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        self.w, self.h = w, h
+        self.hd = d.mslo_sf_create(w, h, fx, fy, cx, cy, far, near)
+
+    def __del__(self):
+        if getattr(self, "hd", None):
+            self.o.dll.mslo_sf_destroy(self.hd)
+            self.hd = None
+
+    def fuse(self, ref, gray, depth, member, pose, local):
+        """SurfelFusion::fuseInitializeMap: returns (updated local copy, new surfels)."""
+        local = local.copy()
+        new = np.zeros((self.w // 8) * (self.h // 8), SURFEL_DTYPE)
+        n = self.o.dll.mslo_sf_fuse(self.hd, ref, _p(gray), gray.strides[0], _p(depth), depth.strides[0], _p(member),
+                                    member.strides[0], _p(pose), _p(local), len(local), _p(new), len(new))
+        assert n >= 0
+        return local, new[:n].copy()
+
+    def map_set(self, m):
+        m = np.ascontiguousarray(m)
+        self.o.dll.mslo_sf_map_set(self.hd, _p(m), len(m))
+
+    def map_get(self):
+        out = np.zeros(self.o.dll.mslo_sf_map_size(self.hd), SURFEL_DTYPE)
+        self.o.dll.mslo_sf_map_get(self.hd, _p(out))
+        return out
+
+    def fuse_map(self, ref, gray, depth, member, pose):
+        return int(self.o.dll.mslo_sf_fuse_map(self.hd, ref, _p(gray), gray.strides[0], _p(depth), depth.strides[0], _p(member),
+                                               member.strides[0], _p(pose)))
+
+    def seeds(self):
+        out = np.zeros((self.w // 8) * (self.h // 8), SEED_DTYPE)
+        self.o.dll.mslo_sf_seeds(self.hd, _p(out))
+        return out
+
+    def index(self):
+        out = np.zeros((self.h, self.w), np.int32)
+        self.o.dll.mslo_sf_index(self.hd, _p(out))
+        return out
+
+
+def fuse_map_compact(local, new):
+    buf = np.zeros(len(local) + len(new), SURFEL_DTYPE)
+    buf[:len(local)] = local
+    new = np.ascontiguousarray(new)
+    n = load().dll.mslo_fuse_map_compact(_p(buf), len(local), _p(new), len(new))
+    return buf[:n].copy()

@@ -1,0 +1,140 @@
+"""GPU parity: HIP surfel fusion (through the C ABI) vs the CPU oracle.
+
+Tolerance (BASELINE.json north_star): positions / normals / radii within 1e-4 of the CPU path; integer fields
+and array order identical.  In practice everything except the FP64 plane-fit reductions is bit-identical."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+FLOAT_FIELDS = ("px", "py", "pz", "nx", "ny", "nz", "size", "color", "weight")
+INT_FIELDS = ("r", "g", "b", "updateTimes", "lastUpdate")
+
+
+def assert_surfels_close(a, b, what=""):
+    assert len(a) == len(b), (what, len(a), len(b))
+    for f in INT_FIELDS:
+        assert np.array_equal(a[f], b[f]), (what, f, np.flatnonzero(a[f] != b[f])[:10])
+    for f in FLOAT_FIELDS:
+        d = np.abs(a[f].astype(np.float64) - b[f].astype(np.float64))
+        assert np.all(np.isnan(a[f]) == np.isnan(b[f])), (what, f)
+        d = d[~np.isnan(d)]
+        assert d.size == 0 or d.max() <= TOL, (what, f, d.max())
+
+
+def assert_seeds_close(a, b):
+    for f in ("r", "g", "b", "fused", "stable", "use"):
+        assert np.array_equal(a[f], b[f]), (f, np.flatnonzero(a[f] != b[f])[:10])
+    for f in ("x", "y", "meanIntensity"):
+        assert np.array_equal(a[f].view(np.int32), b[f].view(np.int32)), f
+    for f in ("size", "normX", "normY", "normZ", "posX", "posY", "posZ", "viewCos", "meanDepth"):
+        d = np.abs(a[f].astype(np.float64) - b[f].astype(np.float64))
+        assert np.all(np.isnan(a[f]) == np.isnan(b[f])), f
+        d = d[~np.isnan(d)]
+        assert d.max() <= TOL, (f, d.max(), np.argmax(d))
+
+
+def _mk(intr, w=640, h=480):
+    from manhattanslam_amd import SurfelFusion
+    from tests.oracle_lib import OracleSurfel
+    g = SurfelFusion(w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5)
+    o = OracleSurfel(w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5)
+    return g, o
+
+
+@pytest.mark.parametrize("variant", ["A", "B"])
+def test_host_vector_mode_matches_oracle(oracle, variant):
+    """SurfelFusion::fuseInitializeMap drop-in: local vector updated in place + new surfel list."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    local = synth.surfel_map(50000, ref=3).astype(SURFEL_DTYPE)
+    gray, depth, member, pose = synth.surfel_frame(3, variant=variant)
+    lo, no = o.fuse(3, gray, depth, member, pose, local)
+    lg = local.copy()
+    ng = g.fuseInitializeMap(3, gray, depth, member, pose, lg)
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(lg, lo, "local")
+    assert_surfels_close(ng, no, "new")
+    assert (lg["updateTimes"] == 0).sum() > 100 and (lg["lastUpdate"] == 3).sum() > 1000 and len(ng) > 50
+    g.close()
+
+
+def test_resident_sequence_matches_oracle(oracle):
+    """Five keyframes on the resident map incl. slot refill and tail compaction (fuseMap)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(120000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(300000)
+    g.map_upload(m)
+    o.map_set(m)
+    for k in range(5):
+        gray, depth, member, pose = synth.surfel_frame(k, variant="B" if k == 2 else "A")
+        g.fuse_resident(k, gray, depth, member, pose)
+        n_new = o.fuse_map(k, gray, depth, member, pose)
+        c = g.counters()
+        assert c["n_new"] == n_new
+        mg, mo = g.map_download(), o.map_get()
+        assert c["n_live_after"] == len(mo)
+        assert_surfels_close(mg, mo, f"map after keyframe {k}")
+    g.close()
+
+
+def test_icl_negative_fy_and_empty_map(oracle):
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.ICL)
+    gray, depth, member, pose = synth.surfel_frame(1, intr=synth.ICL)
+    local = np.zeros(0, SURFEL_DTYPE)
+    lo, no = o.fuse(1, gray, depth, member, pose, local)
+    ng = g.fuseInitializeMap(1, gray, depth, member, pose, local)
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(ng, no, "new")
+    assert len(ng) > 1000
+    g.close()
+
+
+def test_degenerate_depth(oracle):
+    """All-invalid depth: no seed gets a plane, nothing fuses, no new surfels; then a depth image with holes."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    gray, depth, member, pose = synth.surfel_frame(0)
+    zero = np.zeros_like(depth)
+    local = synth.surfel_map(2000, ref=0).astype(SURFEL_DTYPE)
+    lo, no = o.fuse(0, gray, zero, member, pose, local)
+    lg = local.copy()
+    ng = g.fuseInitializeMap(0, gray, zero, member, pose, lg)
+    assert len(ng) == len(no) == 0
+    assert_surfels_close(lg, lo)
+    holes = depth.copy()
+    holes[100:300, 200:500] = 0
+    holes[::7, ::5] = 0
+    lo, no = o.fuse(1, gray, holes, member, pose, local)
+    lg = local.copy()
+    ng = g.fuseInitializeMap(1, gray, holes, member, pose, lg)
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(lg, lo)
+    assert_surfels_close(ng, no)
+    g.close()
+
+
+def test_compaction_matches_literal_loop(oracle):
+    """Slot refill / tail compaction against the literal back-to-front loop for adversarial delete patterns."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    from tests.oracle_lib import fuse_map_compact
+    g, o = _mk(synth.TUM1)
+    rng = np.random.default_rng(3)
+    gray, depth, member, pose = synth.surfel_frame(0)
+    for trial, (n, pdel) in enumerate([(5000, 0.0), (5000, 0.9), (20000, 0.5), (9000, 1.0), (4097, 0.3)]):
+        m = synth.surfel_map(n, ref=0, seed=100 + trial).astype(SURFEL_DTYPE)
+        m["updateTimes"][rng.random(n) < pdel] = 0         # pre-deleted slots
+        m["pz"] += 100.0                                   # far away: the fuse step itself changes nothing else
+        m["lastUpdate"] = 0
+        g.map_upload(m)
+        g.fuse_resident(0, gray, depth, member, pose)
+        mg = g.map_download()
+        lo, no = o.fuse(0, gray, depth, member, pose, m)
+        expect = fuse_map_compact(lo, no)
+        assert_surfels_close(mg, expect, f"trial {trial}")
+    g.close()
