@@ -135,10 +135,12 @@ MSL_API int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h
 MSL_API int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out);
 MSL_API int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys /*3 ints each*/,
                                      int cap, int *n_out);
-/* Per-kernel timing: when enabled, every launch is bracketed by HIP events on the handle's
- * stream; msl_orb_profile_read returns accumulated milliseconds and launch counts per kernel. */
+/* Per-kernel timing with HIP events on the handle's stream.  mode 0 = off, -1 = every kernel,
+ * otherwise a bit mask of kernel ids (bit k = time kernel k only, so a timed region can carry a
+ * single kernel's events).  msl_orb_profile_read returns accumulated milliseconds and launch
+ * counts per kernel since the last enable call. */
 #define MSL_ORB_NKERNELS 6
-MSL_API int msl_orb_profile_enable(msl_orb *h, int on);
+MSL_API int msl_orb_profile_enable(msl_orb *h, int mode);
 MSL_API int msl_orb_profile_read(msl_orb *h, float *ms /*[MSL_ORB_NKERNELS]*/,
                                  int32_t *launches /*[MSL_ORB_NKERNELS]*/);
 MSL_API const char *msl_orb_kernel_name(int k);
@@ -187,7 +189,7 @@ MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
 
 #define MSL_SF_NKERNELS 12
-MSL_API int msl_sf_profile_enable(msl_sf *h, int on);
+MSL_API int msl_sf_profile_enable(msl_sf *h, int mode);
 MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);
 MSL_API const char *msl_sf_kernel_name(int k);
 

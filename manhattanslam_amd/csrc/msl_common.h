@@ -27,9 +27,12 @@ void set_error(const char *fmt, ...);
 
 int bind_device(int device);  // hipSetDevice + gfx950 check; returns msl_status
 
-// Event-pair profiler: one (start, stop) pair per launch, drained at sync points.
+// Event-pair profiler: one (start, stop) pair per launch of the selected kernels, drained at sync points.
+// set_mode(0) = off, set_mode(-1) = every kernel, otherwise a bit mask of kernel ids.
 struct KernelProfiler {
     bool on = false;
+    unsigned mask = 0xFFFFFFFFu;  // bit k set = kernel id k is timed
+    bool open_ = false;
     int nk = 0;
     float ms[16] = {0};
     int32_t launches[16] = {0};
@@ -39,6 +42,7 @@ struct KernelProfiler {
     void begin(int k, hipStream_t s);
     void end(hipStream_t s);
     void drain();  // requires the stream to be idle
+    void set_mode(int m) { on = m != 0; mask = (unsigned)m; for (int i = 0; i < 16; i++) { ms[i] = 0; launches[i] = 0; } }
     void destroy();
 };
 

@@ -32,7 +32,8 @@ int bind_device(int device) {
 }
 
 void KernelProfiler::begin(int k, hipStream_t s) {
-    if (!on) return;
+    open_ = false;
+    if (!on || !((mask >> k) & 1u)) return;
     if (npairs == cap) {
         int ncap = cap ? cap * 2 : 256;
         Pair *np = (Pair *)realloc(pairs, sizeof(Pair) * ncap);
@@ -42,9 +43,11 @@ void KernelProfiler::begin(int k, hipStream_t s) {
     }
     pairs[npairs].k = k;
     (void)hipEventRecord(pairs[npairs].a, s);
+    open_ = true;
 }
 void KernelProfiler::end(hipStream_t s) {
-    if (!on || npairs >= cap) return;
+    if (!open_ || npairs >= cap) return;
+    open_ = false;
     (void)hipEventRecord(pairs[npairs].b, s);
     npairs++;
 }

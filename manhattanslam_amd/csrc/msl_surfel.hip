@@ -1109,8 +1109,7 @@ int msl_sf_profile_enable(msl_sf *h, int on) {
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
     h->prof.drain();
-    h->prof.on = on != 0;
-    for (int i = 0; i < 16; i++) { h->prof.ms[i] = 0; h->prof.launches[i] = 0; }
+    h->prof.set_mode(on);
     return MSL_OK;
 }
 int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {

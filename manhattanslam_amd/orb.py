@@ -119,8 +119,8 @@ class ORBextractor:
         check(lib.msl_orb_debug_candidates(self._h, frame, level, ptr(out), cap, C.byref(n)))
         return out[:n.value].copy()
 
-    def profile_enable(self, on=True):
-        check(lib.msl_orb_profile_enable(self._h, int(on)))
+    def profile_enable(self, mode=-1):
+        check(lib.msl_orb_profile_enable(self._h, int(mode)))
 
     def profile_read(self):
         ms = np.zeros(MSL_ORB_NKERNELS, np.float32)

@@ -101,8 +101,8 @@ class SurfelFusion:
         check(lib.msl_sf_debug_index(self._h, ptr(out)))
         return out
 
-    def profile_enable(self, on=True):
-        check(lib.msl_sf_profile_enable(self._h, int(on)))
+    def profile_enable(self, mode=-1):
+        check(lib.msl_sf_profile_enable(self._h, int(mode)))
 
     def profile_read(self):
         ms = np.zeros(MSL_SF_NKERNELS, np.float32)

@@ -117,7 +117,7 @@ def surfel_frame(k, w=640, h=480, intr=TUM1, variant="A", seed=7):
     return (np.clip(gray, 0, 255).astype(np.uint8), np.ascontiguousarray(depth.astype(np.float32)), member, pose)
 
 
-def surfel_map(n, ref=0, seed=11):
+def surfel_map(n, ref=0, seed=11, min_update_times=1):
     """n live surfels pre-seeded on the room surfaces (area-uniform), as a structured array."""
     rng = np.random.Generator(np.random.PCG64(seed))
     ex = ROOM * 2
@@ -142,6 +142,6 @@ def surfel_map(n, ref=0, seed=11):
     m["color"] = rng.integers(0, 256, n)
     m["r"] = m["g"] = m["b"] = rng.integers(0, 256, n)
     m["weight"] = rng.uniform(1, 20, n)
-    m["updateTimes"] = rng.integers(1, 21, n)
+    m["updateTimes"] = rng.integers(min_update_times, 21, n)
     m["lastUpdate"] = ref - rng.integers(0, 9, n)
     return m
