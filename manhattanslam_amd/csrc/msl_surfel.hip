@@ -62,7 +62,7 @@ struct SfDev {
     msl_surfel *newSurfels;
     unsigned *blockSums;  // scan partials
     unsigned *delList;    // ascending deleted indices
-    unsigned *scanTmp;
+    unsigned *srcOf;      // tail compaction: source position per low hole
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_prop(SfDev P, int round) {
     if (P.tmin[P.index[p]] <= (unsigned)p) {
         if (P.tmin[a] > (unsigned)p + 1u) {
             const unsigned old = atomicMin(&P.tmin[a], (unsigned)p + 1u);
-            if (old > (unsigned)p + 1u) { P.changed[round + 1] = 1; if (P.ctr[7] < round + 1) P.ctr[7] = round + 1; }
+            if (old > (unsigned)p + 1u) P.changed[round + 1] = 1;
         }
     }
 }
@@ -706,44 +706,60 @@ __global__ __launch_bounds__(256) void k_place_new(SfDev P) {
     store_surfel(P.map, dst, P.newSurfels[k]);
 }
 
-// Tail compaction when D > K.  Single workgroup pass over the tail region [nFinal, n) (<= D-K items).
-__global__ __launch_bounds__(1024) void k_tail_compact(SfDev P) {
-    __shared__ unsigned s_wave[17];
+// Tail compaction when D > K (the `while (deletedIndex.size() > 0)` loop, SurfelMapping.cpp:386-390).
+// Step i (i = 1..R) of the literal loop moves the element at position n-i into the i-th largest leftover
+// hole.  A hole inside the tail [nFinal, n) only relays: what lands there is moved again later.  So the
+// a-th smallest leftover hole (all < nFinal) finally receives resolve(nFinal + a), where
+// resolve(p) = p if p is live, else resolve(n - rank_desc(p)) -- a short upward chain.
+constexpr int TAIL_MAX_HOPS = 64;
+
+__global__ __launch_bounds__(256) void k_tail_resolve(SfDev P) {
     const long long n = P.ctr[4], D = P.ctr[2], K = P.ctr[1];
-    if (P.ctr[5] == 20) return;
-    if (threadIdx.x == 0 && blockIdx.x == 0) P.ctr[0] = P.ctr[6];
-    if (D <= K) return;
-    const long long R = D - K;          // leftover holes: delList[0..R)
-    const long long nFinal = n - R;
-    // a tail position p is a leftover hole iff it is deleted and its ascending rank < R; equivalently it
-    // appears in delList[0..R).  Low holes = delList[j], j < cntLow, where cntLow = #entries < nFinal.
-    // Each workgroup handles a slice of the tail; ranks come from delList by binary search.
-    const long long per = (R + gridDim.x - 1) / gridDim.x;
-    const long long t0 = nFinal + (long long)blockIdx.x * per, t1 = min(t0 + per, n);
-    if (t0 >= t1) return;
-    // number of leftover holes below position x: lower_bound on delList[0..R)
-    auto holes_below = [&](long long x) -> long long {
+    if (P.ctr[5] == 20 || D <= K) return;
+    const long long R = D - K, nFinal = n - R;
+    auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
         long long lo = 0, hi = R;
         while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < x) lo = mid + 1; else hi = mid; }
         return lo;
     };
-    const long long cntLow = holes_below(nFinal);
-    // live tail elements before t0: (t0 - nFinal) - (holes in [nFinal, t0))
-    long long liveBase = (t0 - nFinal) - (holes_below(t0) - cntLow);
-    for (long long c0 = t0; c0 < t1; c0 += 1024) {
-        const long long p = c0 + threadIdx.x;
-        bool live = false;
-        if (p < t1) {
-            // hole iff p in delList[0..R)
-            const long long lb = holes_below(p);
-            live = !(lb < R && (long long)P.delList[lb] == p);
+    const long long cntLow = lower(nFinal);
+    for (long long a = (long long)blockIdx.x * 256 + threadIdx.x; a < cntLow; a += (long long)gridDim.x * 256) {
+        long long p = nFinal + a;
+        int hop = 0;
+        for (; hop < TAIL_MAX_HOPS; hop++) {
+            const long long lb = lower(p);
+            if (lb < R && (long long)P.delList[lb] == p) p = n - (R - lb);   // relay hole: follow to where its content came from
+            else break;
         }
-        unsigned tot;
-        const unsigned pos = block_excl_scan(live ? 1u : 0u, s_wave, &tot);
-        if (live) move_surfel(P.map, (long long)P.delList[liveBase + pos], p);
-        liveBase += tot;
+        if (hop == TAIL_MAX_HOPS) P.ctr[7] = -1;   // pathological chain: fall back to the literal loop
+        P.srcOf[a] = (unsigned)p;
     }
-    (void)cntLow;
+}
+
+__global__ __launch_bounds__(256) void k_tail_move(SfDev P) {
+    const long long n = P.ctr[4], D = P.ctr[2], K = P.ctr[1];
+    if (P.ctr[5] == 20) return;
+    if (D > K) {
+        const long long R = D - K, nFinal = n - R;
+        if (P.ctr[7] == -1) {
+            // literal back-to-front loop, one thread (only for pathological delete patterns)
+            if (blockIdx.x == 0 && threadIdx.x == 0)
+                for (long long i = 1; i <= R; i++) {
+                    const long long hole = P.delList[R - i], src = n - i;
+                    if (src != hole) move_surfel(P.map, hole, src);
+                }
+        } else {
+            long long lo = 0, hi = R;
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < nFinal) lo = mid + 1; else hi = mid; }
+            const long long cntLow = lo;
+            for (long long a = (long long)blockIdx.x * 256 + threadIdx.x; a < cntLow; a += (long long)gridDim.x * 256)
+                move_surfel(P.map, (long long)P.delList[a], (long long)P.srcOf[a]);
+        }
+    }
+}
+
+__global__ void k_end_frame(long long *ctr) {
+    if (threadIdx.x == 0 && ctr[5] != 20) { ctr[0] = ctr[6]; if (ctr[7] == -1) ctr[7] = 0; }
 }
 
 // AoS <-> SoA conversion for upload / download / host-vector mode
@@ -786,7 +802,7 @@ struct msl_sf {
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;  // pinned mirror
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
-    unsigned *d_blockSums = nullptr, *d_delList = nullptr;
+    unsigned *d_blockSums = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
 };
@@ -800,23 +816,24 @@ void set_map_ptrs(msl_sf *h) {
     M.r = (int *)(b + 8 * c); M.g = (int *)(b + 9 * c); M.b = (int *)(b + 10 * c); M.weight = b + 11 * c;
     M.updateTimes = (int *)(b + 12 * c); M.lastUpdate = (int *)(b + 13 * c);
     h->dev.cap = c;
-    h->dev.blockSums = h->d_blockSums; h->dev.delList = h->d_delList;
+    h->dev.blockSums = h->d_blockSums; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
 }
 
 // (Re)allocate the resident map for `cap` surfels, preserving the first `keep` entries.
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 1023) & ~(size_t)1023;
-    float *nstore = nullptr; unsigned *nbs = nullptr, *ndl = nullptr;
+    float *nstore = nullptr; unsigned *nbs = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
     MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 2)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
+    MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
     if (keep && h->d_mapStore) {
         MSL_HIP_TRY(hipStreamSynchronize(h->stream));
         for (int a = 0; a < 14; a++)
             MSL_HIP_TRY(hipMemcpy(nstore + (size_t)a * cap, h->d_mapStore + (size_t)a * h->mapCap, sizeof(float) * keep, hipMemcpyDeviceToDevice));
     }
-    if (h->d_mapStore) { (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_delList); }
-    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_delList = ndl; h->mapCap = cap;
+    if (h->d_mapStore) { (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf); }
+    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_delList = ndl; h->d_srcOf = nso; h->mapCap = cap;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -900,7 +917,9 @@ int launch_fusion(msl_sf *h, int ref, const float pose[16], bool compact) {
         hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, P);
         hipLaunchKernelGGL(k_del_list, dim3(512), dim3(1024), 0, s, P);
         hipLaunchKernelGGL(k_place_new, dim3((P.nseeds + 255) / 256), dim3(256), 0, s, P);
-        hipLaunchKernelGGL(k_tail_compact, dim3(64), dim3(1024), 0, s, P);
+        hipLaunchKernelGGL(k_tail_resolve, dim3(256), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_tail_move, dim3(256), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_end_frame, dim3(1), dim3(64), 0, s, P.ctr);
         h->prof.end(s);
     }
     MSL_HIP_TRY(hipGetLastError());
@@ -953,7 +972,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
     F(h->d_gray); F(h->d_depth); F(h->d_member); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_ctr); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_delList); F(h->d_aos);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_ctr); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->stream && h->ownStream) (void)hipStreamDestroy(h->stream);
     delete h;

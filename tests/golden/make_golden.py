@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Regenerates the golden vectors under tests/golden/ from the CPU oracle.
+
+The reference ships no golden vectors and cannot be built in this image (OpenCV/Eigen absent), so these
+fixtures pin the *oracle's* outputs on seeded synthetic inputs (inputs are regenerated from the seed; only
+a SHA-256 of the input is stored).  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from manhattanslam_amd import synth  # noqa: E402
+from tests import oracle_lib  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+o = oracle_lib.load()
+
+seed = synth.ORB_SEED + 5
+img = synth.orb_frame(seed)
+k, d = o.orb_create().extract(img)
+np.savez_compressed(os.path.join(OUT, "orb_640x480.npz"), seed=seed, image_sha256=hashlib.sha256(img.tobytes()).hexdigest(),
+                    keypoints=k, descriptors=d)
+seed = 42
+img = synth.orb_frame(seed, 400, 304)
+k, d = o.orb_create(500, 1.2, 6, 25, 9).extract(img)
+np.savez_compressed(os.path.join(OUT, "orb_400x304.npz"), seed=seed, image_sha256=hashlib.sha256(img.tobytes()).hexdigest(),
+                    keypoints=k, descriptors=d)
+
+I = synth.TUM1
+sf = oracle_lib.OracleSurfel(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+local = synth.surfel_map(30000, ref=2).astype(oracle_lib.SURFEL_DTYPE)
+gray, depth, member, pose = synth.surfel_frame(2, variant="B")
+lo, no = sf.fuse(2, gray, depth, member, pose, local)
+changed = np.flatnonzero((lo.view(np.uint8).reshape(len(lo), -1) != local.view(np.uint8).reshape(len(lo), -1)).any(1))
+np.savez_compressed(os.path.join(OUT, "surfel_640x480_B.npz"), frame=2, n_local=len(local),
+                    depth_sha256=hashlib.sha256(depth.tobytes()).hexdigest(), new_surfels=no, changed_index=changed.astype(np.int32),
+                    changed_surfels=lo[changed], seeds=sf.seeds(), index_sha256=hashlib.sha256(sf.index().tobytes()).hexdigest())
+print("golden vectors written:", os.listdir(OUT))

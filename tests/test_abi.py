@@ -1,0 +1,74 @@
+"""The C-ABI library loads and exports every symbol include/msl.h declares; no compute calls (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "msl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"MSL_API[^;(]*?\b(msl_\w+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from manhattanslam_amd import _lib
+    names = _declared()
+    assert len(names) >= 35
+    dll = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(dll, n), f"{n} declared in include/msl.h but not exported by libmsl.so"
+    assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_struct_layouts_match_reference_types():
+    from manhattanslam_amd import KEYPOINT_DTYPE, SURFEL_DTYPE, SEED_DTYPE
+    assert KEYPOINT_DTYPE.itemsize == 28      # cv::KeyPoint
+    assert SURFEL_DTYPE.itemsize == 56        # struct Surfel, reference include/Surfel.h:28-37
+    assert SEED_DTYPE.itemsize == 64          # SurfelFusion::SuperpixelSeed, include/SurfelFusion.h:46-58
+    assert [SURFEL_DTYPE.fields[n][1] for n in ("px", "size", "r", "weight", "updateTimes", "lastUpdate")] == [0, 24, 32, 44, 48, 52]
+
+
+def test_version_and_error_strings():
+    from manhattanslam_amd import lib
+    assert b"gfx950" in lib.msl_version()
+    assert isinstance(lib.msl_last_error(), bytes)
+    assert lib.msl_orb_kernel_name(1) == b"k_fast" and lib.msl_sf_kernel_name(7) == b"k_fuse"
+
+
+def test_no_cpu_fallback():
+    """Without an MI355X the constructors fail loudly instead of computing on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from manhattanslam_amd import MslError, ORBextractor, SurfelFusion, device_count
+    assert device_count() == 0
+    with pytest.raises(MslError, match="no HIP device|no CPU fallback|not usable"):
+        ORBextractor(1000, 1.2, 8, 20, 7)
+    with pytest.raises(MslError):
+        SurfelFusion(640, 480, 500.0, 500.0, 320.0, 240.0, 30.0, 0.5)
+
+
+def test_product_does_not_reference_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "manhattanslam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in txt.replace("oracle/ is test infrastructure", "") or f.endswith(".md"), os.path.join(dirpath, f)
+                assert "libmsl_oracle" not in txt and "oracle_lib" not in txt, os.path.join(dirpath, f)
+
+
+def test_synth_is_deterministic():
+    from manhattanslam_amd import synth
+    a, b = synth.orb_frame(123), synth.orb_frame(123)
+    assert np.array_equal(a, b) and a.shape == (480, 640) and a.dtype == np.uint8
+    g1 = synth.surfel_frame(3)
+    g2 = synth.surfel_frame(3)
+    assert all(np.array_equal(x, y) for x, y in zip(g1, g2))
+    m = synth.surfel_map(1000)
+    assert m.dtype.itemsize == 56 and np.array_equal(m, synth.surfel_map(1000))

@@ -1,0 +1,41 @@
+"""GPU vs the committed golden vectors (tests/golden/*.npz) -- independent of the oracle library at run time."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_orb_golden_bit_exact():
+    from manhattanslam_amd import ORBextractor, synth
+    g = np.load(os.path.join(GOLD, "orb_640x480.npz"))
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    k, d = ex(synth.orb_frame(int(g["seed"])))
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    ex.close()
+    g = np.load(os.path.join(GOLD, "orb_400x304.npz"))
+    ex = ORBextractor(500, 1.2, 6, 25, 9, max_width=400, max_height=304)
+    k, d = ex(synth.orb_frame(int(g["seed"]), 400, 304))
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    ex.close()
+
+
+def test_surfel_golden_within_tolerance():
+    from manhattanslam_amd import SurfelFusion, synth, SURFEL_DTYPE
+    from tests.test_surfel_gpu import assert_surfels_close
+    g = np.load(os.path.join(GOLD, "surfel_640x480_B.npz"))
+    k = int(g["frame"])
+    gray, depth, member, pose = synth.surfel_frame(k, variant="B")
+    local = synth.surfel_map(int(g["n_local"]), ref=k).astype(SURFEL_DTYPE)
+    I = synth.TUM1
+    sf = SurfelFusion(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+    before = local.copy()
+    new = sf.fuseInitializeMap(k, gray, depth, member, pose, local)
+    assert_surfels_close(new, g["new_surfels"].view(SURFEL_DTYPE), "new")
+    ci = g["changed_index"]
+    assert_surfels_close(local[ci], g["changed_surfels"].view(SURFEL_DTYPE), "changed")
+    untouched = np.setdiff1d(np.arange(len(local)), ci)
+    assert local[untouched].tobytes() == before[untouched].tobytes()
+    sf.close()

@@ -1,0 +1,196 @@
+"""CPU tests of the ORB oracle: known-answer tests derived from first principles and the
+committed golden vectors.  No GPU needed."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from manhattanslam_amd import synth  # noqa: E402  (package import binds libmsl.so symbols, no GPU call)
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0),
+        (-3, 1), (-2, 2), (-1, 3)]
+
+
+def test_constructor_tables(oracle):
+    t = oracle.orb_create(1000, 1.2, 8, 20, 7).tables()
+    assert t[4].tolist() == [217, 181, 151, 126, 105, 87, 73, 60]          # mnFeaturesPerLevel
+    assert t[5].tolist() == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]  # umax
+    sf = np.float32(1.0)
+    for i in range(8):
+        assert t[0][i] == sf and t[1][i] == np.float32(1.0) / sf and t[2][i] == sf * sf
+        sf = np.float32(sf * np.float32(1.2))
+
+
+def test_level_sizes(oracle):
+    ex = oracle.orb_create()
+    ex.extract(synth.orb_frame(1))
+    assert [ex.level(l).shape[::-1] for l in range(8)] == [(640, 480), (533, 400), (444, 333), (370, 278), (309, 231), (257, 193),
+                                                            (214, 161), (179, 134)]
+
+
+def test_resize_known_answers(oracle):
+    c = np.full((48, 64), 93, np.uint8)
+    assert np.all(oracle.resize(c, 53, 40) == 93)                 # constant stays constant
+    # horizontal ramp: closed form of the 11-bit fixed-point bilinear interpolation
+    src = np.tile((np.arange(64) * 3).astype(np.uint8), (48, 1))
+    dst = oracle.resize(src, 53, 40)
+    sx_scale = 1.0 / (53 / 64)
+    for dx in (0, 1, 17, 52):
+        fx = np.float32((dx + 0.5) * sx_scale - 0.5)
+        sx = int(np.floor(fx)); fx = np.float32(fx - sx)
+        if sx >= 63:
+            sx, fx = 63, np.float32(0)
+        a0 = int(np.rint(np.float32(np.float32(1) - fx) * np.float32(2048))); a1 = int(np.rint(fx * np.float32(2048)))
+        h = int(src[0, sx]) * a0 + int(src[0, min(sx + 1, 63)]) * a1
+        # both rows equal -> vertical pass mixes identical values with b0 + b1 (~2048)
+        got = int(dst[5, dx])
+        approx = h / 2048.0
+        assert abs(got - approx) <= 1.0, (dx, got, approx)
+    assert np.abs(dst.astype(int) - dst[0:1, :].astype(int)).max() <= 1    # rows agree up to the >>16 truncations
+
+
+def test_blur_known_answers(oracle):
+    assert oracle.gaussian_kernel().tolist() == [18, 34, 49, 55, 49, 34, 18]
+    for c in (0, 1, 100, 200, 255):
+        out = oracle.blur(np.full((20, 24), c, np.uint8))
+        assert np.all(out == min((c * 257 * 257 + 32768) >> 16, 255))     # gain 257^2/65536, saturated
+    imp = np.zeros((21, 21), np.uint8)
+    imp[10, 10] = 255
+    k = np.array([18, 34, 49, 55, 49, 34, 18])
+    expect = (np.outer(k, k) * 255 + 32768) >> 16
+    assert np.array_equal(oracle.blur(imp)[7:14, 7:14], expect)
+    # reflect-101 border: blur of a flipped image is the flipped blur
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (33, 45), dtype=np.uint8)
+    assert np.array_equal(oracle.blur(a[::-1, ::-1].copy()), oracle.blur(a)[::-1, ::-1])
+
+
+def _brute_fast(img, t):
+    """Literal FAST-9/16 + score-as-max-threshold + 3x3 NMS, written independently of the oracle."""
+    h, w = img.shape
+    score = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            v = int(img[y, x])
+            d = [v - int(img[y + dy, x + dx]) for dx, dy in RING]
+            best = -1
+            for s in range(16):
+                arc = [d[(s + j) % 16] for j in range(9)]
+                best = max(best, min(arc) - 1, min(-a for a in arc) - 1)
+            if best >= t:
+                score[y, x] = best
+    out = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s >= t and s > 0:
+                nb = score[y - 1:y + 2, x - 1:x + 2].copy()
+                nb[1, 1] = -1
+                if np.all(s > nb):
+                    out.append((x, y, s))
+    return np.array(out, np.int32).reshape(-1, 3)
+
+
+def test_fast_known_answers(oracle):
+    img = np.full((15, 15), 100, np.uint8)
+    for k in range(9):                                   # 9 contiguous brighter ring pixels
+        dx, dy = RING[k]
+        img[7 + dy, 7 + dx] = 150
+    got = oracle.fast(img, 20)
+    assert got.tolist() == [[7, 7, 49]]                  # score = min(p - v) - 1
+    img2 = img.copy()
+    dx, dy = RING[8]
+    img2[7 + dy, 7 + dx] = 100                           # unchanged: still exactly the same arc
+    img2[7 + RING[0][1], 7 + RING[0][0]] = 100           # only 8 contiguous -> no corner
+    assert len(oracle.fast(img2, 20)) == 0
+    # darker arc, threshold boundary: diff of exactly t is not a corner, t+1 is
+    img3 = np.full((15, 15), 100, np.uint8)
+    for k in range(4, 14):
+        dx, dy = RING[k]
+        img3[7 + dy, 7 + dx] = 80
+    assert len(oracle.fast(img3, 20)) == 0
+    assert oracle.fast(img3, 19).tolist() == [[7, 7, 19]]
+
+
+def test_fast_nms_ties_and_random(oracle):
+    rng = np.random.default_rng(7)
+    for trial in range(6):
+        img = rng.integers(0, 256, (24, 28), dtype=np.uint8)
+        if trial % 2:
+            img = (img // 64 * 64).astype(np.uint8)      # few grey levels -> many equal scores (ties suppress each other)
+        for t in (7, 20):
+            assert np.array_equal(oracle.fast(img, t), _brute_fast(img, t)), (trial, t)
+
+
+def test_fast_atan2_and_sincos(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        y, x = rng.normal(size=2) * 1000
+        a = oracle.fast_atan2(y, x)
+        ref = np.degrees(np.arctan2(y, x)) % 360
+        assert min(abs(a - ref), 360 - abs(a - ref)) < 0.02
+    assert oracle.fast_atan2(0, 1) == 0 and abs(oracle.fast_atan2(1, 0) - 90) < 1e-3
+    bad = 0
+    angles = np.concatenate([np.linspace(0, 2 * np.pi, 5000), rng.uniform(0, 6.3, 5000)]).astype(np.float32)
+    for a in angles:
+        s, c = oracle.sincos(a)
+        rs, rc = np.float32(np.sin(np.float64(a))), np.float32(np.cos(np.float64(a)))
+        assert abs(s - rs) <= abs(np.spacing(rs)) and abs(c - rc) <= abs(np.spacing(rc))
+        bad += (s != rs) + (c != rc)
+    assert bad <= 2      # the pinned evaluation is the correctly rounded value except for a handful of ties
+
+
+def test_ic_angle_and_descriptor(oracle):
+    img = np.zeros((64, 64), np.uint8)
+    img[32 + 5, 32 + 12] = 200                           # single bright pixel at (dx, dy) = (12, 5)
+    assert abs(oracle.ic_angle(img, 32, 32) - np.degrees(np.arctan2(5, 12))) < 0.02
+    img[:] = 0
+    img[32 - 9, 32 - 3] = 77
+    assert abs(oracle.ic_angle(img, 32, 32) - (np.degrees(np.arctan2(-9, -3)) % 360)) < 0.02
+    # descriptor at angle 0 = unrotated pattern; at 90 deg (x, y) -> (-y, x)
+    rng = np.random.default_rng(2)
+    bl = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    pat = np.loadtxt(os.path.join(os.path.dirname(__file__), "..", "include", "msl_orb_pattern.inc"), delimiter=",", comments="/*",
+                     usecols=range(16), dtype=np.int64).reshape(-1, 4)
+    for ang, rot in ((0.0, lambda x, y: (x, y)), (90.0, lambda x, y: (-y, x)), (180.0, lambda x, y: (-x, -y))):
+        bits = []
+        for x0, y0, x1, y1 in pat:
+            a0, b0 = rot(x0, y0); a1, b1 = rot(x1, y1)
+            bits.append(int(bl[32 + b0, 32 + a0]) < int(bl[32 + b1, 32 + a1]))
+        expect = np.packbits(np.array(bits, np.uint8), bitorder="little")
+        assert np.array_equal(oracle.descriptor(bl, 32, 32, ang), expect), ang
+
+
+def test_octree_properties(oracle):
+    rng = np.random.default_rng(3)
+    for n, N in ((0, 50), (1, 50), (3, 50), (40, 50), (800, 60), (5000, 217), (5000, 1)):
+        xs = rng.integers(0, 608, n); ys = rng.integers(0, 448, n)
+        pts = np.unique(np.stack([xs, ys], 1), axis=0)
+        rng.shuffle(pts)
+        resp = rng.integers(7, 255, len(pts))
+        xyr = np.concatenate([pts, resp[:, None]], 1).astype(np.float32)
+        sel = oracle.octree(xyr, 16, 624, 16, 464, N)
+        assert len(sel) <= max(N + 2, 4) and len(sel) <= len(pts)
+        if len(pts) >= N + 2:
+            assert len(sel) >= min(N, len(pts)) or len(pts) < 4 * N   # reaches the quota when there is material
+        # every selected key is one of the inputs, no duplicates
+        inp = {tuple(r) for r in xyr.tolist()}
+        assert all(tuple(r) in inp for r in sel.tolist())
+        assert len({(r[0], r[1]) for r in sel.tolist()}) == len(sel)
+        # deterministic
+        assert np.array_equal(sel, oracle.octree(xyr, 16, 624, 16, 464, N))
+
+
+def test_golden_orb(oracle):
+    """Committed golden vectors (tests/golden/make_golden.py) pin the oracle's behaviour."""
+    g = np.load(os.path.join(GOLD, "orb_640x480.npz"))
+    img = synth.orb_frame(int(g["seed"]))
+    assert hashlib.sha256(img.tobytes()).hexdigest() == str(g["image_sha256"])
+    k, d = oracle.orb_create().extract(img)
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+    g = np.load(os.path.join(GOLD, "orb_400x304.npz"))
+    img = synth.orb_frame(int(g["seed"]), 400, 304)
+    k, d = oracle.orb_create(500, 1.2, 6, 25, 9).extract(img)
+    assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])

@@ -1,0 +1,137 @@
+"""CPU tests of the surfel-fusion oracle: closed-form known answers + the committed golden vector."""
+import hashlib
+import os
+
+import numpy as np
+
+from manhattanslam_amd import synth
+from tests.oracle_lib import OracleSurfel, SURFEL_DTYPE, fuse_map_compact, load
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+I = synth.TUM1
+IDENT = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+
+
+def _mk(w=640, h=480, intr=I):
+    return OracleSurfel(w, h, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5)
+
+
+def _plane_depth(w, h, n, d, intr=I):
+    """z-depth of the plane n.X + d = 0 seen by the camera at the origin."""
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    rx, ry = (u - intr["cx"]) / intr["fx"], (v - intr["cy"]) / intr["fy"]
+    return (-d / (n[0] * rx + n[1] * ry + n[2])).astype(np.float32)
+
+
+def test_planar_scene_gives_plane_normal_and_positions():
+    n = np.array([0.2, -0.1, -1.0]); n /= np.linalg.norm(n)
+    depth = _plane_depth(640, 480, n, 2.0)
+    gray = np.full((480, 640), 120, np.uint8)
+    member = np.full((240, 320), -1, np.int32)
+    sf = _mk()
+    local = np.zeros(0, SURFEL_DTYPE)
+    _, new = sf.fuse(0, gray, depth, member, IDENT, local)
+    s = sf.seeds()
+    inner = s.reshape(60, 80)[2:-2, 2:-2].ravel()
+    nn = np.stack([inner["normX"], inner["normY"], inner["normZ"]], 1)
+    assert np.abs(nn - n[None, :]).max() < 2e-3                     # robust plane fit recovers the plane normal
+    pos = np.stack([inner["posX"], inner["posY"], inner["posZ"]], 1).astype(np.float64)
+    assert np.abs(pos @ n + 2.0).max() < 2e-3                       # seed centres lie on the plane
+    assert np.all(inner["viewCos"] > 0.1) and np.all(inner["use"] == 1)
+    assert len(new) >= inner.size                                   # nothing to fuse with: every valid seed spawns a surfel
+    assert np.all(new["updateTimes"] == 1) and np.all(new["lastUpdate"] == 0)
+    w = np.minimum(1.0 / new["pz"].astype(np.float64) ** 2, 1.0)
+    assert np.abs(new["weight"] - w).max() < 1e-3                   # getWeight = min(1/z^2, 1) (identity pose: z = pz)
+
+
+def test_single_surfel_fuses_by_weighted_mean_and_deletion_rules():
+    depth = np.full((480, 640), 2.0, np.float32)
+    gray = np.full((480, 640), 50, np.uint8)
+    member = np.full((240, 320), -1, np.int32)
+    sf = _mk()
+    loc = np.zeros(5, SURFEL_DTYPE)
+    # 0: on the wall, facing the camera -> fused;  1: 1.5 m in front of the wall -> occlusion delete
+    # 2: normal facing away -> delete;  3: stale and rarely updated -> delete;  4: behind fuseNear -> untouched
+    loc["px"] = [0.1, 0.1, -0.2, 0.3, 0.0]; loc["py"] = [0.05, 0.05, 0.1, 0.0, 0.0]; loc["pz"] = [2.03, 0.5 + 1e-3, 2.0, 2.0, 0.2]
+    loc["nz"] = [-1, -1, 1, -1, -1]
+    loc["size"] = 1.0; loc["weight"] = [3.0, 1, 1, 1, 1]; loc["updateTimes"] = [7, 7, 7, 2, 7]; loc["lastUpdate"] = [9, 9, 9, 1, 9]
+    out, new = sf.fuse(10, gray, depth, member, IDENT, loc)
+    assert out["updateTimes"].tolist() == [8, 0, 0, 0, 7]
+    assert out["lastUpdate"].tolist() == [10, 9, 9, 1, 9]
+    wn = min(1 / 2.0 ** 2, 1.0)
+    assert abs(out["pz"][0] - (2.03 * 3.0 + wn * 2.0) / (3.0 + wn)) < 1e-4      # weighted mean with w_new = min(1/z^2, 1)
+    assert abs(out["weight"][0] - (3.0 + wn)) < 1e-6
+    assert abs(out["nz"][0] + 1) < 1e-4 and out["color"][0] == 50 and out["size"][0] < 1.0
+    assert out[4].tobytes() == loc[4].tobytes()
+
+
+def test_membership_masks_seeds():
+    gray, depth, member, pose = synth.surfel_frame(0, variant="B")
+    sf = _mk()
+    sf.fuse(0, gray, depth, member, pose, np.zeros(0, SURFEL_DTYPE))
+    s = sf.seeds().reshape(60, 80)
+    idx = sf.index()
+    ys, xs = np.nonzero(np.repeat(np.repeat(member, 2, 0), 2, 1) != -1)
+    assert np.all(idx[ys, xs] == 0)                               # plane pixels are never assigned
+    cy, cx = np.arange(60) * 8 + 4, np.arange(80) * 8 + 4
+    use = member[np.ix_(cy // 2, cx // 2)] == -1
+    assert np.array_equal(s["use"].astype(bool), use)
+
+
+def test_compaction_rule_matches_prefix_sum_model():
+    """Back-to-front refill + tail compaction == 'new k -> k-th largest hole; the a-th smallest leftover hole receives
+    resolve(nFinal + a)', resolve following relay holes inside the tail (the formulation the GPU kernels use)."""
+    rng = np.random.default_rng(0)
+    cases = [(0, 0, 3), (10, 1.0, 3), (10, 1.0, 12), (1000, 0.3, 50), (1000, 0.02, 50), (1000, 0.9, 5), (257, 0.5, 0),
+             (300, 1.0, 1), (300, 0.97, 7)]
+    for n, pdel, k in cases:
+        loc = np.zeros(n, SURFEL_DTYPE)
+        loc["px"] = np.arange(n); loc["updateTimes"] = np.where(rng.random(n) < pdel, 0, 1)
+        new = np.zeros(k, SURFEL_DTYPE)
+        new["px"] = 10000 + np.arange(k); new["updateTimes"] = 1
+        got = fuse_map_compact(loc, new)
+        holes = np.flatnonzero(loc["updateTimes"] == 0)
+        D = len(holes)
+        model = list(loc["px"])
+        for j in range(min(k, D)):
+            model[holes[D - 1 - j]] = 10000 + j
+        model += [10000 + j for j in range(D, k)]
+        if D > k:
+            left = holes[:D - k].tolist()
+            R = len(left)
+            nfin = n - R
+            pos = {h: i for i, h in enumerate(left)}
+            final = list(model)
+            for a, hh in enumerate(h for h in left if h < nfin):
+                p = nfin + a
+                while p in pos:
+                    p = n - (R - pos[p])
+                final[hh] = model[p]
+            model = final[:nfin]
+        assert got["px"].tolist() == [float(v) for v in model], (n, pdel, k)
+
+
+def test_inverse4_matches_numpy():
+    dll = load().dll
+    import ctypes as C
+    rng = np.random.default_rng(4)
+    for k in range(5):
+        pose = synth.camera_pose(k * 17)
+        inv = np.zeros(16, np.float32)
+        dll.mslo_inverse4f(pose.ctypes.data_as(C.c_void_p), inv.ctypes.data_as(C.c_void_p))
+        ref = np.linalg.inv(pose.reshape(4, 4).T.astype(np.float64))
+        assert np.abs(inv.reshape(4, 4).T - ref).max() < 1e-6
+
+
+def test_golden_surfel():
+    g = np.load(os.path.join(GOLD, "surfel_640x480_B.npz"))
+    k = int(g["frame"])
+    gray, depth, member, pose = synth.surfel_frame(k, variant="B")
+    assert hashlib.sha256(depth.tobytes()).hexdigest() == str(g["depth_sha256"])
+    local = synth.surfel_map(int(g["n_local"]), ref=k).astype(SURFEL_DTYPE)
+    sf = _mk()
+    lo, no = sf.fuse(k, gray, depth, member, pose, local)
+    assert no.tobytes() == g["new_surfels"].tobytes()
+    assert lo[g["changed_index"]].tobytes() == g["changed_surfels"].tobytes()
+    assert sf.seeds().tobytes() == g["seeds"].tobytes()
+    assert hashlib.sha256(sf.index().tobytes()).hexdigest() == str(g["index_sha256"])

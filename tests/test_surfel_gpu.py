@@ -126,7 +126,8 @@ def test_compaction_matches_literal_loop(oracle):
     g, o = _mk(synth.TUM1)
     rng = np.random.default_rng(3)
     gray, depth, member, pose = synth.surfel_frame(0)
-    for trial, (n, pdel) in enumerate([(5000, 0.0), (5000, 0.9), (20000, 0.5), (9000, 1.0), (4097, 0.3)]):
+    for trial, (n, pdel) in enumerate([(5000, 0.0), (5000, 0.9), (20000, 0.5), (9000, 1.0), (4097, 0.3), (30000, 1.0), (30000, 0.95),
+                                       (400000, 1.0)]):
         m = synth.surfel_map(n, ref=0, seed=100 + trial).astype(SURFEL_DTYPE)
         m["updateTimes"][rng.random(n) < pdel] = 0         # pre-deleted slots
         m["pz"] += 100.0                                   # far away: the fuse step itself changes nothing else
