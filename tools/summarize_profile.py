@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (rocprofv3 --kernel-trace --stats and the two --pmc passes) into profiles/<tag>_*.
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB per dispatch.  Per MI355X_MICROARCH.md (HBM section), on gfx950
+FETCH_SIZE counts 128-B read requests as 64 B for wide coalesced streams, so the read side is doubled before it is
+compared with a byte count ("fetch_bytes_corrected"); WRITE_SIZE is left uncorrected (uncalibrated in the guide).
+"""
+import collections
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = f"gpurun_out/prof_{tag}"
+os.makedirs("profiles", exist_ok=True)
+
+
+def kname(s):
+    m = re.search(r"(k_\w+)", s)
+    return m.group(1) if m else s.split("(")[0][-48:]
+
+
+stats = list(csv.DictReader(open(f"{src}/trace/bench_kernel_stats.csv")))
+shutil.copy(f"{src}/trace/bench_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+pmc = {}
+for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    p = f"{src}/{name}/bench_counter_collection.csv"
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(p)):
+        if r["Counter_Name"] != ctr:
+            continue
+        a = agg[kname(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    pmc[ctr] = {k: {"launches": n, "avg_KiB_per_launch": v / n} for k, (n, v) in agg.items()}
+summary = {}
+for r in stats:
+    k = kname(r["Name"])
+    e = summary.setdefault(k, {"calls": 0, "total_ns": 0})
+    e["calls"] += int(r["Calls"]); e["total_ns"] += int(r["TotalDurationNs"])
+for k, e in summary.items():
+    e["avg_us"] = round(e["total_ns"] / e["calls"] / 1e3, 2)
+    f = pmc.get("FETCH_SIZE", {}).get(k); w = pmc.get("WRITE_SIZE", {}).get(k)
+    if f:
+        e["fetch_KiB_raw"] = round(f["avg_KiB_per_launch"], 1)
+        e["fetch_bytes_corrected"] = int(2 * 1024 * f["avg_KiB_per_launch"])
+    if w:
+        e["write_bytes"] = int(1024 * w["avg_KiB_per_launch"])
+tot = sum(e["total_ns"] for e in summary.values())
+for e in summary.values():
+    e["pct"] = round(100.0 * e["total_ns"] / tot, 2)
+json.dump(dict(sorted(summary.items(), key=lambda kv: -kv[1]["total_ns"])), open(f"profiles/{tag}_summary.json", "w"), indent=1)
+with open(f"profiles/{tag}_summary.md", "w") as f:
+    f.write(f"# rocprofv3 summary `{tag}` (bench.py --steps 4 --warmup 1 --cpu-frames 0 --no-breakdown)\n\n")
+    f.write("| kernel | calls | avg us | % GPU time | FETCH_SIZE KiB/launch (raw) | HBM read B/launch (x2 corrected) | WRITE_SIZE B/launch |\n|---|---|---|---|---|---|---|\n")
+    for k, e in sorted(summary.items(), key=lambda kv: -kv[1]["total_ns"]):
+        f.write(f"| {k} | {e['calls']} | {e['avg_us']} | {e['pct']} | {e.get('fetch_KiB_raw', '')} | {e.get('fetch_bytes_corrected', '')} | {e.get('write_bytes', '')} |\n")
+print(open(f"profiles/{tag}_summary.md").read())
