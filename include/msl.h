@@ -179,6 +179,17 @@ MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8
                                  size_t gray_stride, const float *depth, size_t depth_stride,
                                  const int32_t *member, size_t member_stride, msl_mem img_mem,
                                  const float pose_colmajor[16]);
+/* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
+ * Keyframe f's images start at base + f * <frame_stride> bytes (member_frame_stride may be 0: one shared
+ * membership image); refs[n_frames] and poses (16 * n_frames floats, column-major Twc each) are host arrays.
+ * generateSuperPixels() of all keyframes of a batch runs frame-batched on a second stream and overlaps the
+ * per-keyframe map stage of the previous batch.  n_frames <= the capacity set below (default 1). */
+MSL_API int msl_sf_set_batch_capacity(msl_sf *h, int max_frames);
+MSL_API int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray,
+                                       size_t gray_stride, size_t gray_frame_stride, const float *depth,
+                                       size_t depth_stride, size_t depth_frame_stride, const int32_t *member,
+                                       size_t member_stride, size_t member_frame_stride, msl_mem img_mem,
+                                       const float *poses_colmajor);
 MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]);
 MSL_API int msl_sf_sync(msl_sf *h);
 MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);

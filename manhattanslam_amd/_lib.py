@@ -56,6 +56,8 @@ SIGNATURES = {
     "msl_sf_map_download": (_i, [_vp, _vp, _sz, _vp]),
     "msl_sf_map_size": (_i, [_vp, _vp]),
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
+    "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
+    "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),
     "msl_sf_last_counters": (_i, [_vp, _vp]),
     "msl_sf_sync": (_i, [_vp]),
     "msl_sf_set_stream": (_i, [_vp, _vp]),

@@ -79,6 +79,20 @@ class SurfelFusion:
         check(lib.msl_sf_fuse_resident(self._h, int(referenceFrameIndex), ptr(gray), strides[0], ptr(depth), strides[1], ptr(member),
                                        strides[2], MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(p)), "msl_sf_fuse_resident")
 
+    def set_batch_capacity(self, max_frames):
+        check(lib.msl_sf_set_batch_capacity(self._h, int(max_frames)), "msl_sf_set_batch_capacity")
+
+    def fuse_resident_batch(self, refs, grays, depths, members, poses, device=False, member_shared=False):
+        """Keyframes in order.  grays (n,H,W) u8, depths (n,H,W) f32, members (n,H/2,W/2) i32 (or (H/2,W/2) with
+        member_shared=True), poses (n,16) column-major; host numpy arrays or, with device=True, torch tensors."""
+        n = len(refs)
+        refs = np.ascontiguousarray(refs, np.int32)
+        poses = np.ascontiguousarray(np.stack([_pose16(p) for p in poses]), np.float32)
+        w, h = self.width, self.height
+        check(lib.msl_sf_fuse_resident_batch(self._h, n, ptr(refs), ptr(grays), w, w * h, ptr(depths), 4 * w, 4 * w * h, ptr(members),
+                                             4 * (w // 2), 0 if member_shared else 4 * (w // 2) * (h // 2),
+                                             MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch")
+
     def counters(self):
         c = np.zeros(5, np.int64)
         check(lib.msl_sf_last_counters(self._h, ptr(c)), "msl_sf_last_counters")

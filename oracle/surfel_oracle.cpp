@@ -483,7 +483,7 @@ struct Fusion {
     // ---- :40-73 ----
     void fuseInitializeMap(int ref, const uint8_t *g, size_t gs, const float *d, size_t ds, const int32_t *m, size_t ms,
                            const float *pose, Surfel *local, size_t n_local, std::vector<Surfel> &newSurfels) {
-        gray = g; gstride = gs; gbytes = gs * (size_t)H;
+        gray = g; gstride = gs; gbytes = gs * (size_t)(H - 1) + W;   // the last row carries no stride padding
         depthp = d; dstride = ds / sizeof(float);
         member = m; mstride = ms / sizeof(int32_t);
         generateSuperPixels();

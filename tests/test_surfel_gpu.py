@@ -81,6 +81,51 @@ def test_resident_sequence_matches_oracle(oracle):
     g.close()
 
 
+def test_batched_keyframes_match_sequential_oracle(oracle):
+    """fuse_resident_batch == the same keyframes one after another (two overlapping batches, device + host input)."""
+    import torch
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    g.set_batch_capacity(4)
+    m = synth.surfel_map(150000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(400000)
+    g.map_upload(m)
+    o.map_set(m)
+    frames = [synth.surfel_frame(k, variant="B" if k % 3 == 1 else "A") for k in range(7)]
+    for k, (gray, depth, member, pose) in enumerate(frames):
+        o.fuse_map(k, gray, depth, member, pose)
+    grays = np.stack([f[0] for f in frames]); depths = np.stack([f[1] for f in frames]); members = np.stack([f[2] for f in frames])
+    poses = [f[3] for f in frames]
+    # batch 1: host memory, 4 keyframes; batch 2: device memory, 3 keyframes, issued without waiting for batch 1
+    g.fuse_resident_batch([0, 1, 2, 3], grays[:4], depths[:4], members[:4], poses[:4])
+    dg, dd, dm = (torch.from_numpy(a[4:]).cuda() for a in (grays, depths, members))
+    g.fuse_resident_batch([4, 5, 6], dg, dd, dm, poses[4:], device=True)
+    mg, mo = g.map_download(), o.map_get()
+    assert_surfels_close(mg, mo, "map after 7 batched keyframes")
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    g.close()
+
+
+def test_strided_images(oracle):
+    """Row strides larger than the width (cv::Mat ROI style) incl. the Vec3b flat-offset quirk."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    gray, depth, member, pose = synth.surfel_frame(1)
+    G = np.zeros((480, 700), np.uint8); G[:, :640] = gray; G[:, 640:] = 17
+    Dp = np.zeros((480, 648), np.float32); Dp[:, :640] = depth
+    Mb = np.full((240, 330), 5, np.int32); Mb[:, :320] = member
+    gv, dv, mv = G[:, :640], Dp[:, :640], Mb[:, :320]
+    local = synth.surfel_map(20000, ref=1).astype(SURFEL_DTYPE)
+    lo, no = o.fuse(1, gv, dv, mv, pose, local)
+    lg = local.copy()
+    ng = g.fuseInitializeMap(1, gv, dv, mv, pose, lg)
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(lg, lo)
+    assert_surfels_close(ng, no)
+    g.close()
+
+
 def test_icl_negative_fy_and_empty_map(oracle):
     from manhattanslam_amd import synth, SURFEL_DTYPE
     g, o = _mk(synth.ICL)
