@@ -119,6 +119,7 @@ def main():
     I = synth.TUM1
     orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=F, device=local_rank)
     sf = SurfelFusion(W, H, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5, device=local_rank)
+    sf.set_batch_capacity(F)
     sf.map_reserve(2 * args.surfels + 65536)
     sf.map_upload(smap)
 
@@ -134,11 +135,12 @@ def main():
     frame_no = [0]
 
     def step():
+        # ORB: one frame-batched launch sequence.  Surfel fusion: every frame is a keyframe; the superpixel stage of the
+        # F keyframes is frame-batched, the map stage (fuse / new surfels / compaction) runs keyframe after keyframe.
         orb.extract_batch_device(d_gray, d_kps, d_desc, d_n, F, W, H)
-        for f in range(F):
-            sf.fuse_resident(frame_no[0], d_gray[f], d_depth[f], d_member, poses[f], device=True,
-                             strides=(W, 4 * W, 4 * (W // 2)))
-            frame_no[0] += 1
+        sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True,
+                               member_shared=True)
+        frame_no[0] += F
 
     def sync_all():
         orb.sync()
@@ -215,11 +217,11 @@ def main():
         orb.sync()
         out["orb_only_fps"] = round(10 * F / (time.perf_counter() - t0), 1)
         t0 = time.perf_counter()
-        for f in range(2 * F):
-            sf.fuse_resident(frame_no[0], d_gray[f % F], d_depth[f % F], d_member, poses[f % F], device=True, strides=(W, 4 * W, 2 * W))
-            frame_no[0] += 1
+        for _ in range(4):
+            sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True, member_shared=True)
+            frame_no[0] += F
         sf.sync()
-        out["surfel_only_keyframes_per_sec"] = round(2 * F / (time.perf_counter() - t0), 1)
+        out["surfel_only_keyframes_per_sec"] = round(4 * F / (time.perf_counter() - t0), 1)
 
     if args.cpu_frames > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(grays, depths, member, poses, smap, args.cpu_frames)

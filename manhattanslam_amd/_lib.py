@@ -72,6 +72,12 @@ MSL_SF_NKERNELS = 12
 
 
 def _load():
+    # PyTorch-ROCm bundles its own libamdhip64; when torch shares the process it must be loaded first so that both
+    # sides bind one HIP runtime (two runtimes in one process cannot both own the GPU).  C/C++ hosts are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise MslError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

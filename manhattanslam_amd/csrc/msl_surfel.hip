@@ -41,7 +41,7 @@ constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE_D = 0.5, DISPA
 constexpr unsigned T_INF = 0xFFFFFFFFu;
 constexpr int PROP_ROUNDS = 2;          // full-grid relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
-constexpr int SCAN_ITEMS = 4096;        // surfels per workgroup chunk in the map-stage kernels
+constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup chunk in the map-stage kernels
 
 // Structure-of-arrays surfel map (device resident): 14 arrays of `cap` 4-byte elements.
 struct MapSoA {
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_del_list(SfDev P) {
         unsigned base = P.blockSums[b];
         const unsigned next = b + 1 < nblk ? P.blockSums[b + 1] : (unsigned)P.ctr[2];
         if (next == base) continue;   // nothing deleted in this chunk
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < SCAN_ITEMS / 1024; k++) {
             const long long i = b * SCAN_ITEMS + k * 1024 + threadIdx.x;
             const unsigned f = (i < n && P.map.updateTimes[i] == 0) ? 1u : 0u;
             unsigned tot;
@@ -1060,7 +1060,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
     for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(1024), dim3(256), P, f);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f);
         LAUNCH(SK_NEW, sm, k_new_scan, dim3(1), dim3(1024), P, f);
         if (compact) {
             h->prof.begin(SK_COMPACT, sm);

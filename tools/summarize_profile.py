@@ -19,7 +19,7 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def kname(s):
-    m = re.search(r"(k_\w+)", s)
+    m = re.search(r"\b(kb?_\w+)", s)
     return m.group(1) if m else s.split("(")[0][-48:]
 
 
