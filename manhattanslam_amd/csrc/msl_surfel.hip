@@ -39,7 +39,7 @@ constexpr int SP = 8;
 constexpr int NCHUNK = 10;  // THREAD_NUM, include/SurfelFusion.h:34
 constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE_D = 0.5, DISPARITY_ERROR = 4.0, MIN_TOLERATE_DIFF = 0.1;
 constexpr unsigned T_INF = 0xFFFFFFFFu;
-constexpr int PROP_ROUNDS = 2;          // full-grid relaxation rounds before the single-workgroup finisher
+constexpr int PROP_ROUNDS = 6;          // full-grid relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup chunk in the map-stage kernels
 
@@ -133,6 +133,28 @@ __host__ __device__ inline void inverse4(const T *m, T *inv) {
 #undef M_
 }
 
+// Strictly sequential (left-to-right) float sums over 16-byte aligned LDS arrays; wide LDS reads are issued
+// ahead of the dependent add chain so the chain runs at VALU latency instead of LDS latency.
+__device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
+    int p = 0;
+    for (; p + 8 <= n; p += 8) {
+        const float4 u = *reinterpret_cast<const float4 *>(a + p), v = *reinterpret_cast<const float4 *>(a + p + 4);
+        s += u.x; s += u.y; s += u.z; s += u.w; s += v.x; s += v.y; s += v.z; s += v.w;
+    }
+    for (; p < n; p++) s += a[p];
+    return s;
+}
+// s = (float)((double)s + t[e]) for e = 0..n-1 (float accumulator, double terms)
+__device__ __forceinline__ float seq_sum_f32_dterms(const double *t, int n, float s) {
+    int e = 0;
+    for (; e + 4 <= n; e += 4) {
+        const double2 u = *reinterpret_cast<const double2 *>(t + e), v = *reinterpret_cast<const double2 *>(t + e + 2);
+        s = (float)((double)s + u.x); s = (float)((double)s + u.y); s = (float)((double)s + v.x); s = (float)((double)s + v.y);
+    }
+    for (; e < n; e++) s = (float)((double)s + t[e]);
+    return s;
+}
+
 // =============================================================================================
 // Frame-batched superpixel stage (blockIdx.y / .z = slot)
 // =============================================================================================
@@ -196,14 +218,25 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it) {
     float minDistDepth = 1e6f, minDistNodepth = 1e6f;
     int minSpIndexDepth = -1, minSpIndexNodepth = -1;
     bool allHasDepth = true;
+    // candidate seed fields for the 3x3 neighbourhood, loaded up front (clamped) so the 9 lookups overlap
+    float2 cxy[9], cdi[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const int sxI = min(max(baseSpX + c / 3 - 1, 0), P.spW - 1), syI = min(max(baseSpY + c % 3 - 1, 0), P.spH - 1);
+        const msl_seed *sp = &seeds[syI * P.spW + sxI];
+        cxy[c] = *reinterpret_cast<const float2 *>(&sp->x);
+        cdi[c] = *reinterpret_cast<const float2 *>(&sp->meanDepth);   // (meanDepth, meanIntensity)
+    }
+#pragma unroll
     for (int checkI = -1; checkI <= 1; checkI++)
+#pragma unroll
         for (int checkJ = -1; checkJ <= 1; checkJ++) {
             const int checkSpX = baseSpX + checkI, checkSpY = baseSpY + checkJ;
             const int distSpX = abs(checkSpX * SP + SP / 2 - colI), distSpY = abs(checkSpY * SP + SP / 2 - rowI);
             if (distSpX < SP && distSpY < SP && checkSpX >= 0 && checkSpX < P.spW && checkSpY >= 0 && checkSpY < P.spH) {
                 const int spIndex = checkSpY * P.spW + checkSpX;
-                const msl_seed *s = &seeds[spIndex];
-                const float sx = s->x, sy = s->y, sI = s->meanIntensity, sD = s->meanDepth;
+                const int c = (checkI + 1) * 3 + (checkJ + 1);
+                const float sx = cxy[c].x, sy = cxy[c].y, sI = cdi[c].y, sD = cdi[c].x;
                 // calculateCost (:333-355)
                 float nodepthCost = 0;
                 const float dist = (sx - colI) * (sx - colI) + (sy - rowI) * (sy - rowI);
@@ -284,8 +317,8 @@ __global__ __launch_bounds__(256) void kb_commit_px(SfDev P) {
 // Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window
 // raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it) {
-    __shared__ float s_depth[16][256];
-    __shared__ double s_term[16][256];
+    __shared__ __attribute__((aligned(16))) float s_depth[16][256];
+    __shared__ __attribute__((aligned(16))) double s_term[16][256];
     __shared__ float s_mean[16];
     __shared__ int s_cnt[16], s_done[16];
     const int slot = blockIdx.y;
@@ -311,34 +344,36 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it) {
     const int xb = xb0 > 0 ? xb0 : 0, yb = yb0 > 0 ? yb0 : 0;
     const int xe = (xb0 + SP * 2) < P.W - 1 ? (xb0 + SP * 2) : P.W - 1, ye = (yb0 + SP * 2) < P.H - 1 ? (yb0 + SP * 2) : P.H - 1;
     int sumX = 0, sumY = 0, sumI = 0, cnt = 0, nd = 0;
-    float dloc[16];
-    unsigned dmask = 0;
-    const int j = yb0 + l;
-    if (active && j >= yb && j < ye) {
+    {
+        // lane = window column, unrolled loop = window row: each load instruction reads 16 contiguous pixels per
+        // seed (coalesced); all 48 loads are issued up front with clamped addresses, ownership is resolved afterwards.
+        float dloc[16];
+        unsigned short idv[16];
+        uint8_t gv[16];
+        const int col = xb0 + l, colc = min(max(col, 0), P.W - 1);
+        const bool colOk = active && col >= xb && col < xe;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int i = xb0 + k;
-            dloc[k] = 0;
-            if (i >= xb && i < xe && index[j * P.W + i] == seedI) {
-                sumX += i; sumY += j; sumI += gray_at(P, F, j, i); cnt++;
-                const float d = depth_at(P, F, j, i);
-                if (d > 0.1) { dloc[k] = d; dmask |= 1u << k; nd++; }
-            }
+            const int jc = min(max(yb0 + k, 0), P.H - 1);
+            idv[k] = index[(size_t)jc * P.W + colc]; dloc[k] = F.depth[(size_t)jc * P.dstride + colc]; gv[k] = F.gray[(size_t)jc * P.gstride + colc];
+        }
+        const int gsh = (g & 3) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {          // window raster order: row k, then the ballot's lane order = column order
+            const int j = yb0 + k;
+            const bool own = colOk && j >= yb && j < ye && idv[k] == seedI;
+            const bool hasd = own && dloc[k] > 0.1;
+            if (own) { sumX += col; sumY += j; sumI += gv[k]; cnt++; }
+            const unsigned gm = (unsigned)((__ballot(hasd) >> gsh) & 0xFFFFull);
+            if (hasd) s_depth[g][nd + __popc(gm & ((1u << l) - 1u))] = dloc[k];
+            nd += __popc(gm);
         }
     }
-    // group (16-lane) reductions and exclusive prefix of the per-row depth counts
-    int off = nd;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { const int t = __shfl_up(off, d, 16); if (l >= d) off += t; }
-    off -= nd;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) {
         sumX += __shfl_xor(sumX, d, 16); sumY += __shfl_xor(sumY, d, 16);
-        sumI += __shfl_xor(sumI, d, 16); cnt += __shfl_xor(cnt, d, 16); nd += __shfl_xor(nd, d, 16);
+        sumI += __shfl_xor(sumI, d, 16); cnt += __shfl_xor(cnt, d, 16);
     }
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (dmask & (1u << k)) s_depth[g][off++] = dloc[k];
     __builtin_amdgcn_wave_barrier();
     msl_seed T = S;
     T._pad = 2;
@@ -357,8 +392,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it) {
                 const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
                 T.stable = (updateDiff < 0.2) ? 1 : 0;
                 if (nd > 0) {
-                    float sumDepth = 0.0f;
-                    for (int p = 0; p < nd; p++) sumDepth += s_depth[g][p];
+                    const float sumDepth = seq_sum_f32(s_depth[g], nd, 0.0f);
                     s_mean[g] = sumDepth / (float)nd;
                     depthLoop = true;
                 } else {
@@ -384,8 +418,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it) {
         if (inr) atomicAdd(&s_cnt[g], inr);
         __builtin_amdgcn_wave_barrier();
         if (l == 0) {
-            float sumA = 0;
-            for (int e = 0; e < nd; e++) sumA = (float)((double)sumA + s_term[g][e]);   // == float add for the in-range terms
+            const float sumA = seq_sum_f32_dterms(s_term[g], nd, 0.0f);   // == float add for the in-range terms
             const float sumB = (float)(2 * s_cnt[g]);
             const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
             const float m = meanDepth + deltaDepth;
@@ -418,13 +451,13 @@ __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
 // kb_seed_plane: calculateNorms (:775-803) fused per seed, 16 lanes per seed, 4 seeds per wave/workgroup.
 // Pixel positions and cross-product normals are recomputed from depth instead of materialising spaceMap
 // (7.4 MB f64) / normMap.  Also prepares the surfel the seed would spawn (initializeSurfels, :285-331).
-__device__ __forceinline__ void pixel_normal(const SfDev &P, const FrameDev &F, int row, int col, float myX, float myY, float myZ,
-                                             float &nX, float &nY, float &nZ) {
+__device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, float myX, float myY, float myZ, float rightDepth,
+                                             float downDepth, float &nX, float &nY, float &nZ) {
     nX = nY = nZ = 0.0f;
     if (row < 1 || row > P.H - 2 || col < 1 || col > P.W - 2) return;  // never written (:620-625)
     float rightX, rightY, rightZ, downX, downY, downZ;
-    back_project(P, (float)(col + 1), (float)row, depth_at(P, F, row, col + 1), rightX, rightY, rightZ);
-    back_project(P, (float)col, (float)(row + 1), depth_at(P, F, row + 1, col), downX, downY, downZ);
+    back_project(P, (float)(col + 1), (float)row, rightDepth, rightX, rightY, rightZ);
+    back_project(P, (float)col, (float)(row + 1), downDepth, downX, downY, downZ);
     if (myZ < 0.1 || rightZ < 0.1 || downZ < 0.1) return;
     rightX = rightX - myX; rightY = rightY - myY; rightZ = rightZ - myZ;
     downX = downX - myX; downY = downY - myY; downZ = downZ - myZ;
@@ -445,9 +478,9 @@ __device__ __forceinline__ double group_sum_d(double v) {
 }
 
 __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
-    __shared__ float s_d[4][256];
-    __shared__ float s_p[4][3][256];
-    __shared__ float s_n[4][3][256];
+    __shared__ __attribute__((aligned(16))) float s_d[4][256];
+    __shared__ __attribute__((aligned(16))) float s_p[4][3][256];
+    __shared__ __attribute__((aligned(16))) float s_n[4][3][256];
     const int slot = blockIdx.y;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15, lane = threadIdx.x;
     const int seedI = blockIdx.x * 4 + g;
@@ -459,45 +492,57 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
     if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
     const int spX = seedI % P.spW, spY = seedI / P.spW;
     const int xb = spX * SP + SP / 2 - SP, yb = spY * SP + SP / 2 - SP;
-    // ---- gather: lane = window row, unclipped window guarded by the flat index range (:680-684) ----
+    // ---- gather: lane = window column, unrolled loop = window row; unclipped window guarded by the flat index range
+    // (:680-684).  All loads (index, depth, right/down neighbours) are issued up front with clamped addresses. ----
     float maxDist = 0;
-    int nv = 0;
-    unsigned vmask = 0;
-    float dv[16];
-    const int jrow = yb + l;
+    int nvalid = 0;
+    {
+        float dv[16], dr[16], dd[16];
+        unsigned short idv[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int i = xb + k;
-        const int pixelIndex = jrow * P.W + i;
-        dv[k] = 0;
-        if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && index[pixelIndex] == seedI) {
-            const float xDiff = i - S.x, yDiff = jrow - S.y;
-            const float dist = xDiff * xDiff + yDiff * yDiff;
-            if (dist > maxDist) maxDist = dist;
-            const float myDepth = F.depth[(size_t)(pixelIndex / P.W) * P.dstride + (pixelIndex % P.W)];
-            if (myDepth > 0.05) { dv[k] = myDepth; vmask |= 1u << k; nv++; }
+        for (int k = 0; k < 16; k++) {
+            const int pixelIndex = (yb + k) * P.W + xb + l;
+            const int pc = min(max(pixelIndex, 0), P.npx - 1);
+            const int row = pc / P.W, col = pc - row * P.W;     // wrapped pixel (App. B.6)
+            idv[k] = index[pc];
+            dv[k] = F.depth[(size_t)row * P.dstride + col];
+            dr[k] = F.depth[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
+            dd[k] = F.depth[(size_t)min(row + 1, P.H - 1) * P.dstride + col];
+        }
+        const int gsh = g * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int i = xb + l, jrow = yb + k;
+            const int pixelIndex = jrow * P.W + i;
+            bool valid = false;
+            if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && idv[k] == seedI) {
+                const float xDiff = i - S.x, yDiff = jrow - S.y;
+                const float dist = xDiff * xDiff + yDiff * yDiff;
+                if (dist > maxDist) maxDist = dist;
+                valid = dv[k] > 0.05;
+            }
+            const unsigned gm = (unsigned)((__ballot(valid) >> gsh) & 0xFFFFull);
+            if (valid) {   // ordered compaction of the raw valid pixels: depth, right depth, down depth, pixel index
+                const int o = nvalid + __popc(gm & ((1u << l) - 1u));
+                s_d[g][o] = dv[k]; s_n[g][0][o] = dr[k]; s_n[g][1][o] = dd[k]; s_n[g][2][o] = __int_as_float(pixelIndex);
+            }
+            nvalid += __popc(gm);
         }
     }
-    int off = nv;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { const int t = __shfl_up(off, d, 16); if (l >= d) off += t; }
-    off -= nv;
-    int nvalid = nv;
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) { nvalid += __shfl_xor(nvalid, d, 16); maxDist = fmaxf(maxDist, __shfl_xor(maxDist, d, 16)); }
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        if (vmask & (1u << k)) {
-            const int pixelIndex = jrow * P.W + xb + k;
-            const int row = pixelIndex / P.W, col = pixelIndex % P.W;   // wrapped pixel (App. B.6)
-            float pX, pY, pZ, nX, nY, nZ;
-            back_project(P, (float)col, (float)row, dv[k], pX, pY, pZ);
-            pixel_normal(P, F, row, col, pX, pY, pZ, nX, nY, nZ);
-            s_d[g][off] = dv[k];
-            s_p[g][0][off] = pX; s_p[g][1][off] = pY; s_p[g][2][off] = pZ;
-            s_n[g][0][off] = nX; s_n[g][1][off] = nY; s_n[g][2][off] = nZ;
-            off++;
-        }
+    for (int d = 8; d >= 1; d >>= 1) maxDist = fmaxf(maxDist, __shfl_xor(maxDist, d, 16));
+    __builtin_amdgcn_wave_barrier();
+    // balanced: entry e -> position + cross-product normal, written back in place (order preserved)
+    for (int e = l; e < nvalid; e += 16) {
+        const int pixelIndex = __float_as_int(s_n[g][2][e]);
+        const int row = pixelIndex / P.W, col = pixelIndex - row * P.W;
+        const float myDepth = s_d[g][e], rightD = s_n[g][0][e], downD = s_n[g][1][e];
+        float pX, pY, pZ, nX, nY, nZ;
+        back_project(P, (float)col, (float)row, myDepth, pX, pY, pZ);
+        pixel_normal(P, row, col, pX, pY, pZ, rightD, downD, nX, nY, nZ);
+        s_p[g][0][e] = pX; s_p[g][1][e] = pY; s_p[g][2][e] = pZ;
+        s_n[g][0][e] = nX; s_n[g][1][e] = nY; s_n[g][2][e] = nZ;
+    }
     __builtin_amdgcn_wave_barrier();
     bool active = inRange && nvalid >= 16;   // validDepthNum < 16 -> continue (:702)
     float meanDepth = S.meanDepth;
@@ -526,10 +571,10 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
     if (active && (float)ninl / (float)nvalid < 0.8) active = false;
     float normX = 0.0f, normY = 0.0f, normZ = 0.0f, sumX = 0.0f, sumY = 0.0f, sumZ = 0.0f;
     if (active && l == 0) {
-        for (int p = 0; p < ninl; p++) { normX += s_n[g][0][p]; normY += s_n[g][1][p]; normZ += s_n[g][2][p]; }
+        normX = seq_sum_f32(s_n[g][0], ninl, 0.0f); normY = seq_sum_f32(s_n[g][1], ninl, 0.0f); normZ = seq_sum_f32(s_n[g][2], ninl, 0.0f);
         const float normLength = sqrtf(normX * normX + normY * normY + normZ * normZ);
         normX = normX / normLength; normY = normY / normLength; normZ = normZ / normLength;
-        for (int p = 0; p < ninl; p++) { sumX += s_p[g][0][p]; sumY += s_p[g][1][p]; sumZ += s_p[g][2][p]; }
+        sumX = seq_sum_f32(s_p[g][0], ninl, 0.0f); sumY = seq_sum_f32(s_p[g][1], ninl, 0.0f); sumZ = seq_sum_f32(s_p[g][2], ninl, 0.0f);
         sumX /= ninl; sumY /= ninl; sumZ /= ninl;
     }
     const int leader = lane & 48;
@@ -727,7 +772,7 @@ __global__ __launch_bounds__(1024) void k_new_scan(SfDev P, int slot) {
     }
     if (threadIdx.x == 0) {
         const long long D = carry;
-        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = upd; P.ctr[4] = n;
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = upd; P.ctr[4] = n; P.ctr[7] = 0;
         const long long nAfter = D >= K ? n - (D - K) : n + (K - D);
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
         P.ctr[6] = nAfter;
@@ -804,6 +849,7 @@ __global__ __launch_bounds__(256) void k_place_resolve(SfDev P) {
 __global__ __launch_bounds__(256) void k_tail_move(SfDev P) {
     if (P.ctr[5] == 20) return;
     const long long n = P.ctr[4], D = P.ctr[2], K = P.ctr[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr[0] = P.ctr[6];   // publish the new live count (nobody reads ctr[0] until the next keyframe)
     if (D > K) {
         const long long R = D - K, nFinal = n - R;
         if (P.ctr[7] == -1) {
@@ -821,9 +867,6 @@ __global__ __launch_bounds__(256) void k_tail_move(SfDev P) {
                 move_surfel(P.map, (long long)P.delList[a], (long long)P.srcOf[a]);
         }
     }
-}
-__global__ void k_end_frame(long long *ctr) {
-    if (threadIdx.x == 0 && ctr[5] != 20) { ctr[0] = ctr[6]; ctr[7] = 0; }
 }
 
 // AoS <-> SoA conversion for upload / download / host-vector mode
@@ -1067,7 +1110,6 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             hipLaunchKernelGGL(k_del_list, dim3(512), dim3(1024), 0, sm, P);
             hipLaunchKernelGGL(k_place_resolve, dim3(128), dim3(256), 0, sm, P);
             hipLaunchKernelGGL(k_tail_move, dim3(128), dim3(256), 0, sm, P);
-            hipLaunchKernelGGL(k_end_frame, dim3(1), dim3(64), 0, sm, P.ctr);
             h->prof.end(sm);
         }
     }
