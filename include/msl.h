@@ -199,6 +199,9 @@ MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
 MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
 
+/* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
+MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);
+
 #define MSL_SF_NKERNELS 12
 MSL_API int msl_sf_profile_enable(msl_sf *h, int mode);
 MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);

@@ -5,7 +5,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsl.so")
+LIB_PATH = os.environ.get("MSL_LIB", os.path.join(_HERE, "libmsl.so"))   # MSL_LIB: kernel-variant experiments only
 
 
 class MslError(RuntimeError):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "msl_sf_set_stream": (_i, [_vp, _vp]),
     "msl_sf_debug_seeds": (_i, [_vp, _vp]),
     "msl_sf_debug_index": (_i, [_vp, _vp]),
+    "msl_debug_div100": (_i, [_vp, _vp, _sz]),
     "msl_sf_profile_enable": (_i, [_vp, _i]),
     "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),
     "msl_sf_kernel_name": (C.c_char_p, [_i]),

@@ -69,6 +69,7 @@ struct SfDev {
     uint8_t *fused;              // [slots][nseeds]
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
+    double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
     int *chunkAbort;             // [slots][2][16]
     int *changed;                // [slots][8]
     MapSoA map;
@@ -133,6 +134,17 @@ __host__ __device__ inline void inverse4(const T *m, T *inv) {
 #undef M_
 }
 
+// Correctly rounded x / 100.0 (x >= 0 finite) without the ~35-instruction f64 divide: two Markstein steps with
+// y = RN(1/100).  q1 is a faithful quotient (error < 1 ulp), so the final fused correction rounds to RN(x/100)
+// (Markstein's theorem; 100 = 1.5625 * 2^6 is not an all-ones significand).  Checked against true division on
+// the GPU by tests/test_surfel_gpu.py::test_div100_exact.
+__device__ __forceinline__ double div100_exact(double x) {
+    const double y = 0.01;                       // RN(1/100)
+    const double q0 = x * y;
+    const double q1 = fma(fma(-q0, 100.0, x), y, q0);
+    return fma(fma(-q1, 100.0, x), y, q1);
+}
+
 // Strictly sequential (left-to-right) float sums over 16-byte aligned LDS arrays; wide LDS reads are issued
 // ahead of the dependent add chain so the chain runs at VALU latency instead of LDS latency.
 __device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
@@ -170,7 +182,10 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     msl_seed s;
     memset(&s, 0, sizeof(s));
     P.fused[(size_t)slot * P.nseeds + seedI] = 0;
-    if (F.member[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) { P.seeds[(size_t)slot * P.nseeds + seedI] = s; return; }
+    if (F.member[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
+        P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.invDepth[(size_t)slot * P.nseeds + seedI] = 0.0;
+        return;
+    }
     s.use = 1;
     s.x = (float)imageX; s.y = (float)imageY;
     vec3b(P, F, (float)imageY, (float)imageX, s.r, s.g, s.b);
@@ -189,6 +204,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
             }
     }
     P.seeds[(size_t)slot * P.nseeds + seedI] = s;
+    P.invDepth[(size_t)slot * P.nseeds + seedI] = s.meanDepth > 0 ? 1.0 / (double)s.meanDepth : 0.0;
 }
 
 // kb_assign: a(p) = argmin seed of pixel p (:357-415 without the `stable` gate).  it == 0: every seed is
@@ -218,43 +234,48 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it) {
     float minDistDepth = 1e6f, minDistNodepth = 1e6f;
     int minSpIndexDepth = -1, minSpIndexNodepth = -1;
     bool allHasDepth = true;
-    // candidate seed fields for the 3x3 neighbourhood, loaded up front (clamped) so the 9 lookups overlap
-    float2 cxy[9], cdi[9];
+    // Of the 3x3 neighbourhood only the seeds with |8c+4-x| < 8 on both axes are candidates (:384-389): per axis the
+    // pixel's own cell plus the left/upper neighbour when (x mod 8) < 4 or the right/lower one when (x mod 8) > 4.
+    // Enumerate those <= 2x2 candidates in the reference's order (checkI outer, checkJ inner, ascending).
+    const int rx = colI - baseSpX * SP, ry = rowI - baseSpY * SP;
+    const int x0 = baseSpX - (rx < SP / 2 ? 1 : 0), nx = (rx == SP / 2) ? 1 : 2;
+    const int y0 = baseSpY - (ry < SP / 2 ? 1 : 0), ny = (ry == SP / 2) ? 1 : 2;
+    const double *invDepth = P.invDepth + (size_t)slot * P.nseeds;
+    // load the (up to) four candidates up front with clamped indices
+    float2 cxy[4], cdi[4];
+    double cinv[4];
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        const int sxI = min(max(baseSpX + c / 3 - 1, 0), P.spW - 1), syI = min(max(baseSpY + c % 3 - 1, 0), P.spH - 1);
+    for (int c = 0; c < 4; c++) {
+        const int sxI = min(max(x0 + (c >> 1), 0), P.spW - 1), syI = min(max(y0 + (c & 1), 0), P.spH - 1);
         const msl_seed *sp = &seeds[syI * P.spW + sxI];
         cxy[c] = *reinterpret_cast<const float2 *>(&sp->x);
         cdi[c] = *reinterpret_cast<const float2 *>(&sp->meanDepth);   // (meanDepth, meanIntensity)
+        cinv[c] = invDepth[syI * P.spW + sxI];                        // 1.0 / (double)meanDepth, the value the divide gives
     }
 #pragma unroll
-    for (int checkI = -1; checkI <= 1; checkI++)
-#pragma unroll
-        for (int checkJ = -1; checkJ <= 1; checkJ++) {
-            const int checkSpX = baseSpX + checkI, checkSpY = baseSpY + checkJ;
-            const int distSpX = abs(checkSpX * SP + SP / 2 - colI), distSpY = abs(checkSpY * SP + SP / 2 - rowI);
-            if (distSpX < SP && distSpY < SP && checkSpX >= 0 && checkSpX < P.spW && checkSpY >= 0 && checkSpY < P.spH) {
-                const int spIndex = checkSpY * P.spW + checkSpX;
-                const int c = (checkI + 1) * 3 + (checkJ + 1);
-                const float sx = cxy[c].x, sy = cxy[c].y, sI = cdi[c].y, sD = cdi[c].x;
-                // calculateCost (:333-355)
-                float nodepthCost = 0;
-                const float dist = (sx - colI) * (sx - colI) + (sy - rowI) * (sy - rowI);
-                nodepthCost += dist / ((SP / 2) * (SP / 2));
-                const float intensityDiff = sI - myIntensity;
-                nodepthCost = (float)((double)nodepthCost + (double)(intensityDiff * intensityDiff) / 100.0);
-                float depthCost = nodepthCost;
-                bool has = false;
-                if (sD > 0 && myInvDepth > 0) {
-                    const float inverseDepthDiff = (float)(1.0 / (double)sD - (double)myInvDepth);
-                    depthCost = (float)((double)depthCost + (double)(inverseDepthDiff * inverseDepthDiff) * 400.0);
-                    has = true;
-                }
-                allHasDepth &= has;
-                if (depthCost < minDistDepth) { minDistDepth = depthCost; minSpIndexDepth = spIndex; }
-                if (nodepthCost < minDistNodepth) { minDistNodepth = nodepthCost; minSpIndexNodepth = spIndex; }
+    for (int c = 0; c < 4; c++) {
+        const int checkSpX = x0 + (c >> 1), checkSpY = y0 + (c & 1);
+        if ((c >> 1) < nx && (c & 1) < ny && checkSpX >= 0 && checkSpX < P.spW && checkSpY >= 0 && checkSpY < P.spH) {
+            const int spIndex = checkSpY * P.spW + checkSpX;
+            const float sx = cxy[c].x, sy = cxy[c].y, sI = cdi[c].y, sD = cdi[c].x;
+            // calculateCost (:333-355)
+            float nodepthCost = 0;
+            const float dist = (sx - colI) * (sx - colI) + (sy - rowI) * (sy - rowI);
+            nodepthCost += dist / ((SP / 2) * (SP / 2));
+            const float intensityDiff = sI - myIntensity;
+            nodepthCost = (float)((double)nodepthCost + div100_exact((double)(intensityDiff * intensityDiff)));
+            float depthCost = nodepthCost;
+            bool has = false;
+            if (sD > 0 && myInvDepth > 0) {
+                const float inverseDepthDiff = (float)(cinv[c] - (double)myInvDepth);
+                depthCost = (float)((double)depthCost + (double)(inverseDepthDiff * inverseDepthDiff) * 400.0);
+                has = true;
             }
+            allHasDepth &= has;
+            if (depthCost < minDistDepth) { minDistDepth = depthCost; minSpIndexDepth = spIndex; }
+            if (nodepthCost < minDistNodepth) { minDistNodepth = nodepthCost; minSpIndexNodepth = spIndex; }
         }
+    }
     const int pick = allHasDepth ? minSpIndexDepth : minSpIndexNodepth;
     if (it == 0) { index[p] = (unsigned short)(pick >= 0 ? pick : 0); return; }
     amap[p] = pick >= 0 ? (unsigned short)pick : IDX_NONE;
@@ -446,6 +467,7 @@ __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     out._pad = 0;
     P.seeds[(size_t)slot * P.nseeds + seedI] = out;
     P.tmin[(size_t)slot * P.nseeds + seedI] = out.stable ? T_INF : 0u;
+    P.invDepth[(size_t)slot * P.nseeds + seedI] = out.meanDepth > 0 ? 1.0 / (double)out.meanDepth : 0.0;
 }
 
 // kb_seed_plane: calculateNorms (:775-803) fused per seed, 16 lanes per seed, 4 seeds per wave/workgroup.
@@ -546,27 +568,43 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
     __builtin_amdgcn_wave_barrier();
     bool active = inRange && nvalid >= 16;   // validDepthNum < 16 -> continue (:702)
     float meanDepth = S.meanDepth;
-    // ---- inliers, kept in order (:707-720): in-place ordered compaction, 16 entries per round ----
+    // ---- inliers, kept in order (:707-720).  Count first: when every valid pixel is an inlier (the common case)
+    // the list is already in place; otherwise in-place ordered compaction, 16 entries per round. ----
     int ninl = 0;
-    for (int t = 0; t < 16; t++) {
-        const int o = t * 16 + l;
-        bool inl = false;
-        float a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
-        if (active && o < nvalid) {
-            const float residual = meanDepth - s_d[g][o];
-            inl = residual < HUBER_RANGE && residual > -HUBER_RANGE;
-            a0 = s_p[g][0][o]; a1 = s_p[g][1][o]; a2 = s_p[g][2][o];
-            b0 = s_n[g][0][o]; b1 = s_n[g][1][o]; b2 = s_n[g][2][o];
+    {
+        int c = 0;
+        if (active)
+            for (int o = l; o < nvalid; o += 16) {
+                const float residual = meanDepth - s_d[g][o];
+                c += (residual < HUBER_RANGE && residual > -HUBER_RANGE) ? 1 : 0;
+            }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 16);
+        ninl = c;
+    }
+    const bool needCompact = active && ninl != nvalid;
+    if (__ballot(needCompact)) {
+        int w0 = 0;
+        for (int t = 0; t < 16; t++) {
+            const int o = t * 16 + l;
+            bool inl = false;
+            float a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+            if (needCompact && o < nvalid) {
+                const float residual = meanDepth - s_d[g][o];
+                inl = residual < HUBER_RANGE && residual > -HUBER_RANGE;
+                a0 = s_p[g][0][o]; a1 = s_p[g][1][o]; a2 = s_p[g][2][o];
+                b0 = s_n[g][0][o]; b1 = s_n[g][1][o]; b2 = s_n[g][2][o];
+            }
+            const unsigned gm = (unsigned)((__ballot(inl) >> (g * 16)) & 0xFFFFull);
+            __builtin_amdgcn_wave_barrier();   // every lane has read its slot before anyone overwrites (w <= o)
+            if (inl) {
+                const int w = w0 + __popc(gm & ((1u << l) - 1u));
+                s_p[g][0][w] = a0; s_p[g][1][w] = a1; s_p[g][2][w] = a2;
+                s_n[g][0][w] = b0; s_n[g][1][w] = b1; s_n[g][2][w] = b2;
+            }
+            w0 += __popc(gm);
+            __builtin_amdgcn_wave_barrier();
         }
-        const unsigned gm = (unsigned)((__ballot(inl) >> (g * 16)) & 0xFFFFull);
-        __builtin_amdgcn_wave_barrier();   // every lane has read its slot before anyone overwrites (w <= o)
-        if (inl) {
-            const int w = ninl + __popc(gm & ((1u << l) - 1u));
-            s_p[g][0][w] = a0; s_p[g][1][w] = a1; s_p[g][2][w] = a2;
-            s_n[g][0][w] = b0; s_n[g][1][w] = b1; s_n[g][2][w] = b2;
-        }
-        ninl += __popc(gm);
-        __builtin_amdgcn_wave_barrier();
     }
     if (active && (float)ninl / (float)nvalid < 0.8) active = false;
     float normX = 0.0f, normY = 0.0f, normZ = 0.0f, sumX = 0.0f, sumY = 0.0f, sumZ = 0.0f;
@@ -582,35 +620,67 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
     sumX = __shfl(sumX, leader, 64); sumY = __shfl(sumY, leader, 64); sumZ = __shfl(sumZ, leader, 64);
     // ---- getHuberNorm (:91-165): 5 Gauss-Newton steps, FP64 normal equations reduced over the 16 lanes ----
     float nx = normX, ny = normY, nz = normZ, nb = 0.0f;
+    // The Hessian depends only on WHICH points lie inside the Huber band; while that set is unchanged between
+    // iterations (the common case: all of them) its sums -- and the inverse -- are bit-identical and are reused.
+    unsigned prevMask = 0xFFFFFFFFu;   // impossible mask: forces the first evaluation
+    double inv[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) inv[q] = 0;
     for (int gnI = 0; gnI < 5; gnI++) {
-        double J0 = 0, J1 = 0, J2 = 0, J3 = 0, H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
-        if (active)
-            for (int o = l; o < ninl; o += 16) {
-                const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
-                const float residual = px * nx + py * ny + pz * nz + nb;
-                if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
-                    J0 += 2 * residual * px; J1 += 2 * residual * py; J2 += 2 * residual * pz; J3 += 2 * residual;
-                    H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
-                    H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
-                    H22 += 2 * pz * pz; H23 += 2 * pz; H33 += 2;
-                } else if (residual >= HUBER_RANGE) {
-                    J0 += HUBER_RANGE * px; J1 += HUBER_RANGE * py; J2 += HUBER_RANGE * pz; J3 += HUBER_RANGE;
-                } else if (residual <= -1 * HUBER_RANGE) {
-                    J0 += -1 * HUBER_RANGE * px; J1 += -1 * HUBER_RANGE * py; J2 += -1 * HUBER_RANGE * pz; J3 += -1 * HUBER_RANGE;
+        double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
+        unsigned mask = 0;
+        float rs[16];
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < 16; t++) {
+                const int o = l + 16 * t;
+                rs[t] = 0;
+                if (o < ninl) {
+                    const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
+                    const float residual = px * nx + py * ny + pz * nz + nb;
+                    rs[t] = residual;
+                    if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
+                        mask |= 1u << t;
+                        J0 += 2 * residual * px; J1 += 2 * residual * py; J2 += 2 * residual * pz; J3 += 2 * residual;
+                    } else if (residual >= HUBER_RANGE) {
+                        J0 += HUBER_RANGE * px; J1 += HUBER_RANGE * py; J2 += HUBER_RANGE * pz; J3 += HUBER_RANGE;
+                    } else if (residual <= -1 * HUBER_RANGE) {
+                        J0 += -1 * HUBER_RANGE * px; J1 += -1 * HUBER_RANGE * py; J2 += -1 * HUBER_RANGE * pz; J3 += -1 * HUBER_RANGE;
+                    }
                 }
             }
+        }
         J0 = group_sum_d(J0); J1 = group_sum_d(J1); J2 = group_sum_d(J2); J3 = group_sum_d(J3);
-        H00 = group_sum_d(H00); H01 = group_sum_d(H01); H02 = group_sum_d(H02); H03 = group_sum_d(H03);
-        H11 = group_sum_d(H11); H12 = group_sum_d(H12); H13 = group_sum_d(H13);
-        H22 = group_sum_d(H22); H23 = group_sum_d(H23); H33 = group_sum_d(H33);
-        double hs[16] = {H00 + 5, H01, H02, H03, H01, H11 + 5, H12, H13, H02, H12, H22 + 5, H23, H03, H13, H23, H33 + 5};
-        double inv[16];
-        inverse4<double>(hs, inv);
+        const bool sameSet = mask == prevMask;
+        const unsigned diffGroups = (unsigned)((__ballot(!sameSet) >> (g * 16)) & 0xFFFFull);   // uniform per group
+        prevMask = mask;
+        if (__ballot(diffGroups != 0)) {
+            double H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
+            if (active && diffGroups) {
+#pragma unroll
+                for (int t = 0; t < 16; t++)
+                    if (mask & (1u << t)) {
+                        const int o = l + 16 * t;
+                        const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
+                        H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
+                        H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
+                        H22 += 2 * pz * pz; H23 += 2 * pz; H33 += 2;
+                    }
+            }
+            H00 = group_sum_d(H00); H01 = group_sum_d(H01); H02 = group_sum_d(H02); H03 = group_sum_d(H03);
+            H11 = group_sum_d(H11); H12 = group_sum_d(H12); H13 = group_sum_d(H13);
+            H22 = group_sum_d(H22); H23 = group_sum_d(H23); H33 = group_sum_d(H33);
+            if (diffGroups) {
+                double hs[16] = {H00 + 5, H01, H02, H03, H01, H11 + 5, H12, H13, H02, H12, H22 + 5, H23, H03, H13, H23, H33 + 5};
+                inverse4<double>(hs, inv);
+            }
+        }
         const double jac[4] = {J0, J1, J2, J3};
         double upd[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) upd[r] = ((inv[0 * 4 + r] * jac[0] + inv[1 * 4 + r] * jac[1]) + inv[2 * 4 + r] * jac[2]) + inv[3 * 4 + r] * jac[3];
         nx = (float)((double)nx - upd[0]); ny = (float)((double)ny - upd[1]); nz = (float)((double)nz - upd[2]); nb = (float)((double)nb - upd[3]);
+        (void)rs;
     }
     if (!inRange || l != 0) return;
     if (active) {
@@ -745,35 +815,38 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
 // the candidates the fuse step did not consume; (2) exclusive scan of the per-chunk deleted counts.
 __global__ __launch_bounds__(1024) void k_new_scan(SfDev P, int slot) {
     __shared__ unsigned s_wave[17];
+    __shared__ unsigned s_upd;
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
     const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    unsigned base = 0;
-    for (int s0 = 0; s0 < P.nseeds; s0 += 1024) {
-        const int i = s0 + threadIdx.x;
-        const bool emit = i < P.nseeds && candOk[i] && !fused[i];
-        unsigned tot;
-        const unsigned pos = base + block_excl_scan(emit ? 1u : 0u, s_wave, &tot);
-        if (emit) P.newSurfels[pos] = cand[i];
-        base += tot;
-    }
-    const long long K = base;
+    if (threadIdx.x == 0) s_upd = 0;
+    // thread t owns the contiguous seeds [t*per, (t+1)*per): emission order = seed index order
+    const int per = (P.nseeds + 1023) / 1024;
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
+    unsigned cnt = 0;
+    for (int i = s0; i < s1; i++) cnt += (candOk[i] && !fused[i]) ? 1u : 0u;
+    unsigned K;
+    unsigned pos = block_excl_scan(cnt, s_wave, &K);
+    if (cnt)
+        for (int i = s0; i < s1; i++)
+            if (candOk[i] && !fused[i]) P.newSurfels[pos++] = cand[i];
     const long long n = P.ctr[0];
     const int nblk = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
-    unsigned carry = 0, upd = 0;
+    unsigned carry = 0;
     for (int b0 = 0; b0 < nblk; b0 += 1024) {
         const int b = b0 + threadIdx.x;
         const unsigned v = b < nblk ? P.blockSums[b] : 0;
         const unsigned u = b < nblk ? P.blockUpd[b] : 0;
-        unsigned tot, totu;
+        unsigned tot;
         const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
-        block_excl_scan(u, s_wave, &totu);
         if (b < nblk) P.blockSums[b] = ex;
-        carry += tot; upd += totu;
+        if (u) atomicAdd(&s_upd, u);
+        carry += tot;
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
         const long long D = carry;
-        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = upd; P.ctr[4] = n; P.ctr[7] = 0;
-        const long long nAfter = D >= K ? n - (D - K) : n + (K - D);
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[7] = 0;
+        const long long nAfter = D >= (long long)K ? n - (D - K) : n + (K - D);
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
         P.ctr[6] = nAfter;
     }
@@ -887,6 +960,11 @@ __global__ void k_set_ctr(long long *ctr, long long n) {
     if (threadIdx.x == 0) { ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
 }
 
+__global__ void k_debug_div100(const float *x, double *out, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = div100_exact((double)(x[i] * x[i]));
+}
+
 enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_COMMIT_SEEDS, SK_SEED_PLANE, SK_FUSE, SK_NEW, SK_COMPACT,
        SK_CONVERT, SK_COPY };
 const char *kSfNames[MSL_SF_NKERNELS] = {"kb_seed_init", "kb_assign", "kb_prop", "kb_commit_px", "kb_update_seeds", "kb_commit_seeds",
@@ -907,6 +985,7 @@ struct msl_sf {
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
     msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
+    double *d_invDepth = nullptr;
     // staged images (host input mode), per slot
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
@@ -962,7 +1041,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_gray); F(h->d_depth); F(h->d_member);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_gray); F(h->d_depth); F(h->d_member);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
     h->grayCap = h->depthCap = h->memberCap = 0;
 }
@@ -981,6 +1060,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_index, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_invDepth, sizeof(double) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_chunkAbort, sizeof(int) * 32 * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
@@ -989,6 +1069,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
+    D.invDepth = h->d_invDepth;
     h->maxBatch = maxBatch;
     h->evMapValid[0] = h->evMapValid[1] = false;
     h->evCopyValid[0] = h->evCopyValid[1] = false;
@@ -1081,6 +1162,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
+    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 pxGrid((W + 31) / 32, (H + 7) / 8, un), flatPx((D.npx + 255) / 256, un), seedGrid((D.nseeds + 255) / 256, un);
@@ -1356,6 +1438,15 @@ int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {
     if (rc != MSL_OK) return rc;
     h->prof.drain();
     for (int i = 0; i < MSL_SF_NKERNELS; i++) { if (ms) ms[i] = h->prof.ms[i]; if (launches) launches[i] = h->prof.launches[i]; }
+    return MSL_OK;
+}
+int msl_debug_div100(const float *x_host, double *out_host, size_t n) {
+    float *dx = nullptr; double *dout = nullptr;
+    MSL_HIP_TRY(hipMalloc(&dx, sizeof(float) * n)); MSL_HIP_TRY(hipMalloc(&dout, sizeof(double) * n));
+    MSL_HIP_TRY(hipMemcpy(dx, x_host, sizeof(float) * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_div100, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, dx, dout, (long long)n);
+    MSL_HIP_TRY(hipMemcpy(out_host, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dout);
     return MSL_OK;
 }
 const char *msl_sf_kernel_name(int k) { return (k >= 0 && k < MSL_SF_NKERNELS) ? kSfNames[k] : ""; }

@@ -184,3 +184,16 @@ def test_compaction_matches_literal_loop(oracle):
         expect = fuse_map_compact(lo, no)
         assert_surfels_close(mg, expect, f"trial {trial}")
     g.close()
+
+
+def test_div100_exact():
+    """The division-free x/100.0 used by the cost kernel is the correctly rounded quotient (bit-exact vs IEEE divide)."""
+    from manhattanslam_amd import lib
+    from manhattanslam_amd._lib import check, ptr
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(0, 255, 3_000_000), rng.uniform(0, 1, 500_000), np.arange(0, 256, 0.125),
+                        np.float32(2.0) ** rng.integers(-60, 60, 100_000) * rng.uniform(1, 2, 100_000)]).astype(np.float32)
+    out = np.zeros(len(x), np.float64)
+    check(lib.msl_debug_div100(ptr(x), ptr(out), len(x)))
+    ref = (x * x).astype(np.float64) / 100.0
+    assert np.array_equal(out, ref), np.flatnonzero(out != ref)[:5]

@@ -6,6 +6,8 @@ F = 32
 I = synth.TUM1
 g = SurfelFusion(640, 480, I['fx'], I['fy'], I['cx'], I['cy'], 30.0, 0.5)
 g.set_batch_capacity(F)
+if len(sys.argv) > 1 and sys.argv[1] == 'serial':
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
 m = synth.surfel_map(1000000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
 g.map_reserve(2100000); g.map_upload(m)
 fr = [synth.surfel_frame(k) for k in range(F)]
