@@ -169,8 +169,22 @@ __device__ __forceinline__ float seq_sum_f32_dterms(const double *t, int n, floa
     return s;
 }
 
+// XCD-aware block -> (keyframe slot, block-in-frame) mapping for the frame-batched kernels.  Workgroup `lin` runs on
+// XCD lin % 8 (observed dispatch order; used for speed only), and each XCD has its own 4 MB L2: give every XCD whole
+// keyframes (slot = xcd, xcd + 8, ...) so that one keyframe's images, index map and seeds (~3 MB) stay L2 resident
+// while its workgroups stream through, instead of all 8 L2s thrashing over the whole batch.
+// Launch with a 1-D grid of 8 * ceil(n_slots / 8) * blocksPerFrame workgroups.
+__device__ __forceinline__ bool xcd_slot(int blocksPerFrame, int nSlots, int &slot, int &blk) {
+    const unsigned lin = blockIdx.x;
+    const unsigned j = lin >> 3;
+    slot = (int)(lin & 7u) + 8 * (int)(j / (unsigned)blocksPerFrame);
+    blk = (int)(j % (unsigned)blocksPerFrame);
+    return slot < nSlots;
+}
+__host__ inline unsigned xcd_grid(int blocksPerFrame, int nSlots) { return 8u * (unsigned)((nSlots + 7) / 8) * (unsigned)blocksPerFrame; }
+
 // =============================================================================================
-// Frame-batched superpixel stage (blockIdx.y / .z = slot)
+// Frame-batched superpixel stage
 // =============================================================================================
 __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     const int slot = blockIdx.y;
@@ -212,10 +226,12 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
 // kb_assign: a(p) = argmin seed of pixel p (:357-415 without the `stable` gate).  it == 0: every seed is
 // unstable, so every free pixel is processed: write the index map directly.  it > 0: store a(p) and run
 // relaxation round 0 (pixels whose current seed is unstable at pass start are processed for sure).
-__global__ __launch_bounds__(256) void kb_assign(SfDev P, int it) {
-    const int slot = blockIdx.z;
-    const int colI = blockIdx.x * 32 + (threadIdx.x & 31), rowI = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+__global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
+    const int tilesX = (P.W + 31) / 32, tilesY = (P.H + 7) / 8;
+    int slot, blk;
+    if (!xcd_slot(tilesX * tilesY, nSlots, slot, blk)) return;
+    const int colI = (blk % tilesX) * 32 + (threadIdx.x & 31), rowI = (blk / tilesX) * 8 + (threadIdx.x >> 5);
+    if (blk == 0) {
         if (it > 0 && threadIdx.x < 8) P.changed[slot * 8 + threadIdx.x] = threadIdx.x == 0 ? 1 : 0;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + NCHUNK) P.chunkAbort[(slot * 2 + (it & 1)) * 16 + threadIdx.x - 64] = 0x7FFFFFFF;
     }
@@ -298,10 +314,11 @@ __device__ __forceinline__ bool relax_pixel(unsigned *tmin, const unsigned short
     return atomicMin(&tmin[a], (unsigned)p + 1u) > (unsigned)p + 1u;
 }
 
-__global__ __launch_bounds__(256) void kb_prop(SfDev P, int round) {
-    const int slot = blockIdx.y;
+__global__ __launch_bounds__(256) void kb_prop(SfDev P, int round, int nSlots) {
+    int slot, blk;
+    if (!xcd_slot((P.npx + 255) / 256, nSlots, slot, blk)) return;
     if (!P.changed[slot * 8 + round]) return;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blk * 256 + threadIdx.x;
     if (p >= P.npx) return;
     if (relax_pixel(P.tmin + (size_t)slot * P.nseeds, P.index + (size_t)slot * P.npx, P.amap + (size_t)slot * P.npx, p))
         P.changed[slot * 8 + round + 1] = 1;
@@ -326,9 +343,10 @@ __global__ __launch_bounds__(1024) void kb_prop_finish(SfDev P) {
     }
 }
 
-__global__ __launch_bounds__(256) void kb_commit_px(SfDev P) {
-    const int slot = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
+    int slot, blk;
+    if (!xcd_slot((P.npx + 255) / 256, nSlots, slot, blk)) return;
+    const int p = blk * 256 + threadIdx.x;
     if (p >= P.npx) return;
     unsigned short *index = P.index + (size_t)slot * P.npx;
     const unsigned short a = P.amap[(size_t)slot * P.npx + p];
@@ -339,14 +357,15 @@ __global__ __launch_bounds__(256) void kb_commit_px(SfDev P) {
 // kb_update_seeds (:428-515): 16 lanes per seed (lane = window row), 16 seeds per workgroup.
 // Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window
 // raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
-__global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it) {
+__global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     __shared__ __attribute__((aligned(16))) float s_depth[16][256];
     __shared__ __attribute__((aligned(16))) double s_term[16][256];
     __shared__ float s_mean[16];
     __shared__ int s_cnt[16], s_done[16];
-    const int slot = blockIdx.y;
+    int slot, blk;
+    if (!xcd_slot((P.nseeds + 15) / 16, nSlots, slot, blk)) return;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int seedI = blockIdx.x * 16 + g;
+    const int seedI = blk * 16 + g;
     const FrameDev &F = P.frames[slot];
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     msl_seed S;
@@ -495,19 +514,32 @@ __device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, f
     nX = normX; nY = normY; nZ = normZ;
 }
 
+// Sum over the 16 lanes of a DPP row (= one seed group); every lane receives the total.  Row rotations by 8 and 4
+// and quad permutes run in the VALU (a few cycles) instead of ds_bpermute round trips through the LDS crossbar.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double group_sum_d(double v) {
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+    v += dpp_mov_d<0x128>(v);   // row_ror:8
+    v += dpp_mov_d<0x124>(v);   // row_ror:4
+    v += dpp_mov_d<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov_d<0xB1>(v);    // quad_perm [1,0,3,2]
     return v;
 }
 
-__global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
+__global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     __shared__ __attribute__((aligned(16))) float s_d[4][256];
     __shared__ __attribute__((aligned(16))) float s_p[4][3][256];
     __shared__ __attribute__((aligned(16))) float s_n[4][3][256];
-    const int slot = blockIdx.y;
+    __shared__ __attribute__((aligned(16))) double s_h[4][16];
+    int slot, blk;
+    if (!xcd_slot((P.nseeds + 3) / 4, nSlots, slot, blk)) return;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15, lane = threadIdx.x;
-    const int seedI = blockIdx.x * 4 + g;
+    const int seedI = blk * 4 + g;
     const FrameDev &F = P.frames[slot];
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     const bool inRange = seedI < P.nseeds;
@@ -609,38 +641,41 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
         }
     }
     if (active && (float)ninl / (float)nvalid < 0.8) active = false;
-    float normX = 0.0f, normY = 0.0f, normZ = 0.0f, sumX = 0.0f, sumY = 0.0f, sumZ = 0.0f;
-    if (active && l == 0) {
-        normX = seq_sum_f32(s_n[g][0], ninl, 0.0f); normY = seq_sum_f32(s_n[g][1], ninl, 0.0f); normZ = seq_sum_f32(s_n[g][2], ninl, 0.0f);
+    // Six strictly sequential f32 sums (inlier normals x,y,z and positions x,y,z, :709-713 and :95-99) run side by side:
+    // lane q < 6 of the group walks array q in list order, so the serial latency is one chain instead of six.
+    float normX, normY, normZ, sumX, sumY, sumZ;
+    {
+        float acc = 0.0f;
+        if (active && l < 6) acc = seq_sum_f32(l < 3 ? s_n[g][l] : s_p[g][l - 3], ninl, 0.0f);
+        const int gb = lane & 48;
+        normX = __shfl(acc, gb + 0, 64); normY = __shfl(acc, gb + 1, 64); normZ = __shfl(acc, gb + 2, 64);
+        sumX = __shfl(acc, gb + 3, 64); sumY = __shfl(acc, gb + 4, 64); sumZ = __shfl(acc, gb + 5, 64);
         const float normLength = sqrtf(normX * normX + normY * normY + normZ * normZ);
         normX = normX / normLength; normY = normY / normLength; normZ = normZ / normLength;
-        sumX = seq_sum_f32(s_p[g][0], ninl, 0.0f); sumY = seq_sum_f32(s_p[g][1], ninl, 0.0f); sumZ = seq_sum_f32(s_p[g][2], ninl, 0.0f);
         sumX /= ninl; sumY /= ninl; sumZ /= ninl;
     }
-    const int leader = lane & 48;
-    normX = __shfl(normX, leader, 64); normY = __shfl(normY, leader, 64); normZ = __shfl(normZ, leader, 64);
-    sumX = __shfl(sumX, leader, 64); sumY = __shfl(sumY, leader, 64); sumZ = __shfl(sumZ, leader, 64);
     // ---- getHuberNorm (:91-165): 5 Gauss-Newton steps, FP64 normal equations reduced over the 16 lanes ----
     float nx = normX, ny = normY, nz = normZ, nb = 0.0f;
     // The Hessian depends only on WHICH points lie inside the Huber band; while that set is unchanged between
     // iterations (the common case: all of them) its sums -- and the inverse -- are bit-identical and are reused.
     unsigned prevMask = 0xFFFFFFFFu;   // impossible mask: forces the first evaluation
-    double inv[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) inv[q] = 0;
+    // Cooperative 4x4 inverse: lane l = 4a+b of the group evaluates cofactor (a,b) with exactly the DET3 expression of
+    // inverse4(), so lane l ends up holding inv[l] (column-major) -- 1/16 of the work and 2 instead of 32 registers.
+    double invl = 0;
+    const int ca = l >> 2, cb = l & 3;
+    const int r0 = ca == 0 ? 1 : 0, r1 = ca <= 1 ? 2 : 1, r2 = ca <= 2 ? 3 : 2;
+    const int c0 = cb == 0 ? 1 : 0, c1 = cb <= 1 ? 2 : 1, c2 = cb <= 2 ? 3 : 2;
+    const int gbase = lane & 48;
     for (int gnI = 0; gnI < 5; gnI++) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
         unsigned mask = 0;
-        float rs[16];
         if (active) {
 #pragma unroll
             for (int t = 0; t < 16; t++) {
                 const int o = l + 16 * t;
-                rs[t] = 0;
                 if (o < ninl) {
                     const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
                     const float residual = px * nx + py * ny + pz * nz + nb;
-                    rs[t] = residual;
                     if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
                         mask |= 1u << t;
                         J0 += 2 * residual * px; J1 += 2 * residual * py; J2 += 2 * residual * pz; J3 += 2 * residual;
@@ -672,17 +707,35 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P) {
             H00 = group_sum_d(H00); H01 = group_sum_d(H01); H02 = group_sum_d(H02); H03 = group_sum_d(H03);
             H11 = group_sum_d(H11); H12 = group_sum_d(H12); H13 = group_sum_d(H13);
             H22 = group_sum_d(H22); H23 = group_sum_d(H23); H33 = group_sum_d(H33);
-            if (diffGroups) {
-                double hs[16] = {H00 + 5, H01, H02, H03, H01, H11 + 5, H12, H13, H02, H12, H22 + 5, H23, H03, H13, H23, H33 + 5};
-                inverse4<double>(hs, inv);
+            if (l == 0) {   // the (symmetric) Hessian + 5 I, column-major
+                double *m = s_h[g];
+                m[0] = H00 + 5; m[1] = H01; m[2] = H02; m[3] = H03; m[4] = H01; m[5] = H11 + 5; m[6] = H12; m[7] = H13;
+                m[8] = H02; m[9] = H12; m[10] = H22 + 5; m[11] = H23; m[12] = H03; m[13] = H13; m[14] = H23; m[15] = H33 + 5;
             }
+            __builtin_amdgcn_wave_barrier();
+            {
+                const double *m = s_h[g];
+#define M_(r, c) m[(c) * 4 + (r)]
+                const double d3 = M_(r0, c0) * (M_(r1, c1) * M_(r2, c2) - M_(r1, c2) * M_(r2, c1)) -
+                                  M_(r0, c1) * (M_(r1, c0) * M_(r2, c2) - M_(r1, c2) * M_(r2, c0)) +
+                                  M_(r0, c2) * (M_(r1, c0) * M_(r2, c1) - M_(r1, c1) * M_(r2, c0));
+                const double cof = ((ca + cb) & 1) ? -d3 : d3;
+                const double f0 = __shfl(cof, gbase + 0, 64), f1 = __shfl(cof, gbase + 1, 64), f2 = __shfl(cof, gbase + 2, 64),
+                             f3 = __shfl(cof, gbase + 3, 64);
+                const double det = ((M_(0, 0) * f0 + M_(0, 1) * f1) + M_(0, 2) * f2) + M_(0, 3) * f3;
+#undef M_
+                if (diffGroups) invl = cof / det;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        const double jac[4] = {J0, J1, J2, J3};
-        double upd[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) upd[r] = ((inv[0 * 4 + r] * jac[0] + inv[1 * 4 + r] * jac[1]) + inv[2 * 4 + r] * jac[2]) + inv[3 * 4 + r] * jac[3];
-        nx = (float)((double)nx - upd[0]); ny = (float)((double)ny - upd[1]); nz = (float)((double)nz - upd[2]); nb = (float)((double)nb - upd[3]);
-        (void)rs;
+        // upd[r] = ((inv[0*4+r] J0 + inv[1*4+r] J1) + inv[2*4+r] J2) + inv[3*4+r] J3; lane l holds inv[l], its column is l >> 2
+        const double prod = invl * (ca == 0 ? J0 : ca == 1 ? J1 : ca == 2 ? J2 : J3);
+        const double q1 = __shfl(prod, gbase + 4 + cb, 64), q2 = __shfl(prod, gbase + 8 + cb, 64), q3 = __shfl(prod, gbase + 12 + cb, 64);
+        const double q0 = __shfl(prod, gbase + cb, 64);
+        const double updr = ((q0 + q1) + q2) + q3;            // lane with cb == r now holds upd[r]
+        const double u0 = __shfl(updr, gbase + 0, 64), u1 = __shfl(updr, gbase + 1, 64), u2 = __shfl(updr, gbase + 2, 64),
+                     u3 = __shfl(updr, gbase + 3, 64);
+        nx = (float)((double)nx - u0); ny = (float)((double)ny - u1); nz = (float)((double)nz - u2); nb = (float)((double)nb - u3);
     }
     if (!inRange || l != 0) return;
     if (active) {
@@ -862,23 +915,25 @@ __global__ __launch_bounds__(1024) void k_new_scan(SfDev P, int slot) {
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
     const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
     if (threadIdx.x == 0) s_upd = 0;
+    // issue every independent global load first (live count, first tile of chunk partials, the seeds' flags)
+    const long long n = P.ctr[0];
+    const unsigned v0 = P.blockSums[threadIdx.x], u0 = P.blockUpd[threadIdx.x];   // the arrays always hold >= 1024 entries (map_realloc)
     // thread t owns the contiguous seeds [t*per, (t+1)*per): emission order = seed index order
     const int per = (P.nseeds + 1023) / 1024;
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
-    unsigned cnt = 0;
-    for (int i = s0; i < s1; i++) cnt += (candOk[i] && !fused[i]) ? 1u : 0u;
+    unsigned cnt = 0, emask = 0;
+    for (int i = s0; i < s1; i++) { const unsigned e = (candOk[i] && !fused[i]) ? 1u : 0u; cnt += e; if (i - s0 < 32) emask |= e << (i - s0); }
     unsigned K;
     unsigned pos = block_excl_scan(cnt, s_wave, &K);
     if (cnt)
         for (int i = s0; i < s1; i++)
-            if (candOk[i] && !fused[i]) P.newSurfels[pos++] = cand[i];
-    const long long n = P.ctr[0];
+            if ((i - s0 < 32) ? ((emask >> (i - s0)) & 1u) : (candOk[i] && !fused[i])) P.newSurfels[pos++] = cand[i];
     const int nblk = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
     unsigned carry = 0;
     for (int b0 = 0; b0 < nblk; b0 += 1024) {
         const int b = b0 + threadIdx.x;
-        const unsigned v = b < nblk ? P.blockSums[b] : 0;
-        const unsigned u = b < nblk ? P.blockUpd[b] : 0;
+        const unsigned v = b < nblk ? (b0 == 0 ? v0 : P.blockSums[b]) : 0;
+        const unsigned u = b < nblk ? (b0 == 0 ? u0 : P.blockUpd[b]) : 0;
         unsigned tot;
         const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
         if (b < nblk) P.blockSums[b] = ex;
@@ -1062,8 +1117,10 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
-    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 2)));
-    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 2)));
+    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));   // >= 1024 entries: k_new_scan reads its first tile unconditionally
+    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
+    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
+    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
     MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
     if (keep && h->d_mapStore) {
@@ -1207,21 +1264,22 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
-    const dim3 pxGrid((W + 31) / 32, (H + 7) / 8, un), flatPx((D.npx + 255) / 256, un), seedGrid((D.nseeds + 255) / 256, un);
+    const dim3 seedGrid((D.nseeds + 255) / 256, un);
+    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid((D.npx + 255) / 256, n));
     LAUNCH(SK_SEED_INIT, sp, kb_seed_init, seedGrid, dim3(256), P);
     for (int it = 0; it < 3; it++) {
-        LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it);
+        LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
         if (it > 0) {
             h->prof.begin(SK_PROP, sp);
-            for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, flatPx, dim3(256), 0, sp, P, r);
+            for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, flatPx, dim3(256), 0, sp, P, r, n);
             hipLaunchKernelGGL(kb_prop_finish, dim3(un), dim3(1024), 0, sp, P);
             h->prof.end(sp);
-            LAUNCH(SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P);
+            LAUNCH(SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
         }
-        LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds, dim3((D.nseeds + 15) / 16, un), dim3(256), P, it);
+        LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         LAUNCH(SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    LAUNCH(SK_SEED_PLANE, sp, kb_seed_plane, dim3((D.nseeds + 3) / 4, un), dim3(64), P);
+    LAUNCH(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid((D.nseeds + 3) / 4, n)), dim3(64), P, n);
     if (sp != sm) {
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
