@@ -68,7 +68,7 @@ struct SfDev {
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
     uint8_t *candOk;             // [slots][nseeds]
-    uint8_t *fused;              // [slots][nseeds]
+    uint8_t *fused;              // [slots][nseeds] seed consumed by a fusion (written write-through, read at agent scope)
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
@@ -80,6 +80,7 @@ struct SfDev {
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
+    unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -785,13 +786,38 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
 // =============================================================================================
 // Map stage (per keyframe, sequential on the map stream)
 // =============================================================================================
-// k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks); each thread owns 4 CONSECUTIVE
-// surfels so that the streaming part (updateTimes, lastUpdate, position: 20 B per surfel) is five 16-byte loads per
-// lane -- enough bytes in flight per wave to approach HBM bandwidth.  The ~80 % of surfels that fail the cheap tests
-// (stale, deleted, out of range, out of image) finish there; survivors run the reference's remaining chain one by one.
+// "Last workgroup continues" hand-off (cdna_hip_programming.md G16): every workgroup publishes its global stores with an
+// agent-scope release, then takes a ticket; the one that draws the last ticket acquires and carries on with the next
+// stage inside the same launch, saving a dependent kernel boundary (~5 us each on this latency-critical chain).
+__device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_flag) {
+    // Everything the continuing workgroup reads from this launch is stored write-through (agent-scope atomic stores /
+    // RMW atomics) and read back with agent-scope loads, so no L2 write-back fence is needed -- a release fence per
+    // workgroup would flush megabytes of freshly dirtied surfel lines 1000 times per launch.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        *s_flag = (t == gridDim.x - 1) ? 1u : 0u;
+        if (*s_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset for the next launch
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks).
+//   Phase A (streaming): each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records
+//   per lane.  The ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.
+//   Survivors are compacted into an LDS list (slot by LDS atomic; per-surfel work is order independent).
+//   Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed,
+//   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
+struct FuseSurv { unsigned i; int pix; float pcz, x, y, z; int ut; };
+
 __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
-    __shared__ unsigned s_cnt[2];
+    __shared__ unsigned s_cnt[3];
+    __shared__ FuseSurv s_surv[SCAN_ITEMS];
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const MapSoA &M = P.map;
@@ -803,12 +829,11 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     static_assert(SCAN_ITEMS == 1024, "4 consecutive surfels per thread x 256 threads");
     for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
-        if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         unsigned ndel = 0, nupd = 0;
-        const long long i0 = b * SCAN_ITEMS + 4 * threadIdx.x;     // map capacity is a multiple of 4096: the 16-byte loads stay in bounds
-        int utv[4], luv[4];
-        float xv[4], yv[4], zv[4];
+        const long long c0 = b * SCAN_ITEMS;
+        const long long i0 = c0 + 4 * threadIdx.x;     // map capacity is a multiple of 4096: the 16-byte loads stay in bounds
         {
             const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
             uint4 q[5];
@@ -818,45 +843,33 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
                                     q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                xv[k] = __uint_as_float(w[5 * k]); yv[k] = __uint_as_float(w[5 * k + 1]); zv[k] = __uint_as_float(w[5 * k + 2]);
-                utv[k] = (int)w[5 * k + 3]; luv[k] = (int)w[5 * k + 4];
+                const long long i = i0 + k;
+                if (i >= n) continue;
+                const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
+                const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
+                if (ref - lu > 5 && ut < 5) { if (ut != 0) M.hot[i].updateTimes = 0; ndel++; continue; }
+                if (ut == 0) { ndel++; continue; }
+                float pc[4];
+                mul4(F.invPose, x, y, z, 1.0f, pc);
+                if (pc[2] < P.fuseNear || pc[2] > P.fuseFar) continue;
+                const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;  // :75-78
+                const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
+                if (pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2) continue;
+                FuseSurv e;
+                e.i = (unsigned)(i - c0); e.pix = pVInt * P.W + pUInt; e.pcz = pc[2]; e.x = x; e.y = y; e.z = z; e.ut = ut;
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = e;
             }
         }
-        int pix[4];
-        float pcz[4];
-        unsigned liveMask = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            pix[k] = 0; pcz[k] = 0;
-            const long long i = i0 + k;
-            if (i >= n) continue;
-            if (ref - luv[k] > 5 && utv[k] < 5) { if (utv[k] != 0) M.hot[i].updateTimes = 0; ndel++; continue; }
-            if (utv[k] == 0) { ndel++; continue; }
-            float pc[4];
-            mul4(F.invPose, xv[k], yv[k], zv[k], 1.0f, pc);
-            if (pc[2] < P.fuseNear || pc[2] > P.fuseFar) continue;
-            const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;  // :75-78
-            const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
-            if (pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2) continue;
-            pix[k] = pVInt * P.W + pUInt; pcz[k] = pc[2];
-            liveMask |= 1u << k;
-        }
-        // depth / superpixel lookups of the survivors, issued together
-        float dep[4];
-        int sp[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int row = pix[k] / P.W, col = pix[k] - row * P.W;
-            dep[k] = F.depth[(size_t)row * P.dstride + col];
-            sp[k] = index[pix[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (!(liveMask & (1u << k))) continue;
-            const long long i = i0 + k;
-            const float pz = pcz[k];
-            if ((double)pz < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; ndel++; continue; }
-            const int spIndex = sp[k];
+        __syncthreads();
+        const unsigned nsurv = s_cnt[2];
+        for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
+            const FuseSurv e = s_surv[sidx];
+            const long long i = c0 + e.i;
+            const float pz = e.pcz;
+            const int row = e.pix / P.W, col = e.pix - row * P.W;
+            const float dep = F.depth[(size_t)row * P.dstride + col];
+            const int spIndex = index[e.pix];
+            if ((double)pz < (double)dep - 1.0) { M.hot[i].updateTimes = 0; ndel++; continue; }
             const msl_seed S = seeds[spIndex];
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
             if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; ndel++; continue; }
-            const float Lpx = xv[k], Lpy = yv[k], Lpz = zv[k];
+            const float Lpx = e.x, Lpy = e.y, Lpz = e.z;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
             const float sumWeight = oldWeight + newWeight;
@@ -887,7 +900,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             float newNormW[3];
             mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
             HotRec Hn;
-            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = utv[k] + 1; Hn.lastUpdate = ref;
+            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = e.ut + 1; Hn.lastUpdate = ref;
             C.r = S.r; C.g = S.g; C.b = S.b;
             C.nx = newNormW[0]; C.ny = newNormW[1]; C.nz = newNormW[2];
             C.weight = sumWeight;
@@ -907,69 +920,6 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     }
 }
 
-// k_new_scan: single workgroup.  (1) initializeSurfels (:285-331): seeds in index order, ordered emission of
-// the candidates the fuse step did not consume; (2) exclusive scan of the per-chunk deleted counts.
-__global__ __launch_bounds__(1024) void k_new_scan(SfDev P, int slot) {
-    __shared__ unsigned s_wave[17];
-    __shared__ unsigned s_upd;
-    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    if (threadIdx.x == 0) s_upd = 0;
-    // issue every independent global load first (live count, first tile of chunk partials, the seeds' flags)
-    const long long n = P.ctr[0];
-    const unsigned v0 = P.blockSums[threadIdx.x], u0 = P.blockUpd[threadIdx.x];   // the arrays always hold >= 1024 entries (map_realloc)
-    // thread t owns the contiguous seeds [t*per, (t+1)*per): emission order = seed index order
-    const int per = (P.nseeds + 1023) / 1024;
-    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
-    unsigned cnt = 0, emask = 0;
-    for (int i = s0; i < s1; i++) { const unsigned e = (candOk[i] && !fused[i]) ? 1u : 0u; cnt += e; if (i - s0 < 32) emask |= e << (i - s0); }
-    unsigned K;
-    unsigned pos = block_excl_scan(cnt, s_wave, &K);
-    if (cnt)
-        for (int i = s0; i < s1; i++)
-            if ((i - s0 < 32) ? ((emask >> (i - s0)) & 1u) : (candOk[i] && !fused[i])) P.newSurfels[pos++] = cand[i];
-    const int nblk = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
-    unsigned carry = 0;
-    for (int b0 = 0; b0 < nblk; b0 += 1024) {
-        const int b = b0 + threadIdx.x;
-        const unsigned v = b < nblk ? (b0 == 0 ? v0 : P.blockSums[b]) : 0;
-        const unsigned u = b < nblk ? (b0 == 0 ? u0 : P.blockUpd[b]) : 0;
-        unsigned tot;
-        const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
-        if (b < nblk) P.blockSums[b] = ex;
-        if (u) atomicAdd(&s_upd, u);
-        carry += tot;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const long long D = carry;
-        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[7] = 0;
-        const long long nAfter = D >= (long long)K ? n - (D - K) : n + (K - D);
-        if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
-        P.ctr[6] = nAfter;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_del_list(SfDev P) {
-    __shared__ unsigned s_wave[17];
-    const long long n = P.ctr[4];
-    if (P.ctr[2] == 0) return;
-    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
-        unsigned base = P.blockSums[b];
-        const unsigned next = b + 1 < nblk ? P.blockSums[b + 1] : (unsigned)P.ctr[2];
-        if (next == base) continue;   // nothing deleted in this chunk
-        for (int k = 0; k < SCAN_ITEMS / 1024; k++) {
-            const long long i = b * SCAN_ITEMS + k * 1024 + threadIdx.x;
-            const unsigned f = (i < n && P.map.hot[i].updateTimes == 0) ? 1u : 0u;
-            unsigned tot;
-            const unsigned pos = base + block_excl_scan(f, s_wave, &tot);
-            if (f) P.delList[pos] = (unsigned)i;
-            base += tot;
-        }
-    }
-}
-
 __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
     HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
     ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
@@ -986,56 +936,108 @@ __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long
 // resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): a short upward chain.
 constexpr int TAIL_MAX_HOPS = 64;
 
-__global__ __launch_bounds__(256) void k_place_resolve(SfDev P) {
-    if (P.ctr[5] == 20) return;
-    const long long n = P.ctr[4], D = P.ctr[2], K = P.ctr[1];
-    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+// k_compact: everything after k_fuse in ONE launch.
+//   every workgroup : exclusive scan of the per-chunk deleted counts (each workgroup scans the <= cap/1024 partials itself,
+//                     so there is no inter-workgroup dependency), then lists the deleted slots of its own chunks in
+//                     ascending order (write-through stores);
+//   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
+//                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
+// mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
+__global__ __launch_bounds__(1024) void k_compact(SfDev P, int slot, int mode) {
+    __shared__ unsigned s_wave[17];
+    __shared__ unsigned s_ex[1024];
+    __shared__ unsigned s_last, s_upd;
+    __shared__ int s_fallback;
+    const long long n = P.ctr[0];
+    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    const bool bad = P.ctr[5] == 20;
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; }
+    // ---- scan of the chunk partials, tile by tile; own chunks of a tile are listed right away ----
+    unsigned carry = 0;
+    for (long long t0 = 0; t0 < nblk; t0 += 1024) {
+        const long long c = t0 + threadIdx.x;
+        const unsigned v = c < nblk ? P.blockSums[c] : 0;
+        unsigned tot;
+        const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
+        s_ex[threadIdx.x] = ex;
+        __syncthreads();
+        if (mode == 0 && !bad)
+            for (long long b = t0 + blockIdx.x; b < min(t0 + 1024, nblk); b += gridDim.x) {
+                const unsigned base = s_ex[b - t0];
+                const unsigned next = (b - t0 + 1 < 1024 && b + 1 < nblk) ? s_ex[b - t0 + 1] : carry + tot;
+                if (next == base) continue;   // nothing deleted in this chunk
+                const long long i = b * SCAN_ITEMS + threadIdx.x;
+                const unsigned f = (i < n && P.map.hot[i].updateTimes == 0) ? 1u : 0u;
+                unsigned tt;
+                const unsigned pos = base + block_excl_scan(f, s_wave, &tt);
+                if (f) st_agent(&P.delList[pos], (unsigned)i);
+            }
+        carry += tot;
+        __syncthreads();
+    }
+    const long long D = carry;
+    if (mode == 0 && !last_workgroup(&P.tickets[1], &s_last)) return;
+    // ================= continuation: one workgroup =================
+    // updated count
+    for (long long c = threadIdx.x; c < nblk; c += blockDim.x) { const unsigned u = P.blockUpd[c]; if (u) atomicAdd(&s_upd, u); }
+    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const int per = (P.nseeds + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
+    unsigned cnt = 0;
+    for (int i = s0; i < s1; i++) cnt += (candOk[i] && !fused[i]) ? 1u : 0u;
+    unsigned Ku;
+    unsigned pos = block_excl_scan(cnt, s_wave, &Ku);
+    if (cnt)
+        for (int i = s0; i < s1; i++)
+            if (candOk[i] && !fused[i]) P.newSurfels[pos++] = cand[i];
+    const long long K = Ku;
+    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
+    __syncthreads();   // newSurfels complete (same workgroup), s_upd complete
+    if (threadIdx.x == 0) {
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
+        if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
+    }
+    if (mode == 1 || bad || (unsigned long long)nAfter > P.cap) return;
+    auto DL = [&](long long j) -> unsigned { return ld_agent(&P.delList[j]); };
+    const long long t0 = threadIdx.x, stride = blockDim.x;
+    // new surfel k -> k-th largest deleted slot while any remain, else appended (SurfelMapping.cpp:372-384)
     for (long long k = t0; k < K; k += stride) {
-        const long long dst = k < D ? (long long)P.delList[D - 1 - k] : n + (k - D);
+        const long long dst = k < D ? (long long)DL(D - 1 - k) : n + (k - D);
         store_surfel(P.map, dst, P.newSurfels[k]);
     }
-    if (D <= K) return;
-    const long long R = D - K, nFinal = n - R;
-    auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
-        long long lo = 0, hi = R;
-        while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < x) lo = mid + 1; else hi = mid; }
-        return lo;
-    };
-    const long long cntLow = lower(nFinal);
-    for (long long a = t0; a < cntLow; a += stride) {
-        long long p = nFinal + a;
-        int hop = 0;
-        for (; hop < TAIL_MAX_HOPS; hop++) {
-            const long long lb = lower(p);
-            if (lb < R && (long long)P.delList[lb] == p) p = n - (R - lb);   // relay hole: follow to where its content came from
-            else break;
-        }
-        if (hop == TAIL_MAX_HOPS) P.ctr[7] = -1;   // pathological chain: fall back to the literal loop
-        P.srcOf[a] = (unsigned)p;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_tail_move(SfDev P) {
-    if (P.ctr[5] == 20) return;
-    const long long n = P.ctr[4], D = P.ctr[2], K = P.ctr[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr[0] = P.ctr[6];   // publish the new live count (nobody reads ctr[0] until the next keyframe)
     if (D > K) {
         const long long R = D - K, nFinal = n - R;
-        if (P.ctr[7] == -1) {
-            // literal back-to-front loop, one thread (only for pathological delete patterns)
-            if (blockIdx.x == 0 && threadIdx.x == 0)
+        auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
+            long long lo = 0, hi = R;
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const long long cntLow = lower(nFinal);
+        for (long long a = t0; a < cntLow; a += stride) {
+            long long p = nFinal + a;
+            int hop = 0;
+            for (; hop < TAIL_MAX_HOPS; hop++) {
+                const long long lb = lower(p);
+                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb);   // relay hole: follow to where its content came from
+                else break;
+            }
+            if (hop == TAIL_MAX_HOPS) s_fallback = 1;   // pathological chain: fall back to the literal loop
+            P.srcOf[a] = (unsigned)p;
+        }
+        __syncthreads();   // also orders the new-surfel stores above before the moves below (same workgroup)
+        if (s_fallback) {
+            if (threadIdx.x == 0)   // literal back-to-front loop (SurfelMapping.cpp:386-390), pathological delete patterns only
                 for (long long i = 1; i <= R; i++) {
-                    const long long hole = P.delList[R - i], src = n - i;
+                    const long long hole = DL(R - i), src = n - i;
                     if (src != hole) move_surfel(P.map, hole, src);
                 }
         } else {
-            long long lo = 0, hi = R;
-            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < nFinal) lo = mid + 1; else hi = mid; }
-            const long long cntLow = lo;
-            for (long long a = (long long)blockIdx.x * 256 + threadIdx.x; a < cntLow; a += (long long)gridDim.x * 256)
-                move_surfel(P.map, (long long)P.delList[a], (long long)P.srcOf[a]);
+            for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
         }
     }
+    if (threadIdx.x == 0) P.ctr[0] = nAfter;   // publish the new live count
 }
 
 // AoS <-> SoA conversion for upload / download / host-vector mode
@@ -1088,6 +1090,7 @@ struct msl_sf {
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
+    unsigned *d_tickets = nullptr;
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
@@ -1286,14 +1289,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     }
     for (int f = 0; f < n; f++) {
         LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f);
-        LAUNCH(SK_NEW, sm, k_new_scan, dim3(1), dim3(1024), P, f);
-        if (compact) {
-            h->prof.begin(SK_COMPACT, sm);
-            hipLaunchKernelGGL(k_del_list, dim3(512), dim3(1024), 0, sm, P);
-            hipLaunchKernelGGL(k_place_resolve, dim3(128), dim3(256), 0, sm, P);
-            hipLaunchKernelGGL(k_tail_move, dim3(128), dim3(256), 0, sm, P);
-            h->prof.end(sm);
-        }
+        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 256 : 1), dim3(1024), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     MSL_HIP_TRY(hipGetLastError());
@@ -1330,9 +1326,10 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 8) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 8);
-    D.ctr = h->d_ctr; D.newSurfels = h->d_new;
+    D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets;
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
     return h;
@@ -1346,7 +1343,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
