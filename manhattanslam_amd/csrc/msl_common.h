@@ -64,20 +64,22 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
 
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
 // s_wave must hold >= 17 unsigned. Returns the exclusive prefix; *total gets the block sum.
+// Two barriers, no serial section: every thread folds the <= 16 wave totals itself (LDS broadcast reads).
 __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *s_wave, unsigned *total) {
     const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    unsigned inc = wave_incl_scan(v);
+    const unsigned inc = wave_incl_scan(v);
     __syncthreads();  // protect s_wave reuse
     if (lane_id() == 63) s_wave[w] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned run = 0;
-        for (int i = 0; i < nw; i++) { unsigned t = s_wave[i]; s_wave[i] = run; run += t; }
-        s_wave[16] = run;
+    unsigned before = 0, all = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const unsigned t = i < nw ? s_wave[i] : 0u;
+        all += t;
+        before += i < w ? t : 0u;
     }
-    __syncthreads();
-    *total = s_wave[16];
-    return s_wave[w] + inc - v;
+    *total = all;
+    return before + inc - v;
 }
 
 // In-place inclusive scan of an LDS array (len elements) by the whole block.

@@ -11,16 +11,16 @@
 //   pre stream, one launch per batch of F keyframes:
 //     kb_seed_init                        one thread per 8x8 superpixel seed                  (:528-584)
 //     3 x { kb_assign                     one thread per pixel: argmin over <= 9 seeds        (:333-415)
-//           [kb_prop x2, kb_prop_finish,  raster-order `stable` semantics as a min-fixpoint   (App. B.7.1)
-//            kb_commit_px]
+//           [kb_prop x6, kb_prop_finish,  raster-order `stable` semantics as a min-fixpoint   (App. B.7.1)
+//            kb_commit_px]                  over a compact worklist of the only pixels that can extend a chain
 //           kb_update_seeds               16 lanes per seed: ordered window gather, Huber mean (:428-515)
 //           kb_commit_seeds }             chunk-abort (`return`) semantics                    (App. B.7.2)
 //     kb_seed_plane                       16 lanes per seed: back-projection, pixel normals, Huber plane
 //                                         fit with FP64 4x4 normal equations                  (:91-165, :597-773)
-//   map stream, per keyframe:
-//     k_fuse                              live surfels, SoA map resident in HBM               (:167-283)
-//     k_new_scan                          ordered emission of un-fused seeds + scan partials  (:285-331)
-//     k_del_list / k_place_resolve / k_tail_move   deleted-slot refill + tail compaction      (SurfelMapping.cpp:366-391)
+//   map stream, per keyframe (two launches):
+//     k_fuse                              live surfels, hot/cold record map resident in HBM   (:167-283)
+//     k_compact                           chunk scan, deleted-slot list, ordered emission of un-fused seeds (:285-331),
+//                                         deleted-slot refill + tail compaction               (SurfelMapping.cpp:366-391)
 //
 // HBM-bound integer/float streaming; no MFMA.  Every float expression keeps the reference's evaluation
 // order and float/double promotions; compiled with -ffp-contract=off.
@@ -39,7 +39,7 @@ constexpr int SP = 8;
 constexpr int NCHUNK = 10;  // THREAD_NUM, include/SurfelFusion.h:34
 constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE_D = 0.5, DISPARITY_ERROR = 4.0, MIN_TOLERATE_DIFF = 0.1;
 constexpr unsigned T_INF = 0xFFFFFFFFu;
-constexpr int PROP_ROUNDS = 6;          // full-grid relaxation rounds before the single-workgroup finisher
+constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup chunk in the map-stage kernels
 
@@ -72,6 +72,8 @@ struct SfDev {
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
+    unsigned *wl;                // [slots][npx] relaxation worklist: pixels on a stable seed that pick a different seed
+    unsigned *wlCount;           // [slots]
     int *chunkAbort;             // [slots][2][16]
     int *changed;                // [slots][8]
     MapSoA map;
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;
     if (seedI >= P.nseeds) return;
+    if (seedI == 0) P.wlCount[slot] = 0;
     const FrameDev &F = P.frames[slot];
     const int spX = seedI % P.spW, spY = seedI / P.spW;
     int imageX = spX * SP + SP / 2, imageY = spY * SP + SP / 2;
@@ -300,7 +303,14 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
     amap[p] = pick >= 0 ? (unsigned short)pick : IDX_NONE;
     if (pick >= 0) {
         unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
-        if (seeds[index[p]].stable == 0 && tmin[pick] > (unsigned)p + 1u) atomicMin(&tmin[pick], (unsigned)p + 1u);
+        const int cur = index[p];
+        if (seeds[cur].stable == 0) {
+            if (tmin[pick] > (unsigned)p + 1u) atomicMin(&tmin[pick], (unsigned)p + 1u);       // processed for sure: round 0
+        } else if (pick != cur) {
+            // Only these pixels can extend a chain: p is processed iff its (stable) seed gets unstabilised before p, and it
+            // then unstabilises a DIFFERENT seed.  (pick == cur would only re-lower t(cur) above its current value.)
+            P.wl[(size_t)slot * P.npx + atomicAdd(&P.wlCount[slot], 1u)] = (unsigned)p;
+        }
     }
 }
 
@@ -315,14 +325,18 @@ __device__ __forceinline__ bool relax_pixel(unsigned *tmin, const unsigned short
     return atomicMin(&tmin[a], (unsigned)p + 1u) > (unsigned)p + 1u;
 }
 
+constexpr int PROP_BLOCKS = 16;   // workgroups per keyframe over the (small) worklist
 __global__ __launch_bounds__(256) void kb_prop(SfDev P, int round, int nSlots) {
     int slot, blk;
-    if (!xcd_slot((P.npx + 255) / 256, nSlots, slot, blk)) return;
+    if (!xcd_slot(PROP_BLOCKS, nSlots, slot, blk)) return;
     if (!P.changed[slot * 8 + round]) return;
-    const int p = blk * 256 + threadIdx.x;
-    if (p >= P.npx) return;
-    if (relax_pixel(P.tmin + (size_t)slot * P.nseeds, P.index + (size_t)slot * P.npx, P.amap + (size_t)slot * P.npx, p))
-        P.changed[slot * 8 + round + 1] = 1;
+    unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
+    const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
+    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    const unsigned nwl = P.wlCount[slot];
+    bool any = false;
+    for (unsigned e = blk * 256 + threadIdx.x; e < nwl; e += PROP_BLOCKS * 256) any |= relax_pixel(tmin, index, amap, (int)wl[e]);
+    if (any) P.changed[slot * 8 + round + 1] = 1;
 }
 
 // Finisher: one workgroup per keyframe iterates the relaxation to its fixpoint (normally zero rounds).
@@ -333,12 +347,14 @@ __global__ __launch_bounds__(1024) void kb_prop_finish(SfDev P) {
     __syncthreads();
     unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
+    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    const unsigned nwl = P.wlCount[slot];
     while (s_ch) {
         __syncthreads();
         if (threadIdx.x == 0) s_ch = 0;
         __syncthreads();
         bool any = false;
-        for (int p = threadIdx.x; p < P.npx; p += 1024) any |= relax_pixel(tmin, index, amap, p);
+        for (unsigned e = threadIdx.x; e < nwl; e += 1024) any |= relax_pixel(tmin, index, amap, (int)wl[e]);
         if (any) s_ch = 1;
         __syncthreads();
     }
@@ -481,6 +497,7 @@ __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;
     if (seedI >= P.nseeds) return;
+    if (seedI == 0) P.wlCount[slot] = 0;   // the next pixel pass rebuilds the relaxation worklist
     const msl_seed T = P.seedsTmp[(size_t)slot * P.nseeds + seedI];
     msl_seed out;
     if (T._pad == 0) out = T;                                                                                          // skipped
@@ -943,34 +960,62 @@ constexpr int TAIL_MAX_HOPS = 64;
 //   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
 //                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
 // mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
-__global__ __launch_bounds__(1024) void k_compact(SfDev P, int slot, int mode) {
+__global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
+    constexpr int NT = 256, TILE = 4 * NT;      // 256-thread workgroups find a free CU quickly next to the batched kernels
     __shared__ unsigned s_wave[17];
-    __shared__ unsigned s_ex[1024];
+    __shared__ unsigned s_ex[TILE];
     __shared__ unsigned s_last, s_upd;
     __shared__ int s_fallback;
+    // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
+    // the continuation needs, so the last workgroup does not start its dependent chain with a cold memory round trip.
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
+    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
+    unsigned cnt = 0;
+    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
+    for (int i = s0; i < s1; i += 4) {
+        unsigned c4, f4;
+        if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
+            c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
+        } else {
+            c4 = f4 = 0;
+            for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
+            cnt += e;
+            if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+        }
+    }
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const bool bad = P.ctr[5] == 20;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; }
-    // ---- scan of the chunk partials, tile by tile; own chunks of a tile are listed right away ----
+    // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread); own chunks of a tile are listed right away ----
     unsigned carry = 0;
-    for (long long t0 = 0; t0 < nblk; t0 += 1024) {
-        const long long c = t0 + threadIdx.x;
-        const unsigned v = c < nblk ? P.blockSums[c] : 0;
+    for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+        const long long c = t0 + 4 * threadIdx.x;
+        const uint4 v4 = *reinterpret_cast<const uint4 *>(P.blockSums + c);   // the array is padded by >= 1024 zeroed entries
+        const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
         unsigned tot;
-        const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
-        s_ex[threadIdx.x] = ex;
+        unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s_ex[4 * threadIdx.x + j] = ex; ex += v[j]; }
         __syncthreads();
         if (mode == 0 && !bad)
-            for (long long b = t0 + blockIdx.x; b < min(t0 + 1024, nblk); b += gridDim.x) {
+            for (long long b = t0 + blockIdx.x; b < min(t0 + TILE, nblk); b += gridDim.x) {
                 const unsigned base = s_ex[b - t0];
-                const unsigned next = (b - t0 + 1 < 1024 && b + 1 < nblk) ? s_ex[b - t0 + 1] : carry + tot;
+                const unsigned next = (b - t0 + 1 < TILE && b + 1 < nblk) ? s_ex[b - t0 + 1] : carry + tot;
                 if (next == base) continue;   // nothing deleted in this chunk
-                const long long i = b * SCAN_ITEMS + threadIdx.x;
-                const unsigned f = (i < n && P.map.hot[i].updateTimes == 0) ? 1u : 0u;
+                const long long i0 = b * SCAN_ITEMS + 4 * threadIdx.x;   // 4 consecutive slots per thread keep the list ascending
+                unsigned f[4], c4 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { f[j] = (i0 + j < n && P.map.hot[i0 + j].updateTimes == 0) ? 1u : 0u; c4 += f[j]; }
                 unsigned tt;
-                const unsigned pos = base + block_excl_scan(f, s_wave, &tt);
-                if (f) st_agent(&P.delList[pos], (unsigned)i);
+                unsigned pos = base + block_excl_scan(c4, s_wave, &tt);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (f[j]) st_agent(&P.delList[pos++], (unsigned)(i0 + j));
             }
         carry += tot;
         __syncthreads();
@@ -981,17 +1026,12 @@ __global__ __launch_bounds__(1024) void k_compact(SfDev P, int slot, int mode) {
     // updated count
     for (long long c = threadIdx.x; c < nblk; c += blockDim.x) { const unsigned u = P.blockUpd[c]; if (u) atomicAdd(&s_upd, u); }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
-    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
     const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    const int per = (P.nseeds + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
-    unsigned cnt = 0;
-    for (int i = s0; i < s1; i++) cnt += (candOk[i] && !fused[i]) ? 1u : 0u;
     unsigned Ku;
     unsigned pos = block_excl_scan(cnt, s_wave, &Ku);
     if (cnt)
         for (int i = s0; i < s1; i++)
-            if (candOk[i] && !fused[i]) P.newSurfels[pos++] = cand[i];
+            if ((i - s0 < 64) ? ((emit >> (i - s0)) & 1ull) : (candOk[i] && !fused[i])) P.newSurfels[pos++] = cand[i];
     const long long K = Ku;
     const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
     __syncthreads();   // newSurfels complete (same workgroup), s_upd complete
@@ -1068,7 +1108,7 @@ __global__ void k_debug_div100(const float *x, double *out, long long n) {
 enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_COMMIT_SEEDS, SK_SEED_PLANE, SK_FUSE, SK_NEW, SK_COMPACT,
        SK_CONVERT, SK_COPY };
 const char *kSfNames[MSL_SF_NKERNELS] = {"kb_seed_init", "kb_assign", "kb_prop", "kb_commit_px", "kb_update_seeds", "kb_commit_seeds",
-                                         "kb_seed_plane", "k_fuse", "k_new_scan", "k_compact", "k_convert", "copy"};
+                                         "kb_seed_plane", "k_fuse", "(unused)", "k_compact", "k_convert", "copy"};
 
 }  // namespace
 
@@ -1085,7 +1125,7 @@ struct msl_sf {
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
     msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
-    double *d_invDepth = nullptr;
+    double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
     // staged images (host input mode), per slot
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
@@ -1120,10 +1160,10 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
-    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));   // >= 1024 entries: k_new_scan reads its first tile unconditionally
-    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
-    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
-    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 1026)));
+    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));   // >= 1024 entries: k_new_scan reads its first tile unconditionally
+    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
     MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
     if (keep && h->d_mapStore) {
@@ -1143,7 +1183,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_gray); F(h->d_depth); F(h->d_member);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
     h->grayCap = h->depthCap = h->memberCap = 0;
 }
@@ -1163,6 +1203,9 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_invDepth, sizeof(double) * ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_wl, sizeof(unsigned) * npx * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_wlCount, sizeof(unsigned) * slots));
+    MSL_HIP_TRY(hipMemset(h->d_wlCount, 0, sizeof(unsigned) * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_chunkAbort, sizeof(int) * 32 * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
@@ -1171,7 +1214,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
-    D.invDepth = h->d_invDepth;
+    D.invDepth = h->d_invDepth; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
     h->maxBatch = maxBatch;
     h->evMapValid[0] = h->evMapValid[1] = false;
     h->evCopyValid[0] = h->evCopyValid[1] = false;
@@ -1264,7 +1307,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
-    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds;
+    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 seedGrid((D.nseeds + 255) / 256, un);
@@ -1274,7 +1317,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
         if (it > 0) {
             h->prof.begin(SK_PROP, sp);
-            for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, flatPx, dim3(256), 0, sp, P, r, n);
+            for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, dim3(xcd_grid(PROP_BLOCKS, n)), dim3(256), 0, sp, P, r, n);
             hipLaunchKernelGGL(kb_prop_finish, dim3(un), dim3(1024), 0, sp, P);
             h->prof.end(sp);
             LAUNCH(SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
@@ -1289,7 +1332,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     }
     for (int f = 0; f < n; f++) {
         LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f);
-        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 256 : 1), dim3(1024), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
+        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     MSL_HIP_TRY(hipGetLastError());
