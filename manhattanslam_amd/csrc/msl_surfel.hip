@@ -161,14 +161,19 @@ __device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
     for (; p < n; p++) s += a[p];
     return s;
 }
-// s = (float)((double)s + t[e]) for e = 0..n-1 (float accumulator, double terms)
-__device__ __forceinline__ float seq_sum_f32_dterms(const double *t, int n, float s) {
+// Huber/Newton numerator (:494-503) in list order: finite terms are 2*residual (a float add; identical to the double
+// add rounded to float), +-inf marks a tail element whose contribution is the DOUBLE constant +-HUBER_RANGE.
+__device__ __forceinline__ float huber_term_add(float s, float t) {
+    return __builtin_isinf(t) ? (float)((double)s + (t > 0 ? HUBER_RANGE : -1 * HUBER_RANGE)) : s + t;
+}
+__device__ __forceinline__ float seq_sum_huber(const float *t, int n, float s) {
     int e = 0;
-    for (; e + 4 <= n; e += 4) {
-        const double2 u = *reinterpret_cast<const double2 *>(t + e), v = *reinterpret_cast<const double2 *>(t + e + 2);
-        s = (float)((double)s + u.x); s = (float)((double)s + u.y); s = (float)((double)s + v.x); s = (float)((double)s + v.y);
+    for (; e + 8 <= n; e += 8) {
+        const float4 u = *reinterpret_cast<const float4 *>(t + e), v = *reinterpret_cast<const float4 *>(t + e + 4);
+        s = huber_term_add(s, u.x); s = huber_term_add(s, u.y); s = huber_term_add(s, u.z); s = huber_term_add(s, u.w);
+        s = huber_term_add(s, v.x); s = huber_term_add(s, v.y); s = huber_term_add(s, v.z); s = huber_term_add(s, v.w);
     }
-    for (; e < n; e++) s = (float)((double)s + t[e]);
+    for (; e < n; e++) s = huber_term_add(s, t[e]);
     return s;
 }
 
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
 // raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     __shared__ __attribute__((aligned(16))) float s_depth[16][256];
-    __shared__ __attribute__((aligned(16))) double s_term[16][256];
+    __shared__ __attribute__((aligned(16))) float s_term[16][256];   // in-range: 2*residual; Huber tails: +-inf markers
     __shared__ float s_mean[16];
     __shared__ int s_cnt[16], s_done[16];
     int slot, blk;
@@ -471,13 +476,13 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         int inr = 0;
         for (int e = l; e < nd; e += 16) {
             const float residual = meanDepth - s_depth[g][e];
-            if (residual < HUBER_RANGE && residual > -HUBER_RANGE) { s_term[g][e] = (double)(2 * residual); inr++; }
-            else s_term[g][e] = residual > 0 ? HUBER_RANGE : -1 * HUBER_RANGE;
+            if (residual < HUBER_RANGE && residual > -HUBER_RANGE) { s_term[g][e] = 2 * residual; inr++; }
+            else s_term[g][e] = residual > 0 ? __builtin_inff() : -__builtin_inff();
         }
         if (inr) atomicAdd(&s_cnt[g], inr);
         __builtin_amdgcn_wave_barrier();
         if (l == 0) {
-            const float sumA = seq_sum_f32_dterms(s_term[g], nd, 0.0f);   // == float add for the in-range terms
+            const float sumA = seq_sum_huber(s_term[g], nd, 0.0f);
             const float sumB = (float)(2 * s_cnt[g]);
             const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
             const float m = meanDepth + deltaDepth;
@@ -830,11 +835,10 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 //   Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed,
 //   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
-struct FuseSurv { unsigned i; int pix; float pcz, x, y, z; int ut; };
 
 __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     __shared__ unsigned s_cnt[3];
-    __shared__ FuseSurv s_surv[SCAN_ITEMS];
+    __shared__ unsigned short s_surv[SCAN_ITEMS];   // 2 KB: keeps the kernel co-resident with the LDS-heavy batched kernels
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const MapSoA &M = P.map;
@@ -872,20 +876,21 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
                 const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;  // :75-78
                 const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
                 if (pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2) continue;
-                FuseSurv e;
-                e.i = (unsigned)(i - c0); e.pix = pVInt * P.W + pUInt; e.pcz = pc[2]; e.x = x; e.y = y; e.z = z; e.ut = ut;
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = e;
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned short)(i - c0);
             }
         }
         __syncthreads();
         const unsigned nsurv = s_cnt[2];
         for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
-            const FuseSurv e = s_surv[sidx];
-            const long long i = c0 + e.i;
-            const float pz = e.pcz;
-            const int row = e.pix / P.W, col = e.pix - row * P.W;
-            const float dep = F.depth[(size_t)row * P.dstride + col];
-            const int spIndex = index[e.pix];
+            const long long i = c0 + s_surv[sidx];
+            const HotRec hr = M.hot[i];                      // just streamed by this workgroup: cache hit
+            float pc[4];
+            mul4(F.invPose, hr.px, hr.py, hr.pz, 1.0f, pc);  // same expressions as phase A -> same pixel
+            const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;
+            const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
+            const float pz = pc[2];
+            const float dep = F.depth[(size_t)pVInt * P.dstride + pUInt];
+            const int spIndex = index[pVInt * P.W + pUInt];
             if ((double)pz < (double)dep - 1.0) { M.hot[i].updateTimes = 0; ndel++; continue; }
             const msl_seed S = seeds[spIndex];
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
@@ -899,7 +904,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
             if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; ndel++; continue; }
-            const float Lpx = e.x, Lpy = e.y, Lpz = e.z;
+            const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
             const float sumWeight = oldWeight + newWeight;
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             float newNormW[3];
             mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
             HotRec Hn;
-            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = e.ut + 1; Hn.lastUpdate = ref;
+            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = hr.updateTimes + 1; Hn.lastUpdate = ref;
             C.r = S.r; C.g = S.g; C.b = S.b;
             C.nx = newNormW[0]; C.ny = newNormW[1]; C.nz = newNormW[2];
             C.weight = sumWeight;
