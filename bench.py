@@ -194,6 +194,7 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": int(SURFEL_BYTES * n_live_avg), "avg_launch_us": round(fuse_s * 1e6, 2),
+                     "timer": "HIP events carried by the k_fuse dispatch (hipExtLaunchKernelGGL) on the map stream, timed region",
                      "launches": int(fuse_launches)},
         "counters_per_rank": gathered,
     }
@@ -222,6 +223,22 @@ def main():
             frame_no[0] += F
         sf.sync()
         out["surfel_only_keyframes_per_sec"] = round(4 * F / (time.perf_counter() - t0), 1)
+
+    if not args.no_breakdown:
+        # the same kernel without co-running work: put the whole surfel pipeline on ONE stream (no overlap with the batched
+        # superpixel stage or ORB) and time k_fuse again.  Reported next to, never instead of, the in-region roofline.
+        sf.set_stream(torch.cuda.current_stream().cuda_stream)
+        sf.profile_enable(1 << K_FUSE)
+        for _ in range(2):
+            sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True, member_shared=True)
+            frame_no[0] += F
+        ms_iso, n_iso = sf.profile_read()["k_fuse"]
+        sf.profile_enable(0)
+        n_now = sf.counters()["n_live_after"]
+        iso = SURFEL_BYTES * n_now / (ms_iso * 1e-3 / max(n_iso, 1)) / 1e9
+        out["roofline_isolated"] = {"kernel": "k_fuse", "achieved": round(iso, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(iso / HBM_PEAK_GBS, 4), "avg_launch_us": round(ms_iso * 1e3 / max(n_iso, 1), 2),
+                                    "note": "single stream, no co-running kernels; HIP events carried by the dispatch"}
 
     if args.cpu_frames > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(grays, depths, member, poses, smap, args.cpu_frames)

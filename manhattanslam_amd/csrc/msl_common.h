@@ -41,6 +41,9 @@ struct KernelProfiler {
     int npairs = 0, cap = 0;
     void begin(int k, hipStream_t s);
     void end(hipStream_t s);
+    // For single-kernel timing without extra stream packets: returns an event pair to hand to hipExtLaunchKernelGGL
+    // (the events then carry the dispatch's own start/end timestamps), or false when kernel k is not being timed.
+    bool kernel_pair(int k, hipEvent_t *a, hipEvent_t *b);
     void drain();  // requires the stream to be idle
     void set_mode(int m) { on = m != 0; mask = (unsigned)m; for (int i = 0; i < 16; i++) { ms[i] = 0; launches[i] = 0; } }
     void destroy();

@@ -51,6 +51,20 @@ void KernelProfiler::end(hipStream_t s) {
     (void)hipEventRecord(pairs[npairs].b, s);
     npairs++;
 }
+bool KernelProfiler::kernel_pair(int k, hipEvent_t *a, hipEvent_t *b) {
+    if (!on || !((mask >> k) & 1u)) return false;
+    if (npairs == cap) {
+        int ncap = cap ? cap * 2 : 256;
+        Pair *np = (Pair *)realloc(pairs, sizeof(Pair) * ncap);
+        if (!np) return false;
+        for (int i = cap; i < ncap; i++) { (void)hipEventCreate(&np[i].a); (void)hipEventCreate(&np[i].b); }
+        pairs = np; cap = ncap;
+    }
+    pairs[npairs].k = k;
+    *a = pairs[npairs].a; *b = pairs[npairs].b;
+    npairs++;
+    return true;
+}
 void KernelProfiler::drain() {
     for (int i = 0; i < npairs; i++) {
         float t = 0;

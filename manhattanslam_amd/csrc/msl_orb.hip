@@ -895,7 +895,9 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
             ++v0;
         }
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    int prLo = 0, prHi = 0;   // frame-batched throughput work: lowest priority, so latency-critical streams of the process go first
+    (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
+    if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prLo) != hipSuccess ||
         hipMalloc(&h->d_err, sizeof(int)) != hipSuccess || hipMemset(h->d_err, 0, sizeof(int)) != hipSuccess ||
         hipHostMalloc(&h->h_err, sizeof(int)) != hipSuccess) {
         set_error("msl_orb_create: HIP resource allocation failed");

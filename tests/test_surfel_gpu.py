@@ -186,6 +186,25 @@ def test_compaction_matches_literal_loop(oracle):
     g.close()
 
 
+def test_1280x960_sequence(oracle):
+    """Config-5 frame size: 19 200 superpixels, three keyframes on the resident map."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    intr = {k: v * 2 for k, v in synth.TUM1.items()}
+    g, o = _mk(intr, 1280, 960)
+    m = synth.surfel_map(60000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(200000)
+    g.map_upload(m)
+    o.map_set(m)
+    for k in range(3):
+        gray, depth, member, pose = synth.surfel_frame(k, 1280, 960, intr=intr, variant="B" if k == 1 else "A")
+        g.fuse_resident(k, gray, depth, member, pose)
+        o.fuse_map(k, gray, depth, member, pose)
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(g.map_download(), o.map_get(), "1280x960 map")
+    g.close()
+
+
 def test_div100_exact():
     """The division-free x/100.0 used by the cost kernel is the correctly rounded quotient (bit-exact vs IEEE divide)."""
     from manhattanslam_amd import lib
