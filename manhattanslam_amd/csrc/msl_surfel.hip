@@ -967,14 +967,18 @@ constexpr int TAIL_MAX_HOPS = 64;
 //   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
 //                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
 // mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
+constexpr int SMALL_D = 2048, SMALL_CHUNKS = 48;   // fast path: few deletions in few chunks (the steady state)
+
 __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     constexpr int NT = 256, TILE = 4 * NT;      // 256-thread workgroups find a free CU quickly next to the batched kernels
     __shared__ unsigned s_wave[17];
     __shared__ unsigned s_ex[TILE];
-    __shared__ unsigned s_last, s_upd;
+    __shared__ unsigned s_dl[SMALL_D];          // fast path: the deleted-slot list stays in LDS
+    __shared__ unsigned s_last, s_upd, s_nzChunks;
+    __shared__ unsigned short s_nzList[SMALL_CHUNKS];   // fast path: the chunks that contain deletions
     __shared__ int s_fallback;
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
-    // the continuation needs, so the last workgroup does not start its dependent chain with a cold memory round trip.
+    // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
     const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
@@ -998,9 +1002,12 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const bool bad = P.ctr[5] == 20;
-    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; }
-    // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread); own chunks of a tile are listed right away ----
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
+    __syncthreads();
+    // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread) ----
+    const bool oneTile = nblk <= TILE;
     unsigned carry = 0;
+    bool small = false;
     for (long long t0 = 0; t0 < nblk; t0 += TILE) {
         const long long c = t0 + 4 * threadIdx.x;
         const uint4 v4 = *reinterpret_cast<const uint4 *>(P.blockSums + c);   // the array is padded by >= 1024 zeroed entries
@@ -1009,9 +1016,19 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
 #pragma unroll
         for (int j = 0; j < 4; j++) { s_ex[4 * threadIdx.x + j] = ex; ex += v[j]; }
+        if (oneTile)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (v[j] > 0) { const unsigned q = atomicAdd(&s_nzChunks, 1u); if (q < SMALL_CHUNKS) s_nzList[q] = (unsigned short)(4 * threadIdx.x + j); }
         __syncthreads();
-        if (mode == 0 && !bad)
-            for (long long b = t0 + blockIdx.x; b < min(t0 + TILE, nblk); b += gridDim.x) {
+        // Fast path (steady state: a handful of deletions in a handful of chunks): workgroup 0 does everything alone -- no
+        // ticket, no write-through list -- and the other workgroups leave at once.
+        small = mode == 0 && oneTile && tot <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
+        if (small && blockIdx.x != 0) return;
+        if (mode == 0 && !bad) {
+            const long long nIter = small ? (long long)s_nzChunks : (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
+            for (long long it = 0; it < nIter; it++) {
+                const long long b = small ? t0 + s_nzList[it] : t0 + blockIdx.x + it * gridDim.x;
                 const unsigned base = s_ex[b - t0];
                 const unsigned next = (b - t0 + 1 < TILE && b + 1 < nblk) ? s_ex[b - t0 + 1] : carry + tot;
                 if (next == base) continue;   // nothing deleted in this chunk
@@ -1022,13 +1039,15 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                 unsigned tt;
                 unsigned pos = base + block_excl_scan(c4, s_wave, &tt);
 #pragma unroll
-                for (int j = 0; j < 4; j++) if (f[j]) st_agent(&P.delList[pos++], (unsigned)(i0 + j));
+                for (int j = 0; j < 4; j++)
+                    if (f[j]) { if (small) s_dl[pos++] = (unsigned)(i0 + j); else st_agent(&P.delList[pos++], (unsigned)(i0 + j)); }
             }
+        }
         carry += tot;
         __syncthreads();
     }
     const long long D = carry;
-    if (mode == 0 && !last_workgroup(&P.tickets[1], &s_last)) return;
+    if (mode == 0 && !small && !last_workgroup(&P.tickets[1], &s_last)) return;
     // ================= continuation: one workgroup =================
     // updated count
     for (long long c = threadIdx.x; c < nblk; c += blockDim.x) { const unsigned u = P.blockUpd[c]; if (u) atomicAdd(&s_upd, u); }
@@ -1047,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
     }
     if (mode == 1 || bad || (unsigned long long)nAfter > P.cap) return;
-    auto DL = [&](long long j) -> unsigned { return ld_agent(&P.delList[j]); };
+    auto DL = [&](long long j) -> unsigned { return small ? s_dl[j] : ld_agent(&P.delList[j]); };
     const long long t0 = threadIdx.x, stride = blockDim.x;
     // new surfel k -> k-th largest deleted slot while any remain, else appended (SurfelMapping.cpp:372-384)
     for (long long k = t0; k < K; k += stride) {
