@@ -43,6 +43,7 @@ constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE_D = 0.5, DISPA
 constexpr unsigned T_INF = 0xFFFFFFFFu;
 constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
+constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup chunk in the map-stage kernels
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
@@ -85,6 +86,8 @@ struct SfDev {
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
     unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
+    unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
+    unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -839,8 +842,10 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
 __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
-    __shared__ unsigned s_cnt[3];
+    __shared__ unsigned s_cnt[4];
     __shared__ unsigned short s_surv[SCAN_ITEMS];   // 2 KB: keeps the kernel co-resident with the LDS-heavy batched kernels
+    __shared__ unsigned short s_del[SCAN_ITEMS];    // local indices of the chunk's deleted slots
+    __shared__ unsigned s_delBase;
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const MapSoA &M = P.map;
@@ -852,10 +857,11 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     static_assert(SCAN_ITEMS == 1024, "4 consecutive surfels per thread x 256 threads");
     for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
-        if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
         __syncthreads();
-        unsigned ndel = 0, nupd = 0;
+        unsigned nupd = 0;
         const long long c0 = b * SCAN_ITEMS;
+        auto mark_deleted = [&](long long i) { s_del[atomicAdd(&s_cnt[0], 1u)] = (unsigned short)(i - c0); };
         const long long i0 = c0 + 4 * threadIdx.x;     // map capacity is a multiple of 4096: the 16-byte loads stay in bounds
         {
             const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
@@ -870,8 +876,8 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
                 if (i >= n) continue;
                 const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
                 const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
-                if (ref - lu > 5 && ut < 5) { if (ut != 0) M.hot[i].updateTimes = 0; ndel++; continue; }
-                if (ut == 0) { ndel++; continue; }
+                if (ref - lu > 5 && ut < 5) { if (ut != 0) M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
+                if (ut == 0) { mark_deleted(i); continue; }
                 float pc[4];
                 mul4(F.invPose, x, y, z, 1.0f, pc);
                 if (pc[2] < P.fuseNear || pc[2] > P.fuseFar) continue;
@@ -893,7 +899,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             const float pz = pc[2];
             const float dep = F.depth[(size_t)pVInt * P.dstride + pUInt];
             const int spIndex = index[pVInt * P.W + pUInt];
-            if ((double)pz < (double)dep - 1.0) { M.hot[i].updateTimes = 0; ndel++; continue; }
+            if ((double)pz < (double)dep - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
             const msl_seed S = seeds[spIndex];
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
@@ -905,7 +911,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             float nc[3];
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; ndel++; continue; }
+            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
             const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
@@ -936,10 +942,19 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             fused[spIndex] = 1;
             nupd++;
         }
-        if (ndel) atomicAdd(&s_cnt[0], ndel);
         if (nupd) atomicAdd(&s_cnt[1], nupd);
         __syncthreads();
-        if (threadIdx.x == 0) { P.blockSums[b] = s_cnt[0]; P.blockUpd[b] = s_cnt[1]; }
+        const unsigned ndelBlk = s_cnt[0];
+        if (threadIdx.x == 0) {
+            P.blockSums[b] = ndelBlk; P.blockUpd[b] = s_cnt[1];
+            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per chunk that deleted something
+        }
+        __syncthreads();
+        if (ndelBlk) {
+            const unsigned base = s_delBase;
+            for (unsigned j = threadIdx.x; j < ndelBlk; j += 256)
+                if (base + j < LIST_D) P.delU[base + j] = (unsigned)(c0 + s_del[j]);
+        }
         __syncthreads();
     }
 }
@@ -979,6 +994,10 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     __shared__ int s_fallback;
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
+    const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
+    const uint4 bu0 = *reinterpret_cast<const uint4 *>(P.blockUpd + 4 * threadIdx.x);    // (arrays are padded by >= 1024 zeroed entries)
+    const long long n = P.ctr[0];
+    const bool bad = P.ctr[5] == 20;
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
     const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
@@ -999,9 +1018,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
         }
     }
-    const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    const bool bad = P.ctr[5] == 20;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
     // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread) ----
@@ -1010,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     bool small = false;
     for (long long t0 = 0; t0 < nblk; t0 += TILE) {
         const long long c = t0 + 4 * threadIdx.x;
-        const uint4 v4 = *reinterpret_cast<const uint4 *>(P.blockSums + c);   // the array is padded by >= 1024 zeroed entries
+        const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
         const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
         unsigned tot;
         unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
@@ -1025,6 +1042,18 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         // ticket, no write-through list -- and the other workgroups leave at once.
         small = mode == 0 && oneTile && tot <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
         if (small && blockIdx.x != 0) return;
+        if (small && tot <= LIST_D && !bad) {
+            // fastest path: k_fuse already handed over the (few) deleted slots, unordered; rank-sort them in LDS
+            for (unsigned e = threadIdx.x; e < tot; e += NT) {
+                const unsigned ve = P.delU[e];
+                unsigned r = 0;
+                for (unsigned j = 0; j < tot; j++) r += P.delU[j] < ve ? 1u : 0u;
+                s_dl[r] = ve;
+            }
+            carry += tot;
+            __syncthreads();
+            continue;
+        }
         if (mode == 0 && !bad) {
             const long long nIter = small ? (long long)s_nzChunks : (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
             for (long long it = 0; it < nIter; it++) {
@@ -1050,29 +1079,36 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     if (mode == 0 && !small && !last_workgroup(&P.tickets[1], &s_last)) return;
     // ================= continuation: one workgroup =================
     // updated count
-    for (long long c = threadIdx.x; c < nblk; c += blockDim.x) { const unsigned u = P.blockUpd[c]; if (u) atomicAdd(&s_upd, u); }
+    {
+        const long long c = 4 * threadIdx.x;
+        unsigned u = (c < nblk ? bu0.x : 0u) + (c + 1 < nblk ? bu0.y : 0u) + (c + 2 < nblk ? bu0.z : 0u) + (c + 3 < nblk ? bu0.w : 0u);
+        for (long long c2 = TILE + threadIdx.x; c2 < nblk; c2 += blockDim.x) u += P.blockUpd[c2];
+        if (u) atomicAdd(&s_upd, u);
+    }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
     const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
     unsigned Ku;
     unsigned pos = block_excl_scan(cnt, s_wave, &Ku);
-    if (cnt)
-        for (int i = s0; i < s1; i++)
-            if ((i - s0 < 64) ? ((emit >> (i - s0)) & 1ull) : (candOk[i] && !fused[i])) P.newSurfels[pos++] = cand[i];
     const long long K = Ku;
     const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
-    __syncthreads();   // newSurfels complete (same workgroup), s_upd complete
+    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
+    auto DL = [&](long long j) -> unsigned { return small ? s_dl[j] : ld_agent(&P.delList[j]); };
+    if (cnt)
+        for (int i = s0; i < s1; i++)
+            if ((i - s0 < 64) ? ((emit >> (i - s0)) & 1ull) : (candOk[i] && !fused[i])) {
+                const msl_surfel e = cand[i];
+                const long long k = pos++;
+                P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
+                if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
+                    store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
+            }
+    __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
     if (threadIdx.x == 0) {
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
     }
-    if (mode == 1 || bad || (unsigned long long)nAfter > P.cap) return;
-    auto DL = [&](long long j) -> unsigned { return small ? s_dl[j] : ld_agent(&P.delList[j]); };
+    if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }
     const long long t0 = threadIdx.x, stride = blockDim.x;
-    // new surfel k -> k-th largest deleted slot while any remain, else appended (SurfelMapping.cpp:372-384)
-    for (long long k = t0; k < K; k += stride) {
-        const long long dst = k < D ? (long long)DL(D - 1 - k) : n + (k - D);
-        store_surfel(P.map, dst, P.newSurfels[k]);
-    }
     if (D > K) {
         const long long R = D - K, nFinal = n - R;
         auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
@@ -1103,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
         }
     }
-    if (threadIdx.x == 0) P.ctr[0] = nAfter;   // publish the new live count
+    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
 }
 
 // AoS <-> SoA conversion for upload / download / host-vector mode
@@ -1122,8 +1158,8 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
     dst[i] = e;
 }
-__global__ void k_set_ctr(long long *ctr, long long n) {
-    if (threadIdx.x == 0) { ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
+__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
+    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
 }
 
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
@@ -1156,7 +1192,7 @@ struct msl_sf {
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
-    unsigned *d_tickets = nullptr;
+    unsigned *d_tickets = nullptr, *d_delU = nullptr;
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
@@ -1403,9 +1439,10 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 8);
-    D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets;
+    D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
     return h;
@@ -1419,7 +1456,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
@@ -1488,7 +1525,7 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
         MSL_HIP_TRY(hipMemcpyAsync(h->d_aos, host, sizeof(msl_surfel) * n, hipMemcpyHostToDevice, s));
         LAUNCH(SK_CONVERT, s, k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), h->dev.map, h->d_aos, (long long)n);
     }
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipStreamSynchronize(s));
     return MSL_OK;
 }
