@@ -55,6 +55,21 @@ def build_inputs(rank, F, n_surfels):
     return np.stack(grays), np.stack(depths), member, poses, smap
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            e = json.load(open(f)).get(kernel)
+        except Exception:
+            continue
+        if e and "fetch_bytes_corrected" in e and "write_bytes" in e:
+            best = (e["fetch_bytes_corrected"] + e["write_bytes"], os.path.basename(f))
+    return best
+
+
 def aggregate(local_ms, counters, world, device=None):
     """max-over-ranks of the timed region + all_gather of the per-sequence counters (RCCL on GPU, gloo on CPU)."""
     import torch
@@ -192,7 +207,8 @@ def main():
                    "frames_per_step": F, "seeded_surfels": args.surfels, "n_live_surfels": int(n_live_avg),
                    "intrinsics": "TUM1", "sequences_per_gpu": 1},
         "roofline": {"bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic("k_fuse") or (None, None))[0],
+                     "traffic_source": (pmc_traffic("k_fuse") or (None, "no committed PMC summary"))[1],
                      "algorithmic_bytes_per_launch": int(SURFEL_BYTES * n_live_avg), "avg_launch_us": round(fuse_s * 1e6, 2),
                      "timer": "HIP events carried by the k_fuse dispatch (hipExtLaunchKernelGGL) on the map stream, timed region",
                      "launches": int(fuse_launches)},
