@@ -60,7 +60,7 @@ def pmc_traffic(kernel):
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime):
         try:
             e = json.load(open(f)).get(kernel)
         except Exception:
