@@ -124,6 +124,28 @@ MSL_API int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames,
                                   int height, size_t row_stride, size_t frame_stride,
                                   msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
                                   int32_t *n_out, msl_mem out_mem);
+/* ---- widening, SURVEY.md 8(f) rank 1: the Frame steps that consume the ORB output right after the join
+ * (src/Frame.cc:107-153): UndistortKeyPoints (:437-463), ComputeStereoFromRGBD (:495-513), AssignFeaturesToGrid
+ * (:155-168, PosInGrid :418-427), fused behind the extraction so the keypoints never leave HBM in between. ---- */
+typedef struct msl_frame_params {
+    float fx, fy, cx, cy;          /* mK (CV_32F) */
+    float k1, k2, p1, p2, k3;      /* mDistCoef; k1 == 0 => mvKeysUn = mvKeys (src/Frame.cc:438-441) */
+    float bf;                      /* mbf */
+    float minX, maxX, minY, maxY;  /* mnMinX.. (ComputeImageBounds, src/Frame.cc:465-494): see msl_frame_image_bounds */
+} msl_frame_params;
+#define MSL_FRAME_GRID_ROWS 48     /* include/Frame.h:53-54 */
+#define MSL_FRAME_GRID_COLS 64
+/* ComputeImageBounds: fills minX..maxY from fx..k3 and the image size (host arithmetic only). */
+MSL_API int msl_frame_image_bounds(msl_frame_params *p, int width, int height);
+/* msl_orb_extract_batch plus, per keypoint i of frame f (outputs at index f*cap + i, same memory space as kps):
+ *   kps_un_xy[2i..2i+1] = mvKeysUn[i].pt      depth_out[i] = mvDepth[i] (-1 if the depth pixel is <= 0)
+ *   uright_out[i] = mvuRight[i]               grid_cell[i] = posX * 48 + posY of mGrid[posX][posY], or -1 (PosInGrid false)
+ * depth: CV_32FC1 metres (imDepthScaled), strides in bytes. */
+MSL_API int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *depth, int n_frames, int width, int height,
+                                        size_t gray_row_stride, size_t gray_frame_stride, size_t depth_row_stride,
+                                        size_t depth_frame_stride, msl_mem in_mem, const msl_frame_params *params,
+                                        msl_keypoint *kps, uint8_t *desc32, float *kps_un_xy, float *depth_out, float *uright_out,
+                                        int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem);
 MSL_API int msl_orb_sync(msl_orb *h);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
 MSL_API int msl_orb_set_stream(msl_orb *h, void *hip_stream);

@@ -6,5 +6,5 @@ entry classes, used by the tests and ``bench.py``.  There is no CPU fallback: im
 compute classes without the built library, or constructing them without an MI355X, raises.
 """
 from ._lib import lib, MslError, KEYPOINT_DTYPE, SURFEL_DTYPE, SEED_DTYPE, device_count  # noqa: F401
-from .orb import ORBextractor  # noqa: F401
+from .orb import ORBextractor, frame_params  # noqa: F401
 from .surfel import SurfelFusion, SurfelMap  # noqa: F401

@@ -22,6 +22,7 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
                        ("viewCos", "<f4"), ("meanDepth", "<f4"), ("meanIntensity", "<f4"), ("r", "<i4"),
                        ("g", "<i4"), ("b", "<i4"), ("fused", "u1"), ("stable", "u1"), ("use", "u1"),
                        ("_pad", "u1")])
+FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
 assert KEYPOINT_DTYPE.itemsize == 28 and SURFEL_DTYPE.itemsize == 56 and SEED_DTYPE.itemsize == 64
 
 MSL_MEM_HOST, MSL_MEM_DEVICE = 0, 1
@@ -40,6 +41,8 @@ SIGNATURES = {
     "msl_orb_levels": (_i, [_vp]),
     "msl_orb_extract": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _i, _vp]),
     "msl_orb_extract_batch": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _vp, _vp, _i, _vp, _i]),
+    "msl_frame_image_bounds": (_i, [_vp, _i, _i]),
+    "msl_orb_extract_frame_batch": (_i, [_vp, _vp, _vp, _i, _i, _i, _sz, _sz, _sz, _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i]),
     "msl_orb_sync": (_i, [_vp]),
     "msl_orb_set_stream": (_i, [_vp, _vp]),
     "msl_orb_debug_level_size": (_i, [_vp, _i, _vp, _vp]),

@@ -65,6 +65,11 @@ struct OrbDev {
     uint16_t *knode;
     uint32_t *sel; int *nsel, *ncand;
     msl_keypoint *kps; uint8_t *desc; int *nout; int *err;
+    // Frame post-ORB epilogue; frameOn == 0: plain extractor
+    int frameOn;
+    msl_frame_params fp; float gridWInv, gridHInv;
+    const float *depth; unsigned long long depthRowStride, depthFrameStride;   // bytes
+    float *unXY, *depthOut, *uRight; int *gridCell;
 };
 
 __constant__ int8_t c_pattern[1024] = {
@@ -556,6 +561,29 @@ __device__ __forceinline__ void sincos_pinned(float angle, float *s_out, float *
     *c_out = (float)c;
 }
 
+// cv::undistortPoints(K, dist, P = K) for one point, OpenCV 3.x cvUndistortPoints plain C path (double arithmetic, 5
+// fixed-point iterations); src/Frame.cc:437-463.  The zero terms of the 12-coefficient model are kept so that the
+// operation order is the library's.
+__device__ __forceinline__ void undistort_point(const msl_frame_params &p, float xin, float yin, float *xo, float *yo) {
+    const double fx = p.fx, fy = p.fy, cx = p.cx, cy = p.cy, ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = p.k1, k1 = p.k2, k2 = p.p1, k3 = p.p2, k4 = p.k3, kz = 0.0;
+    double x = xin, y = yin;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((kz * r2 + kz) * r2 + kz) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + kz * r2 + kz * r2 * r2;
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + kz * r2 + kz * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    *xo = (float)(xx * ww);
+    *yo = (float)(yy * ww);
+}
+
 __global__ __launch_bounds__(256) void k_describe(OrbDev P) {
     const int frame = blockIdx.z, level = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -625,6 +653,19 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P) {
         if (level != 0) { fx *= D.scale; fy *= D.scale; }  // :861-866
         kp->x = fx; kp->y = fy; kp->size = (float)D.patch; kp->angle = angle;
         kp->response = (float)score; kp->octave = level; kp->class_id = -1;
+        if (P.frameOn) {
+            // UndistortKeyPoints (src/Frame.cc:437-463), ComputeStereoFromRGBD (:495-513), PosInGrid (:418-427)
+            const size_t o = (size_t)frame * P.outCap + outIdx;
+            float ux = fx, uy = fy;
+            if (P.fp.k1 != 0.0) undistort_point(P.fp, fx, fy, &ux, &uy);
+            P.unXY[2 * o] = ux; P.unXY[2 * o + 1] = uy;
+            const float d = *(const float *)((const uint8_t *)P.depth + (size_t)frame * P.depthFrameStride + (size_t)(int)fy * P.depthRowStride +
+                                             sizeof(float) * (size_t)(int)fx);
+            P.depthOut[o] = d > 0 ? d : -1.0f;
+            P.uRight[o] = d > 0 ? ux - P.fp.bf / d : -1.0f;
+            const int posX = (int)roundf((ux - P.fp.minX) * P.gridWInv), posY = (int)roundf((uy - P.fp.minY) * P.gridHInv);
+            P.gridCell[o] = (posX < 0 || posX >= MSL_FRAME_GRID_COLS || posY < 0 || posY >= MSL_FRAME_GRID_ROWS) ? -1 : posX * MSL_FRAME_GRID_ROWS + posY;
+        }
     }
 }
 
@@ -660,6 +701,8 @@ struct msl_orb {
     uint32_t *d_sel = nullptr; int *d_nsel = nullptr, *d_ncand = nullptr;
     msl_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_nout = nullptr; int *d_err = nullptr;
     int *h_err = nullptr;  // pinned
+    float *d_depthIn = nullptr; size_t depthInCap = 0;     // staged depth frames (host input)
+    float *d_unXY = nullptr, *d_depthOut = nullptr, *d_uRight = nullptr; int *d_gridCell = nullptr; bool frameBufs = false;
     int lastFrames = 0;
     KernelProfiler prof;
 };
@@ -806,11 +849,24 @@ int build_geometry(msl_orb *h, int W, int H) {
 }
 
 // Launch the whole pipeline for n frames whose pixels are already on the device.
+struct FrameEpilogue {
+    msl_frame_params fp; const float *depth; size_t depthRowStride, depthFrameStride;
+    float *unXY, *depthOut, *uRight; int *gridCell;
+};
+
 int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t frameStride, int n,
-                    msl_keypoint *d_kps, uint8_t *d_desc, int *d_nout) {
+                    msl_keypoint *d_kps, uint8_t *d_desc, int *d_nout, const FrameEpilogue *ep = nullptr) {
     OrbDev P = h->dev;
     P.in = d_gray; P.inRowStride = rowStride; P.inFrameStride = frameStride;
     P.kps = d_kps; P.desc = d_desc; P.nout = d_nout;
+    P.frameOn = ep ? 1 : 0;
+    if (ep) {
+        P.fp = ep->fp;
+        P.gridWInv = (float)MSL_FRAME_GRID_COLS / (float)(ep->fp.maxX - ep->fp.minX);   // src/Frame.cc:137-138
+        P.gridHInv = (float)MSL_FRAME_GRID_ROWS / (float)(ep->fp.maxY - ep->fp.minY);
+        P.depth = ep->depth; P.depthRowStride = ep->depthRowStride; P.depthFrameStride = ep->depthFrameStride;
+        P.unXY = ep->unXY; P.depthOut = ep->depthOut; P.uRight = ep->uRight; P.gridCell = ep->gridCell;
+    }
     hipStream_t s = h->stream;
     const int L = h->nlevels;
     for (int l = 1; l < L; l++) {
@@ -917,6 +973,11 @@ void msl_orb_destroy(msl_orb *h) {
     free_geometry(h);
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->d_depthIn) (void)hipFree(h->d_depthIn);
+    if (h->d_unXY) (void)hipFree(h->d_unXY);
+    if (h->d_depthOut) (void)hipFree(h->d_depthOut);
+    if (h->d_uRight) (void)hipFree(h->d_uRight);
+    if (h->d_gridCell) (void)hipFree(h->d_gridCell);
     if (h->stream && h->ownStream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1006,6 +1067,102 @@ int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size
                                          cap, &n, MSL_MEM_HOST);
     *n_out = n;
     return rc;
+}
+
+// host twin of the device undistortion (same expression order), used by ComputeImageBounds only
+static void undistort_point_host(const msl_frame_params &p, float xin, float yin, float *xo, float *yo) {
+    const double fx = p.fx, fy = p.fy, cx = p.cx, cy = p.cy, ifx = 1. / fx, ify = 1. / fy;
+    const double k0 = p.k1, k1 = p.k2, k2 = p.p1, k3 = p.p2, k4 = p.k3, kz = 0.0;
+    double x = xin, y = yin;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((kz * r2 + kz) * r2 + kz) * r2) / (1 + ((k4 * r2 + k1) * r2 + k0) * r2);
+        const double deltaX = 2 * k2 * x * y + k3 * (r2 + 2 * x * x) + kz * r2 + kz * r2 * r2;
+        const double deltaY = k2 * (r2 + 2 * y * y) + 2 * k3 * x * y + kz * r2 + kz * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    *xo = (float)(xx * ww);
+    *yo = (float)(yy * ww);
+}
+
+int msl_frame_image_bounds(msl_frame_params *p, int width, int height) {   // ComputeImageBounds, src/Frame.cc:465-494
+    if (!p || width < 1 || height < 1 || p->fx == 0 || p->fy == 0) { set_error("msl_frame_image_bounds: invalid argument"); return MSL_ERR_INVALID; }
+    if (p->k1 != 0.0) {
+        const float c[4][2] = {{0.f, 0.f}, {(float)width, 0.f}, {0.f, (float)height}, {(float)width, (float)height}};
+        float u[4][2];
+        for (int i = 0; i < 4; i++) undistort_point_host(*p, c[i][0], c[i][1], &u[i][0], &u[i][1]);
+        p->minX = std::min(u[0][0], u[2][0]); p->maxX = std::max(u[1][0], u[3][0]);
+        p->minY = std::min(u[0][1], u[1][1]); p->maxY = std::max(u[2][1], u[3][1]);
+    } else {
+        p->minX = 0.0f; p->maxX = (float)width; p->minY = 0.0f; p->maxY = (float)height;
+    }
+    return MSL_OK;
+}
+
+int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *depth, int n_frames, int width, int height,
+                                size_t gray_row_stride, size_t gray_frame_stride, size_t depth_row_stride, size_t depth_frame_stride,
+                                msl_mem in_mem, const msl_frame_params *params, msl_keypoint *kps, uint8_t *desc32, float *kps_un_xy,
+                                float *depth_out, float *uright_out, int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem) {
+    if (!h || !gray || !depth || !params || !kps || !desc32 || !kps_un_xy || !depth_out || !uright_out || !grid_cell || !n_out ||
+        n_frames < 1 || n_frames > h->maxBatch || width < 1 || height < 1 || width > h->maxW || height > h->maxH ||
+        gray_row_stride < (size_t)width || depth_row_stride < (size_t)width * 4 || (depth_row_stride & 3) ||
+        !(params->maxX > params->minX) || !(params->maxY > params->minY) || params->fx == 0 || params->fy == 0) {
+        set_error("msl_orb_extract_frame_batch: invalid argument (call msl_frame_image_bounds first?)");
+        return MSL_ERR_INVALID;
+    }
+    const int outCap = h->nfeatures + 2 * h->nlevels;
+    if (cap < outCap) { set_error("msl_orb_extract_frame_batch: cap %d < required %d", cap, outCap); return MSL_ERR_CAPACITY; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = build_geometry(h, width, height);
+    if (rc != MSL_OK) return rc;
+    const size_t B = (size_t)h->maxBatch;
+    if (!h->frameBufs) {
+        MSL_HIP_TRY(hipMalloc(&h->d_unXY, sizeof(float) * 2 * outCap * B)); MSL_HIP_TRY(hipMalloc(&h->d_depthOut, sizeof(float) * outCap * B));
+        MSL_HIP_TRY(hipMalloc(&h->d_uRight, sizeof(float) * outCap * B)); MSL_HIP_TRY(hipMalloc(&h->d_gridCell, sizeof(int) * outCap * B));
+        h->frameBufs = true;
+    }
+    const uint8_t *d_gray = gray; size_t rs = gray_row_stride, fs = gray_frame_stride;
+    FrameEpilogue ep{};
+    ep.fp = *params; ep.depth = depth; ep.depthRowStride = depth_row_stride; ep.depthFrameStride = depth_frame_stride;
+    if (in_mem == MSL_MEM_HOST) {
+        const size_t dpitch = (size_t)width * 4, dframe = dpitch * height;
+        if (dframe * B > h->depthInCap) {
+            MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->d_depthIn) (void)hipFree(h->d_depthIn);
+            h->d_depthIn = nullptr; h->depthInCap = 0;
+            MSL_HIP_TRY(hipMalloc(&h->d_depthIn, dframe * B));
+            h->depthInCap = dframe * B;
+        }
+        for (int f = 0; f < n_frames; f++) {
+            MSL_HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * h->inPitch * height, h->inPitch, gray + (size_t)f * gray_frame_stride, gray_row_stride,
+                                         width, height, hipMemcpyHostToDevice, h->stream));
+            MSL_HIP_TRY(hipMemcpy2DAsync((uint8_t *)h->d_depthIn + (size_t)f * dframe, dpitch, (const uint8_t *)depth + (size_t)f * depth_frame_stride,
+                                         depth_row_stride, dpitch, height, hipMemcpyHostToDevice, h->stream));
+        }
+        d_gray = h->d_in; rs = h->inPitch; fs = h->inPitch * height;
+        ep.depth = h->d_depthIn; ep.depthRowStride = dpitch; ep.depthFrameStride = dframe;
+    }
+    const bool direct = out_mem == MSL_MEM_DEVICE && cap == outCap;
+    ep.unXY = direct ? kps_un_xy : h->d_unXY; ep.depthOut = direct ? depth_out : h->d_depthOut;
+    ep.uRight = direct ? uright_out : h->d_uRight; ep.gridCell = direct ? grid_cell : h->d_gridCell;
+    if (direct) return launch_pipeline(h, d_gray, rs, fs, n_frames, kps, desc32, n_out, &ep);
+    rc = launch_pipeline(h, d_gray, rs, fs, n_frames, h->d_kps, h->d_desc, h->d_nout, &ep);
+    if (rc != MSL_OK) return rc;
+    const hipMemcpyKind kind = out_mem == MSL_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    MSL_HIP_TRY(hipMemcpyAsync(n_out, h->d_nout, sizeof(int) * n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(kps, sizeof(msl_keypoint) * cap, h->d_kps, sizeof(msl_keypoint) * outCap, sizeof(msl_keypoint) * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(desc32, (size_t)32 * cap, h->d_desc, (size_t)32 * outCap, (size_t)32 * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(kps_un_xy, sizeof(float) * 2 * cap, h->d_unXY, sizeof(float) * 2 * outCap, sizeof(float) * 2 * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(depth_out, sizeof(float) * cap, h->d_depthOut, sizeof(float) * outCap, sizeof(float) * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(uright_out, sizeof(float) * cap, h->d_uRight, sizeof(float) * outCap, sizeof(float) * outCap, n_frames, kind, h->stream));
+    MSL_HIP_TRY(hipMemcpy2DAsync(grid_cell, sizeof(int) * cap, h->d_gridCell, sizeof(int) * outCap, sizeof(int) * outCap, n_frames, kind, h->stream));
+    if (out_mem == MSL_MEM_HOST) return check_device_error(h);
+    return MSL_OK;
 }
 
 int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out) {

@@ -3,7 +3,16 @@ import ctypes as C
 
 import numpy as np
 
-from ._lib import (KEYPOINT_DTYPE, MSL_MEM_DEVICE, MSL_MEM_HOST, MSL_ORB_NKERNELS, MslError, check, lib, ptr)
+from ._lib import (FRAME_PARAMS_DTYPE, KEYPOINT_DTYPE, MSL_MEM_DEVICE, MSL_MEM_HOST, MSL_ORB_NKERNELS, MslError, check, lib, ptr)
+
+
+def frame_params(fx, fy, cx, cy, bf, width, height, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+    """msl_frame_params with the image bounds of Frame::ComputeImageBounds filled in."""
+    p = np.zeros(1, FRAME_PARAMS_DTYPE)
+    for k, v in dict(fx=fx, fy=fy, cx=cx, cy=cy, k1=k1, k2=k2, p1=p1, p2=p2, k3=k3, bf=bf).items():
+        p[k] = v
+    check(lib.msl_frame_image_bounds(ptr(p), int(width), int(height)), "msl_frame_image_bounds")
+    return p
 
 
 class ORBextractor:
@@ -88,6 +97,21 @@ class ORBextractor:
         check(lib.msl_orb_extract_batch(self._h, ptr(images), b, w, h, w, w * h, MSL_MEM_HOST, ptr(kps), ptr(desc),
                                         self.capacity, ptr(n), MSL_MEM_HOST), "msl_orb_extract_batch")
         return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy()) for f in range(b)]
+
+    def extract_frames(self, images, depths, params):
+        """ORB + the Frame post-ORB steps (src/Frame.cc:107-153) for RGB-D frames: images (B,H,W) u8, depths (B,H,W) f32 metres.
+        Returns per frame (mvKeys, mDescriptors, mvKeysUn xy (N,2), mvDepth, mvuRight, grid cell id or -1)."""
+        images = np.ascontiguousarray(images); depths = np.ascontiguousarray(depths, np.float32)
+        b, h, w = images.shape
+        cap = self.capacity
+        kps = np.zeros((b, cap), KEYPOINT_DTYPE); desc = np.zeros((b, cap, 32), np.uint8)
+        un = np.zeros((b, cap, 2), np.float32); dep = np.zeros((b, cap), np.float32); ur = np.zeros((b, cap), np.float32)
+        cell = np.zeros((b, cap), np.int32); n = np.zeros(b, np.int32)
+        check(lib.msl_orb_extract_frame_batch(self._h, ptr(images), ptr(depths), b, w, h, w, w * h, 4 * w, 4 * w * h, MSL_MEM_HOST, ptr(params),
+                                              ptr(kps), ptr(desc), ptr(un), ptr(dep), ptr(ur), ptr(cell), cap, ptr(n), MSL_MEM_HOST),
+              "msl_orb_extract_frame_batch")
+        return [(kps[f, :n[f]].copy(), desc[f, :n[f]].copy(), un[f, :n[f]].copy(), dep[f, :n[f]].copy(), ur[f, :n[f]].copy(),
+                 cell[f, :n[f]].copy()) for f in range(b)]
 
     def extract_batch_device(self, d_images, d_kps, d_desc, d_n, n_frames, width, height):
         """Asynchronous, everything resident in HBM (torch tensors or raw pointers)."""

@@ -696,6 +696,61 @@ __attribute__((visibility("default"))) int mslo_orb_candidates(mslo_orb *h, int 
     return (int)c.size();
 }
 
+// ---- Frame post-ORB steps (src/Frame.cc:437-463, :495-513, :155-168, :418-427) ----------------
+// cv::undistortPoints(src, dst, K, distCoeffs, noArray(), P = K) follows OpenCV 3.x cvUndistortPoints (plain C path):
+// normalise with 1/fx (double), 5 fixed-point iterations of the radial/tangential model, re-project with P.
+static void undistort_point(const msl_frame_params &p, float xin, float yin, float *xo, float *yo) {
+    const double fx = p.fx, fy = p.fy, cx = p.cx, cy = p.cy, ifx = 1. / fx, ify = 1. / fy;
+    const double k[12] = {p.k1, p.k2, p.p1, p.p2, p.k3, 0, 0, 0, 0, 0, 0, 0};
+    double x = xin, y = yin;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        double r2 = x * x + y * y;
+        double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+        double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+        double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = fx * x + 0.0 * y + cx, yy = 0.0 * x + fy * y + cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    *xo = (float)(xx * ww);
+    *yo = (float)(yy * ww);
+}
+
+__attribute__((visibility("default"))) void mslo_frame_image_bounds(msl_frame_params *p, int width, int height) {
+    if (p->k1 != 0.0) {   // src/Frame.cc:466-488
+        float c[4][2] = {{0.f, 0.f}, {(float)width, 0.f}, {0.f, (float)height}, {(float)width, (float)height}}, u[4][2];
+        for (int i = 0; i < 4; i++) undistort_point(*p, c[i][0], c[i][1], &u[i][0], &u[i][1]);
+        p->minX = std::min(u[0][0], u[2][0]); p->maxX = std::max(u[1][0], u[3][0]);
+        p->minY = std::min(u[0][1], u[1][1]); p->maxY = std::max(u[2][1], u[3][1]);
+    } else {
+        p->minX = 0.0f; p->maxX = (float)width; p->minY = 0.0f; p->maxY = (float)height;
+    }
+}
+
+// UndistortKeyPoints + ComputeStereoFromRGBD + AssignFeaturesToGrid for n keypoints of one frame
+__attribute__((visibility("default"))) void mslo_frame_epilogue(const msl_frame_params *pp, const msl_keypoint *kps, int n,
+                                                                const float *depth, size_t depth_stride_bytes, float *un_xy,
+                                                                float *depth_out, float *uright_out, int32_t *grid_cell) {
+    const msl_frame_params &p = *pp;
+    const float gridW = (float)MSL_FRAME_GRID_COLS / (float)(p.maxX - p.minX);   // src/Frame.cc:137-138
+    const float gridH = (float)MSL_FRAME_GRID_ROWS / (float)(p.maxY - p.minY);
+    for (int i = 0; i < n; i++) {
+        float ux = kps[i].x, uy = kps[i].y;
+        if (p.k1 != 0.0) undistort_point(p, kps[i].x, kps[i].y, &ux, &uy);
+        un_xy[2 * i] = ux; un_xy[2 * i + 1] = uy;
+        const float v = kps[i].y, u = kps[i].x;
+        const float d = *(const float *)((const uint8_t *)depth + (size_t)(int)v * depth_stride_bytes + sizeof(float) * (size_t)(int)u);
+        depth_out[i] = -1; uright_out[i] = -1;
+        if (d > 0) { depth_out[i] = d; uright_out[i] = ux - p.bf / d; }
+        const int posX = (int)roundf((ux - p.minX) * gridW), posY = (int)roundf((uy - p.minY) * gridH);
+        grid_cell[i] = (posX < 0 || posX >= MSL_FRAME_GRID_COLS || posY < 0 || posY >= MSL_FRAME_GRID_ROWS) ? -1
+                                                                                                           : posX * MSL_FRAME_GRID_ROWS + posY;
+    }
+}
+
 // ---- primitives, exposed for known-answer tests ------------------------------------------------
 __attribute__((visibility("default"))) void mslo_resize_linear_u8(const uint8_t *src, int sw, int sh, uint8_t *dst,
                                                                   int dw, int dh) {

@@ -233,3 +233,29 @@ def fuse_map_compact(local, new):
     new = np.ascontiguousarray(new)
     n = load().dll.mslo_fuse_map_compact(_p(buf), len(local), _p(new), len(new))
     return buf[:n].copy()
+
+
+# ------------------------------------------------------------------------------------------------
+# Frame post-ORB steps
+# ------------------------------------------------------------------------------------------------
+FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
+
+
+def frame_params(fx, fy, cx, cy, bf, width, height, k1=0.0, k2=0.0, p1=0.0, p2=0.0, k3=0.0):
+    p = np.zeros(1, FRAME_PARAMS_DTYPE)
+    for k, v in dict(fx=fx, fy=fy, cx=cx, cy=cy, k1=k1, k2=k2, p1=p1, p2=p2, k3=k3, bf=bf).items():
+        p[k] = v
+    d = load().dll
+    d.mslo_frame_image_bounds.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    d.mslo_frame_image_bounds(_p(p), width, height)
+    return p
+
+
+def frame_epilogue(params, kps, depth):
+    d = load().dll
+    d.mslo_frame_epilogue.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t] + [C.c_void_p] * 4
+    n = len(kps)
+    kps = np.ascontiguousarray(kps); depth = np.ascontiguousarray(depth, np.float32)
+    un = np.zeros((n, 2), np.float32); dep = np.zeros(n, np.float32); ur = np.zeros(n, np.float32); cell = np.zeros(n, np.int32)
+    d.mslo_frame_epilogue(_p(params), _p(kps), n, _p(depth), depth.strides[0], _p(un), _p(dep), _p(ur), _p(cell))
+    return un, dep, ur, cell

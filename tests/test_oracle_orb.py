@@ -194,3 +194,34 @@ def test_golden_orb(oracle):
     img = synth.orb_frame(int(g["seed"]), 400, 304)
     k, d = oracle.orb_create(500, 1.2, 6, 25, 9).extract(img)
     assert k.tobytes() == g["keypoints"].tobytes() and np.array_equal(d, g["descriptors"])
+
+
+def test_frame_epilogue_known_answers(oracle):
+    """Frame post-ORB steps: zero distortion copies the keypoints; undistortion inverts the forward distortion model;
+    stereo/grid formulas (src/Frame.cc:418-427, :495-513)."""
+    from tests import oracle_lib
+    I = synth.TUM1
+    p0 = oracle_lib.frame_params(I["fx"], I["fy"], I["cx"], I["cy"], 40.0, 640, 480)
+    assert (p0["minX"][0], p0["maxX"][0], p0["minY"][0], p0["maxY"][0]) == (0.0, 640.0, 0.0, 480.0)
+    kps = np.zeros(4, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"] = [19.0, 320.4, 600.7, 639.0]; kps["y"] = [19.0, 240.6, 100.2, 479.0]
+    depth = np.full((480, 640), 2.0, np.float32); depth[100, 600] = 0.0
+    un, dep, ur, cell = oracle_lib.frame_epilogue(p0, kps, depth)
+    assert np.array_equal(un, np.stack([kps["x"], kps["y"]], 1))
+    assert dep.tolist() == [2.0, 2.0, -1.0, 2.0] and ur[2] == -1.0
+    assert ur[1] == np.float32(np.float32(320.4) - np.float32(40.0) / np.float32(2.0))
+    gx = np.round(kps["x"] * np.float32(64 / 640.0)); gy = np.round(kps["y"] * np.float32(48 / 480.0))
+    expect = np.where((gx < 64) & (gy < 48), gx * 48 + gy, -1)
+    assert cell.tolist() == expect.astype(int).tolist() and cell[3] == -1       # (639, 479) rounds to cell (64, 48): outside
+    # with distortion: distort(undistort(p)) == p to float precision
+    k1, k2, p1, p2, k3 = 0.262383, -0.953104, -0.005358, 0.002628, 1.163314
+    pd = oracle_lib.frame_params(I["fx"], I["fy"], I["cx"], I["cy"], 40.0, 640, 480, k1=k1, k2=k2, p1=p1, p2=p2, k3=k3)
+    rng = np.random.default_rng(0)
+    kps = np.zeros(200, oracle_lib.KEYPOINT_DTYPE)
+    kps["x"] = rng.uniform(19, 620, 200); kps["y"] = rng.uniform(19, 460, 200)
+    un, _, _, _ = oracle_lib.frame_epilogue(pd, kps, depth)
+    x = (un[:, 0].astype(np.float64) - I["cx"]) / I["fx"]; y = (un[:, 1].astype(np.float64) - I["cy"]) / I["fy"]
+    r2 = x * x + y * y
+    rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    assert np.abs(xd * I["fx"] + I["cx"] - kps["x"]).max() < 0.05 and np.abs(yd * I["fy"] + I["cy"] - kps["y"]).max() < 0.05

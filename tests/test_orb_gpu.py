@@ -123,3 +123,33 @@ def test_device_resident_batch(oracle):
         ko, do = oex.extract(imgs[f])
         _assert_same(kps[f, :n[f]], desc[f, :n[f]], ko, do)
     ex.close()
+
+
+@pytest.mark.parametrize("dist", [False, True])
+def test_frame_epilogue_matches_oracle(oracle, dist):
+    """UndistortKeyPoints + ComputeStereoFromRGBD + AssignFeaturesToGrid fused behind the extraction."""
+    from manhattanslam_amd import ORBextractor, frame_params, synth
+    from tests import oracle_lib
+    I = synth.TUM1
+    kw = dict(k1=0.262383, k2=-0.953104, p1=-0.005358, p2=0.002628, k3=1.163314) if dist else {}   # Example/TUM1.yaml:13-17
+    pg = frame_params(I["fx"], I["fy"], I["cx"], I["cy"], 40.0, 640, 480, **kw)
+    po = oracle_lib.frame_params(I["fx"], I["fy"], I["cx"], I["cy"], 40.0, 640, 480, **kw)
+    assert pg.tobytes() == po.tobytes()                       # ComputeImageBounds
+    if dist:
+        assert pg["minX"][0] != 0 and pg["maxX"][0] != 640
+    imgs = synth.orb_frames(3, seed=555)
+    depths = np.stack([synth.surfel_frame(k)[1] for k in range(3)])
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=3)
+    res = ex.extract_frames(imgs, depths, pg)
+    oex = oracle.orb_create()
+    for f in range(3):
+        ko, do = oex.extract(imgs[f])
+        kg, dg, un, dep, ur, cell = res[f]
+        _assert_same(kg, dg, ko, do)
+        uo, depo, uro, cello = oracle_lib.frame_epilogue(po, ko, depths[f])
+        assert un.tobytes() == uo.tobytes() and dep.tobytes() == depo.tobytes() and ur.tobytes() == uro.tobytes()
+        assert np.array_equal(cell, cello)
+        assert (dep == -1).sum() > 0 and (dep > 0).sum() > 900 and (cell >= 0).sum() > 900
+        if dist:
+            assert np.abs(un - np.stack([kg["x"], kg["y"]], 1)).max() > 1.0      # the distortion really moves points
+    ex.close()
