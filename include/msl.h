@@ -201,6 +201,18 @@ MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8
                                  size_t gray_stride, const float *depth, size_t depth_stride,
                                  const int32_t *member, size_t member_stride, msl_mem img_mem,
                                  const float pose_colmajor[16]);
+/* ---- widening, SURVEY.md 8(f) rank 4: map maintenance on the resident map (so SurfelMapping::moveAddSurfels and Stop() need
+ * no full download/upload).  All three are synchronous and keep the reference's element order. ----
+ * msl_sf_map_detach: the inner loop of moveAddSurfels (src/SurfelMapping.cpp:207-224) for one leaving pose: every live surfel
+ *   (updateTimes > 0) whose lastUpdate == pose_index is copied, in map order, to `out` (host) and marked deleted in the map
+ *   (updateTimes = 0).  *n_out = number found; MSL_ERR_CAPACITY (nothing modified) if it exceeds cap.
+ * msl_sf_map_append: mvLocalSurfels.insert(end, ...) of re-entering poses (src/SurfelMapping.cpp:291-296).
+ * msl_sf_map_export: the local-surfel filter of SurfelMapping::Stop (src/SurfelMapping.cpp:67-84): surfels with
+ *   updateTimes >= min_update_times, in map order. */
+MSL_API int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out);
+MSL_API int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n);
+MSL_API int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out);
+
 /* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
  * Keyframe f's images start at base + f * <frame_stride> bytes (member_frame_stride may be 0: one shared
  * membership image); refs[n_frames] and poses (16 * n_frames floats, column-major Twc each) are host arrays.

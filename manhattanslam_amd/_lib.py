@@ -58,6 +58,9 @@ SIGNATURES = {
     "msl_sf_map_upload": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_download": (_i, [_vp, _vp, _sz, _vp]),
     "msl_sf_map_size": (_i, [_vp, _vp]),
+    "msl_sf_map_detach": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
+    "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
     "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
     "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),

@@ -1142,6 +1142,76 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
 }
 
+// ---- map maintenance: ordered selection of surfels by a predicate -------------------------------
+// mode 0: updateTimes > 0 && lastUpdate == arg (moveAddSurfels, src/SurfelMapping.cpp:213)   mode 1: updateTimes >= arg (Stop, :68)
+__device__ __forceinline__ bool select_pred(const HotRec &h, int mode, int arg) {
+    return mode == 0 ? (h.updateTimes > 0 && h.lastUpdate == arg) : (h.updateTimes >= arg);
+}
+__global__ __launch_bounds__(256) void k_select_count(SfDev P, int mode, int arg) {
+    __shared__ unsigned s_c;
+    const long long n = P.ctr[0];
+    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        if (threadIdx.x == 0) s_c = 0;
+        __syncthreads();
+        unsigned c = 0;
+        for (int k = 0; k < SCAN_ITEMS / 256; k++) {
+            const long long i = b * SCAN_ITEMS + k * 256 + threadIdx.x;
+            if (i < n && select_pred(P.map.hot[i], mode, arg)) c++;
+        }
+        if (c) atomicAdd(&s_c, c);
+        __syncthreads();
+        if (threadIdx.x == 0) P.blockSums[b] = s_c;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_select_scan(SfDev P) {   // one workgroup: exclusive scan of the chunk counts, total -> ctr[7]
+    __shared__ unsigned s_wave[17];
+    const long long n = P.ctr[0];
+    const int nblk = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
+    unsigned carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const unsigned v = b < nblk ? P.blockSums[b] : 0;
+        unsigned tot;
+        const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
+        if (b < nblk) P.blockSums[b] = ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) P.ctr[7] = carry;
+}
+__global__ __launch_bounds__(256) void k_select_write(SfDev P, int mode, int arg, msl_surfel *out, int markDeleted) {
+    __shared__ unsigned s_wave[17];
+    const long long n = P.ctr[0];
+    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        unsigned base = P.blockSums[b];
+        for (int k = 0; k < SCAN_ITEMS / 256; k++) {           // 256 consecutive surfels per round keep the map order
+            const long long i = b * SCAN_ITEMS + k * 256 + threadIdx.x;
+            HotRec h{};
+            const bool sel = i < n && select_pred(h = P.map.hot[i], mode, arg);
+            unsigned tot;
+            const unsigned pos = base + block_excl_scan(sel ? 1u : 0u, s_wave, &tot);
+            if (sel) {
+                const ColdRec c = P.map.cold[i];
+                msl_surfel e;
+                e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz; e.size = c.size; e.color = c.color;
+                e.r = c.r; e.g = c.g; e.b = c.b; e.weight = c.weight; e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
+                out[pos] = e;
+                if (markDeleted) P.map.hot[i].updateTimes = 0;   // "Delete the surfel from the local point" (:224)
+            }
+            base += tot;
+        }
+    }
+}
+__global__ void k_add_ctr(long long *ctr, long long add) {
+    if (threadIdx.x == 0) { ctr[0] += add; ctr[4] = ctr[0]; ctr[6] = ctr[0]; }
+}
+__global__ __launch_bounds__(256) void k_aos_to_soa_at(MapSoA M, const msl_surfel *src, long long n, const long long *ctr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) store_surfel(M, ctr[0] + i, src[i]);
+}
+
 // AoS <-> SoA conversion for upload / download / host-vector mode
 __global__ __launch_bounds__(256) void k_aos_to_soa(MapSoA M, const msl_surfel *src, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1556,6 +1626,62 @@ int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) 
         MSL_HIP_TRY(hipStreamSynchronize(s));
     }
     return check_err(h);
+}
+
+static int map_select(msl_sf *h, int mode, int arg, bool mark, msl_surfel *out, size_t cap, size_t *n_out, const char *what) {
+    if (!h || !n_out) { set_error("%s: invalid argument", what); return MSL_ERR_INVALID; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctr(h);                       // waits for both streams
+    if (rc != MSL_OK) return rc;
+    rc = check_err(h);
+    if (rc != MSL_OK) return rc;
+    const size_t n = (size_t)h->h_ctr[0];
+    *n_out = 0;
+    if (n == 0) return MSL_OK;
+    hipStream_t s = h->mapStream;
+    const SfDev P = h->dev;
+    hipLaunchKernelGGL(k_select_count, dim3(512), dim3(256), 0, s, P, mode, arg);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, s, P);
+    rc = read_ctr(h);
+    if (rc != MSL_OK) return rc;
+    const size_t m = (size_t)h->h_ctr[7];
+    *n_out = m;
+    (void)hipMemsetAsync(h->d_ctr + 7, 0, sizeof(long long), s);
+    if (m > cap || (m && !out)) { set_error("%s: %zu surfels selected, capacity %zu", what, m, cap); return MSL_ERR_CAPACITY; }
+    if (m == 0) return MSL_OK;
+    rc = ensure_aos(h, m);
+    if (rc != MSL_OK) return rc;
+    hipLaunchKernelGGL(k_select_write, dim3(512), dim3(256), 0, s, P, mode, arg, h->d_aos, mark ? 1 : 0);
+    MSL_HIP_TRY(hipMemcpyAsync(out, h->d_aos, sizeof(msl_surfel) * m, hipMemcpyDeviceToHost, s));
+    MSL_HIP_TRY(hipStreamSynchronize(s));
+    return MSL_OK;
+}
+
+int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out) {
+    return map_select(h, 0, pose_index, true, out, cap, n_out, "msl_sf_map_detach");
+}
+int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out) {
+    return map_select(h, 1, min_update_times, false, out, cap, n_out, "msl_sf_map_export");
+}
+int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
+    if (!h || (n && !surfels)) { set_error("msl_sf_map_append: invalid argument"); return MSL_ERR_INVALID; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctr(h);
+    if (rc != MSL_OK) return rc;
+    if (n == 0) return MSL_OK;
+    const size_t cur = (size_t)h->h_ctr[0];
+    if (cur + n + (size_t)h->dev.nseeds > h->mapCap) {
+        rc = map_realloc(h, cur + n + (cur + n) / 4 + 4 * (size_t)h->dev.nseeds, cur);
+        if (rc != MSL_OK) return rc;
+    }
+    rc = ensure_aos(h, n);
+    if (rc != MSL_OK) return rc;
+    hipStream_t s = h->mapStream;
+    MSL_HIP_TRY(hipMemcpyAsync(h->d_aos, surfels, sizeof(msl_surfel) * n, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_aos_to_soa_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev.map, h->d_aos, (long long)n, h->d_ctr);
+    hipLaunchKernelGGL(k_add_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n);
+    MSL_HIP_TRY(hipStreamSynchronize(s));
+    return MSL_OK;
 }
 
 int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray, size_t gray_stride,

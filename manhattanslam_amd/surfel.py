@@ -70,6 +70,31 @@ class SurfelFusion:
         check(lib.msl_sf_map_download(self._h, ptr(out) if n else None, n, C.byref(got)), "msl_sf_map_download")
         return out[:got.value]
 
+    # ---- map maintenance (SurfelMapping::moveAddSurfels / Stop on the resident map) ----
+    def map_detach(self, pose_index):
+        """Live surfels last updated by `pose_index`, in map order; they are marked deleted in the map."""
+        return self._select(lib.msl_sf_map_detach, pose_index, "msl_sf_map_detach")
+
+    def map_export(self, min_update_times=5):
+        """Surfels with updateTimes >= min_update_times, in map order (SurfelMapping::Stop filter)."""
+        return self._select(lib.msl_sf_map_export, min_update_times, "msl_sf_map_export")
+
+    def _select(self, fn, arg, what):
+        n = C.c_size_t(0)
+        out = np.zeros(0, SURFEL_DTYPE)
+        rc = fn(self._h, int(arg), None, 0, C.byref(n))
+        if rc == 0:
+            return out
+        if rc != -4:
+            check(rc, what)
+        out = np.zeros(n.value, SURFEL_DTYPE)
+        check(fn(self._h, int(arg), ptr(out), len(out), C.byref(n)), what)
+        return out[:n.value]
+
+    def map_append(self, surfels):
+        surfels = np.ascontiguousarray(surfels, SURFEL_DTYPE)
+        check(lib.msl_sf_map_append(self._h, ptr(surfels) if len(surfels) else None, len(surfels)), "msl_sf_map_append")
+
     def fuse_resident(self, referenceFrameIndex, gray, depth, member, pose, device=False, strides=None):
         """fuseInitializeMap + fuseMap compaction on the resident map; asynchronous."""
         if strides is None:

@@ -563,4 +563,27 @@ MSLO_API size_t mslo_fuse_map_compact(msl_surfel *local, size_t n_local, const m
 }
 MSLO_API void mslo_inverse4f(const float *m, float *inv) { inverse4<float>(m, inv); }
 
+// ---- map maintenance ----
+// inner loop of moveAddSurfels for one leaving pose (src/SurfelMapping.cpp:212-225); returns the number moved
+MSLO_API size_t mslo_map_detach(msl_surfel *local, size_t n, int inactiveIndex, msl_surfel *out) {
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        msl_surfel &localSurfel = local[i];
+        if (localSurfel.updateTimes > 0 && localSurfel.lastUpdate == inactiveIndex) {
+            out[m++] = localSurfel;
+            localSurfel.updateTimes = 0;
+        }
+    }
+    return m;
+}
+// local-surfel filter of SurfelMapping::Stop (src/SurfelMapping.cpp:67-84)
+MSLO_API size_t mslo_map_export(const msl_surfel *local, size_t n, int minUpdateTimes, msl_surfel *out) {
+    size_t m = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (local[i].updateTimes < minUpdateTimes) continue;
+        out[m++] = local[i];
+    }
+    return m;
+}
+
 }  // extern "C"

@@ -216,3 +216,38 @@ def test_div100_exact():
     check(lib.msl_debug_div100(ptr(x), ptr(out), len(x)))
     ref = (x * x).astype(np.float64) / 100.0
     assert np.array_equal(out, ref), np.flatnonzero(out != ref)[:5]
+
+
+def test_map_maintenance_matches_literal_loops(oracle):
+    """moveAddSurfels detach / re-attach and the Stop() export filter on the resident map."""
+    import ctypes as C
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    from tests.oracle_lib import load, _p
+    d = load().dll
+    d.mslo_map_detach.restype = C.c_size_t; d.mslo_map_detach.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    d.mslo_map_export.restype = C.c_size_t; d.mslo_map_export.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(70000, ref=8).astype(SURFEL_DTYPE)          # lastUpdate in 0..8, updateTimes 1..20
+    m["updateTimes"][::17] = 0                                       # some already deleted slots
+    g.map_upload(m)
+    ref_map = m.copy()
+    for pose in (3, 8, 100):
+        buf = np.zeros(len(ref_map), SURFEL_DTYPE)
+        k = d.mslo_map_detach(_p(ref_map), len(ref_map), pose, _p(buf))
+        got = g.map_detach(pose)
+        assert len(got) == k and got.tobytes() == buf[:k].tobytes(), pose
+        assert g.map_download().tobytes() == ref_map.tobytes()
+    buf = np.zeros(len(ref_map), SURFEL_DTYPE)
+    k = d.mslo_map_export(_p(ref_map), len(ref_map), 5, _p(buf))
+    exp = g.map_export(5)
+    assert len(exp) == k and exp.tobytes() == buf[:k].tobytes() and 0 < k < len(ref_map)
+    extra = synth.surfel_map(1234, ref=9, seed=5).astype(SURFEL_DTYPE)
+    g.map_append(extra)                                              # mvLocalSurfels.insert(end, attachedSurfels...)
+    assert g.map_download().tobytes() == np.concatenate([ref_map, extra]).tobytes()
+    # and fusion keeps working on the maintained map
+    gray, depth, member, pose = synth.surfel_frame(9)
+    o.map_set(np.concatenate([ref_map, extra]))
+    g.fuse_resident(9, gray, depth, member, pose)
+    o.fuse_map(9, gray, depth, member, pose)
+    assert_surfels_close(g.map_download(), o.map_get(), "after maintenance")
+    g.close()
