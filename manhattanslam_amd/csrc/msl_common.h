@@ -84,6 +84,24 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned *s_wave
     *total = all;
     return before + inc - v;
 }
+// Two independent exclusive scans sharing one pair of barriers (s_wave: 2 x 16 entries).
+__device__ __forceinline__ void block_excl_scan_pair(unsigned a, unsigned b, unsigned *s_wave, unsigned *totalA, unsigned *totalB,
+                                                     unsigned &exA, unsigned &exB) {
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const unsigned ia = wave_incl_scan(a), ib = wave_incl_scan(b);
+    __syncthreads();
+    if (lane_id() == 63) { s_wave[w] = ia; s_wave[16 + w] = ib; }
+    __syncthreads();
+    unsigned beforeA = 0, allA = 0, beforeB = 0, allB = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const unsigned ta = i < nw ? s_wave[i] : 0u, tb = i < nw ? s_wave[16 + i] : 0u;
+        allA += ta; beforeA += i < w ? ta : 0u;
+        allB += tb; beforeB += i < w ? tb : 0u;
+    }
+    *totalA = allA; *totalB = allB;
+    exA = beforeA + ia - a; exB = beforeB + ib - b;
+}
 
 // In-place inclusive scan of an LDS array (len elements) by the whole block.
 template <typename T>

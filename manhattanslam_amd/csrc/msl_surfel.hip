@@ -88,6 +88,7 @@ struct SfDev {
     unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
     unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
+    const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -487,7 +488,8 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         if (inr) atomicAdd(&s_cnt[g], inr);
         __builtin_amdgcn_wave_barrier();
         if (l == 0) {
-            const float sumA = seq_sum_huber(s_term[g], nd, 0.0f);
+            // no Huber tails (the common case): a plain float chain, 1 VALU op per element instead of ~8
+            const float sumA = s_cnt[g] == nd ? seq_sum_f32(s_term[g], nd, 0.0f) : seq_sum_huber(s_term[g], nd, 0.0f);
             const float sumB = (float)(2 * s_cnt[g]);
             const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
             const float m = meanDepth + deltaDepth;
@@ -523,12 +525,13 @@ __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
 // Pixel positions and cross-product normals are recomputed from depth instead of materialising spaceMap
 // (7.4 MB f64) / normMap.  Also prepares the surfel the seed would spawn (initializeSurfels, :285-331).
 __device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, float myX, float myY, float myZ, float rightDepth,
-                                             float downDepth, float &nX, float &nY, float &nZ) {
+                                             float downDepth, float cxr, float cx1, float ryr, float ry1,
+                                             float &nX, float &nY, float &nZ) {
     nX = nY = nZ = 0.0f;
     if (row < 1 || row > P.H - 2 || col < 1 || col > P.W - 2) return;  // never written (:620-625)
-    float rightX, rightY, rightZ, downX, downY, downZ;
-    back_project(P, (float)(col + 1), (float)row, rightDepth, rightX, rightY, rightZ);
-    back_project(P, (float)col, (float)(row + 1), downDepth, downX, downY, downZ);
+    // back_project of the right / down neighbours with the tabulated quotients: (col+1, row) and (col, row+1)
+    float rightX = cx1 * rightDepth, rightY = ryr * rightDepth, rightZ = rightDepth;
+    float downX = cxr * downDepth, downY = ry1 * downDepth, downZ = downDepth;
     if (myZ < 0.1 || rightZ < 0.1 || downZ < 0.1) return;
     rightX = rightX - myX; rightY = rightY - myY; rightZ = rightZ - myZ;
     downX = downX - myX; downY = downY - myY; downZ = downZ - myZ;
@@ -559,27 +562,30 @@ __device__ __forceinline__ double group_sum_d(double v) {
     return v;
 }
 
+// LDS: one pool per wave.  The four seeds of a wave form a 2x2 block of the seed lattice, so their 16x16 windows cover
+// 24x24 = 576 distinct pixels; every pixel belongs to one seed, hence the four ordered lists hold <= 576 entries in total
+// (+ 3 x 3 for 16-byte alignment of each list) instead of 4 x 256.  14 KB per wave: 11 waves per CU instead of 5.
+constexpr int PLANE_POOL = 24 * 24 + 12;
 __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
-    __shared__ __attribute__((aligned(16))) float s_d[4][256];
-    __shared__ __attribute__((aligned(16))) float s_p[4][3][256];
-    __shared__ __attribute__((aligned(16))) float s_n[4][3][256];
+    __shared__ __attribute__((aligned(16))) float s_pool[6][PLANE_POOL];   // position x y z, normal x y z
     __shared__ __attribute__((aligned(16))) double s_h[4][16];
     int slot, blk;
-    if (!xcd_slot((P.nseeds + 3) / 4, nSlots, slot, blk)) return;
+    const int bW = (P.spW + 1) / 2, bH = (P.spH + 1) / 2;
+    if (!xcd_slot(bW * bH, nSlots, slot, blk)) return;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15, lane = threadIdx.x;
-    const int seedI = blk * 4 + g;
+    const int spX = (blk % bW) * 2 + (g & 1), spY = (blk / bW) * 2 + (g >> 1);
+    const bool inRange = spX < P.spW && spY < P.spH;
+    const int seedI = inRange ? spY * P.spW + spX : 0;
     const FrameDev &F = P.frames[slot];
     const unsigned short *index = P.index + (size_t)slot * P.npx;
-    const bool inRange = seedI < P.nseeds;
     msl_seed S;
     memset(&S, 0, sizeof(S));
     if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
-    const int spX = seedI % P.spW, spY = seedI / P.spW;
     const int xb = spX * SP + SP / 2 - SP, yb = spY * SP + SP / 2 - SP;
     // ---- gather: lane = window column, unrolled loop = window row; unclipped window guarded by the flat index range
     // (:680-684).  All loads (index, depth, right/down neighbours) are issued up front with clamped addresses. ----
     float maxDist = 0;
-    int nvalid = 0;
+    int nvalid = 0, base = 0;
     {
         float dv[16], dr[16], dd[16];
         unsigned short idv[16];
@@ -593,39 +599,55 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             dr[k] = F.depth[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
             dd[k] = F.depth[(size_t)min(row + 1, P.H - 1) * P.dstride + col];
         }
-        const int gsh = g * 16;
+        unsigned vm = 0;   // bit k: pixel (row k of the window, this lane's column) is a valid-depth pixel of the seed
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int i = xb + l, jrow = yb + k;
             const int pixelIndex = jrow * P.W + i;
-            bool valid = false;
             if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && idv[k] == seedI) {
                 const float xDiff = i - S.x, yDiff = jrow - S.y;
                 const float dist = xDiff * xDiff + yDiff * yDiff;
                 if (dist > maxDist) maxDist = dist;
-                valid = dv[k] > 0.05;
+                if (dv[k] > 0.05) vm |= 1u << k;
             }
+        }
+        nvalid = __popc(vm);
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
+        {   // list bases inside the pool, each rounded up to 4 entries
+            const int pad = (nvalid + 3) & ~3;
+            const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64);
+            base = g == 0 ? 0 : g == 1 ? n0 : g == 2 ? n0 + n1 : n0 + n1 + n2;
+        }
+        const int gsh = g * 16;
+        int run = base;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool valid = (vm >> k) & 1u;
             const unsigned gm = (unsigned)((__ballot(valid) >> gsh) & 0xFFFFull);
             if (valid) {   // ordered compaction of the raw valid pixels: depth, right depth, down depth, pixel index
-                const int o = nvalid + __popc(gm & ((1u << l) - 1u));
-                s_d[g][o] = dv[k]; s_n[g][0][o] = dr[k]; s_n[g][1][o] = dd[k]; s_n[g][2][o] = __int_as_float(pixelIndex);
+                const int o = run + __popc(gm & ((1u << l) - 1u));
+                s_pool[2][o] = dv[k]; s_pool[3][o] = dr[k]; s_pool[4][o] = dd[k]; s_pool[5][o] = __int_as_float((yb + k) * P.W + xb + l);
             }
-            nvalid += __popc(gm);
+            run += __popc(gm);
         }
     }
+    float *const pX = s_pool[0] + base, *const pY = s_pool[1] + base, *const pZ = s_pool[2] + base;
+    float *const qX = s_pool[3] + base, *const qY = s_pool[4] + base, *const qZ = s_pool[5] + base;
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) maxDist = fmaxf(maxDist, __shfl_xor(maxDist, d, 16));
     __builtin_amdgcn_wave_barrier();
     // balanced: entry e -> position + cross-product normal, written back in place (order preserved)
     for (int e = l; e < nvalid; e += 16) {
-        const int pixelIndex = __float_as_int(s_n[g][2][e]);
+        const int pixelIndex = __float_as_int(qZ[e]);
         const int row = pixelIndex / P.W, col = pixelIndex - row * P.W;
-        const float myDepth = s_d[g][e], rightD = s_n[g][0][e], downD = s_n[g][1][e];
-        float pX, pY, pZ, nX, nY, nZ;
-        back_project(P, (float)col, (float)row, myDepth, pX, pY, pZ);
-        pixel_normal(P, row, col, pX, pY, pZ, rightD, downD, nX, nY, nZ);
-        s_p[g][0][e] = pX; s_p[g][1][e] = pY; s_p[g][2][e] = pZ;
-        s_n[g][0][e] = nX; s_n[g][1][e] = nY; s_n[g][2][e] = nZ;
+        const float myDepth = pZ[e], rightD = qX[e], downD = qY[e];
+        const float cxr = P.colX[col], cx1 = P.colX[col + 1], ryr = P.rowY[row], ry1 = P.rowY[row + 1];
+        const float x = cxr * myDepth, y = ryr * myDepth;   // back_project(col, row, myDepth)
+        float nX, nY, nZ;
+        pixel_normal(P, row, col, x, y, myDepth, rightD, downD, cxr, cx1, ryr, ry1, nX, nY, nZ);
+        pX[e] = x; pY[e] = y;
+        qX[e] = nX; qY[e] = nY; qZ[e] = nZ;
     }
     __builtin_amdgcn_wave_barrier();
     bool active = inRange && nvalid >= 16;   // validDepthNum < 16 -> continue (:702)
@@ -637,7 +659,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         int c = 0;
         if (active)
             for (int o = l; o < nvalid; o += 16) {
-                const float residual = meanDepth - s_d[g][o];
+                const float residual = meanDepth - pZ[o];
                 c += (residual < HUBER_RANGE && residual > -HUBER_RANGE) ? 1 : 0;
             }
 #pragma unroll
@@ -652,17 +674,17 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             bool inl = false;
             float a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
             if (needCompact && o < nvalid) {
-                const float residual = meanDepth - s_d[g][o];
+                const float residual = meanDepth - pZ[o];
                 inl = residual < HUBER_RANGE && residual > -HUBER_RANGE;
-                a0 = s_p[g][0][o]; a1 = s_p[g][1][o]; a2 = s_p[g][2][o];
-                b0 = s_n[g][0][o]; b1 = s_n[g][1][o]; b2 = s_n[g][2][o];
+                a0 = pX[o]; a1 = pY[o]; a2 = pZ[o];
+                b0 = qX[o]; b1 = qY[o]; b2 = qZ[o];
             }
             const unsigned gm = (unsigned)((__ballot(inl) >> (g * 16)) & 0xFFFFull);
             __builtin_amdgcn_wave_barrier();   // every lane has read its slot before anyone overwrites (w <= o)
             if (inl) {
                 const int w = w0 + __popc(gm & ((1u << l) - 1u));
-                s_p[g][0][w] = a0; s_p[g][1][w] = a1; s_p[g][2][w] = a2;
-                s_n[g][0][w] = b0; s_n[g][1][w] = b1; s_n[g][2][w] = b2;
+                pX[w] = a0; pY[w] = a1; pZ[w] = a2;
+                qX[w] = b0; qY[w] = b1; qZ[w] = b2;
             }
             w0 += __popc(gm);
             __builtin_amdgcn_wave_barrier();
@@ -674,7 +696,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     float normX, normY, normZ, sumX, sumY, sumZ;
     {
         float acc = 0.0f;
-        if (active && l < 6) acc = seq_sum_f32(l < 3 ? s_n[g][l] : s_p[g][l - 3], ninl, 0.0f);
+        if (active && l < 6) acc = seq_sum_f32(s_pool[l < 3 ? 3 + l : l - 3] + base, ninl, 0.0f);
         const int gb = lane & 48;
         normX = __shfl(acc, gb + 0, 64); normY = __shfl(acc, gb + 1, 64); normZ = __shfl(acc, gb + 2, 64);
         sumX = __shfl(acc, gb + 3, 64); sumY = __shfl(acc, gb + 4, 64); sumZ = __shfl(acc, gb + 5, 64);
@@ -702,7 +724,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             for (int t = 0; t < 16; t++) {
                 const int o = l + 16 * t;
                 if (o < ninl) {
-                    const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
+                    const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
                     const float residual = px * nx + py * ny + pz * nz + nb;
                     if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
                         mask |= 1u << t;
@@ -726,7 +748,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                 for (int t = 0; t < 16; t++)
                     if (mask & (1u << t)) {
                         const int o = l + 16 * t;
-                        const float px = s_p[g][0][o] - sumX, py = s_p[g][1][o] - sumY, pz = s_p[g][2][o] - sumZ;
+                        const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
                         H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
                         H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
                         H22 += 2 * pz * pz; H23 += 2 * pz; H33 += 2;
@@ -846,6 +868,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     __shared__ unsigned short s_surv[SCAN_ITEMS];   // 2 KB: keeps the kernel co-resident with the LDS-heavy batched kernels
     __shared__ unsigned short s_del[SCAN_ITEMS];    // local indices of the chunk's deleted slots
     __shared__ unsigned s_delBase;
+    __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const MapSoA &M = P.map;
@@ -986,16 +1009,20 @@ constexpr int SMALL_D = 2048, SMALL_CHUNKS = 48;   // fast path: few deletions i
 
 __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     constexpr int NT = 256, TILE = 4 * NT;      // 256-thread workgroups find a free CU quickly next to the batched kernels
-    __shared__ unsigned s_wave[17];
+    __shared__ unsigned s_wave[33];
     __shared__ unsigned s_ex[TILE];
     __shared__ unsigned s_dl[SMALL_D];          // fast path: the deleted-slot list stays in LDS
+    __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
     __shared__ unsigned s_last, s_upd, s_nzChunks;
     __shared__ unsigned short s_nzList[SMALL_CHUNKS];   // fast path: the chunks that contain deletions
     __shared__ int s_fallback;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
     const uint4 bu0 = *reinterpret_cast<const uint4 *>(P.blockUpd + 4 * threadIdx.x);    // (arrays are padded by >= 1024 zeroed entries)
+    static_assert(LIST_D == NT, "one hand-over entry per thread");
+    const unsigned du = P.delU[threadIdx.x];
     const long long n = P.ctr[0];
     const bool bad = P.ctr[5] == 20;
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
@@ -1018,19 +1045,32 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
         }
     }
+    // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
+    // that this round trip overlaps the scans below instead of following them.
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    msl_surfel e0, e1;
+    memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
+    const bool pf = blockIdx.x == 0 || mode == 1;
+    if (pf && emit) {
+        e0 = cand[s0 + __builtin_ctzll(emit)];
+        const unsigned long long m1 = emit & (emit - 1);
+        if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
+    }
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
     // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread) ----
     const bool oneTile = nblk <= TILE;
-    unsigned carry = 0;
+    unsigned carry = 0, Ku = 0, pos = 0;
     bool small = false;
     for (long long t0 = 0; t0 < nblk; t0 += TILE) {
         const long long c = t0 + 4 * threadIdx.x;
         const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
         const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
-        unsigned tot;
-        unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+        unsigned tot, ex;
+        if (t0 == 0) { block_excl_scan_pair(v[0] + v[1] + v[2] + v[3], cnt, s_wave, &tot, &Ku, ex, pos); ex += carry; }   // + emission scan
+        else ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
 #pragma unroll
         for (int j = 0; j < 4; j++) { s_ex[4 * threadIdx.x + j] = ex; ex += v[j]; }
         if (oneTile)
@@ -1044,11 +1084,10 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (small && blockIdx.x != 0) return;
         if (small && tot <= LIST_D && !bad) {
             // fastest path: k_fuse already handed over the (few) deleted slots, unordered; rank-sort them in LDS
-            for (unsigned e = threadIdx.x; e < tot; e += NT) {
-                const unsigned ve = P.delU[e];
+            if (threadIdx.x < tot) {
                 unsigned r = 0;
-                for (unsigned j = 0; j < tot; j++) r += P.delU[j] < ve ? 1u : 0u;
-                s_dl[r] = ve;
+                for (unsigned j = 0; j < tot; j++) r += s_raw[j] < du ? 1u : 0u;
+                s_dl[r] = du;
             }
             carry += tot;
             __syncthreads();
@@ -1086,22 +1125,28 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (u) atomicAdd(&s_upd, u);
     }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    unsigned Ku;
-    unsigned pos = block_excl_scan(cnt, s_wave, &Ku);
+    if (nblk == 0) pos = block_excl_scan(cnt, s_wave, &Ku);   // empty map: the tile loop (and its paired scan) did not run
     const long long K = Ku;
     const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
     const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
     auto DL = [&](long long j) -> unsigned { return small ? s_dl[j] : ld_agent(&P.delList[j]); };
-    if (cnt)
-        for (int i = s0; i < s1; i++)
-            if ((i - s0 < 64) ? ((emit >> (i - s0)) & 1ull) : (candOk[i] && !fused[i])) {
-                const msl_surfel e = cand[i];
-                const long long k = pos++;
-                P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
-                if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
-                    store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
-            }
+    if (cnt) {
+        auto emit_one = [&](const msl_surfel &e) {
+            const long long k = pos++;
+            P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
+            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
+                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
+        };
+        unsigned long long m = emit;
+        for (int j = 0; m; j++, m &= m - 1) {
+            const int i = s0 + __builtin_ctzll(m);
+            if (pf && j == 0) emit_one(e0);
+            else if (pf && j == 1) emit_one(e1);
+            else emit_one(cand[i]);
+        }
+        for (int i = s0 + 64; i < s1; i++)
+            if (candOk[i] && !fused[i]) emit_one(cand[i]);
+    }
     __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
     if (threadIdx.x == 0) {
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
@@ -1263,6 +1308,7 @@ struct msl_sf {
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
     unsigned *d_tickets = nullptr, *d_delU = nullptr;
+    float *d_projTab = nullptr;
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
@@ -1462,7 +1508,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         LAUNCH(SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    LAUNCH(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid((D.nseeds + 3) / 4, n)), dim3(64), P, n);
+    LAUNCH(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), P, n);
     if (sp != sm) {
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
@@ -1510,6 +1556,15 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
     ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D) == hipSuccess;
+    {   // (u - cx) / fx and (v - cy) / fy of every integer pixel coordinate: the float expression of back_project
+        // (src/SurfelFusion.cpp:80-85) evaluated once here instead of six divisions per pixel in kb_seed_plane
+        std::vector<float> tab((size_t)width + 1 + height + 1);
+        for (int u = 0; u <= width; u++) tab[u] = ((float)u - cx) / fx;
+        for (int v = 0; v <= height; v++) tab[(size_t)width + 1 + v] = ((float)v - cy) / fy;
+        ok = ok && hipMalloc(&h->d_projTab, sizeof(float) * tab.size()) == hipSuccess;
+        ok = ok && hipMemcpy(h->d_projTab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) == hipSuccess;
+        D.colX = h->d_projTab; D.rowY = h->d_projTab + width + 1;
+    }
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 8);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;
@@ -1526,7 +1581,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
