@@ -864,9 +864,11 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
 __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
-    __shared__ unsigned s_cnt[4];
-    __shared__ unsigned short s_surv[SCAN_ITEMS];   // 2 KB: keeps the kernel co-resident with the LDS-heavy batched kernels
-    __shared__ unsigned short s_del[SCAN_ITEMS];    // local indices of the chunk's deleted slots
+    // One 4 KB list per workgroup keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
+    // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
+    // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
+    __shared__ unsigned s_cnt[5];
+    __shared__ unsigned s_surv[SCAN_ITEMS];
     __shared__ unsigned s_delBase;
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
@@ -880,11 +882,11 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     static_assert(SCAN_ITEMS == 1024, "4 consecutive surfels per thread x 256 threads");
     for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
-        if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         unsigned nupd = 0;
         const long long c0 = b * SCAN_ITEMS;
-        auto mark_deleted = [&](long long i) { s_del[atomicAdd(&s_cnt[0], 1u)] = (unsigned short)(i - c0); };
+        auto mark_deleted = [&](long long i) { s_surv[SCAN_ITEMS - 1 - atomicAdd(&s_cnt[0], 1u)] = (unsigned)(i - c0); };
         const long long i0 = c0 + 4 * threadIdx.x;     // map capacity is a multiple of 4096: the 16-byte loads stay in bounds
         {
             const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
@@ -893,9 +895,14 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             for (int j = 0; j < 5; j++) q[j] = hp[j];
             const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
                                     q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+            bool live[4];
+            float pzv[4], dep[4];
+            int pix[4];
+            unsigned short spi[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const long long i = i0 + k;
+                live[k] = false; pzv[k] = 0; dep[k] = 0; pix[k] = 0; spi[k] = 0;
                 if (i >= n) continue;
                 const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
                 const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
@@ -907,34 +914,43 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
                 const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;  // :75-78
                 const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
                 if (pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2) continue;
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned short)(i - c0);
+                live[k] = true; pzv[k] = pc[2];
+                // depth / superpixel lookups of all (up to 4) in-view surfels of the lane are in flight together
+                dep[k] = F.depth[(size_t)pVInt * P.dstride + pUInt];
+                spi[k] = index[pVInt * P.W + pUInt];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (!live[k]) continue;
+                const long long i = i0 + k;
+                if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned)(i - c0) | ((unsigned)spi[k] << 16);
             }
         }
         __syncthreads();
         const unsigned nsurv = s_cnt[2];
+        unsigned ndelB = 0;
         for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
-            const long long i = c0 + s_surv[sidx];
-            const HotRec hr = M.hot[i];                      // just streamed by this workgroup: cache hit
-            float pc[4];
-            mul4(F.invPose, hr.px, hr.py, hr.pz, 1.0f, pc);  // same expressions as phase A -> same pixel
-            const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;
-            const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
-            const float pz = pc[2];
-            const float dep = F.depth[(size_t)pVInt * P.dstride + pUInt];
-            const int spIndex = index[pVInt * P.W + pUInt];
-            if ((double)pz < (double)dep - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
+            const unsigned sv = s_surv[sidx];
+            const long long i = c0 + (sv & 0xFFFFu);
+            const int spIndex = (int)(sv >> 16);
+            // seed, hot record (just streamed by this workgroup: cache hit) and cold record in ONE round trip; the cold
+            // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
+            // fourth dependent round trip on this latency-bound chain
             const msl_seed S = seeds[spIndex];
+            const HotRec hr = M.hot[i];
+            ColdRec C = M.cold[i];
+            const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
             float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
             tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
             if (pz < S.meanDepth - tolerateDiff) continue;
             if (pz > S.meanDepth + tolerateDiff) continue;
-            ColdRec C = M.cold[i];
             float nc[3];
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
+            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; ndelB++; continue; }
             const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
@@ -966,8 +982,9 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             nupd++;
         }
         if (nupd) atomicAdd(&s_cnt[1], nupd);
+        if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
-        const unsigned ndelBlk = s_cnt[0];
+        const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
         if (threadIdx.x == 0) {
             P.blockSums[b] = ndelBlk; P.blockUpd[b] = s_cnt[1];
             if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per chunk that deleted something
@@ -975,8 +992,15 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
         __syncthreads();
         if (ndelBlk) {
             const unsigned base = s_delBase;
-            for (unsigned j = threadIdx.x; j < ndelBlk; j += 256)
-                if (base + j < LIST_D) P.delU[base + j] = (unsigned)(c0 + s_del[j]);
+            for (unsigned j = threadIdx.x; j < ndelA; j += 256)
+                if (base + j < LIST_D) P.delU[base + j] = (unsigned)(c0 + s_surv[SCAN_ITEMS - 1 - j]);
+            if (ndelBlk != ndelA)
+                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
+                    const unsigned sv = s_surv[sidx];
+                    if ((sv >> 16) != 0xFFFFu) continue;
+                    const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
+                    if (j < LIST_D) P.delU[j] = (unsigned)(c0 + (sv & 0xFFFFu));
+                }
         }
         __syncthreads();
     }
@@ -1005,16 +1029,16 @@ constexpr int TAIL_MAX_HOPS = 64;
 //   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
 //                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
 // mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
-constexpr int SMALL_D = 2048, SMALL_CHUNKS = 48;   // fast path: few deletions in few chunks (the steady state)
+constexpr int SMALL_D = 512, SMALL_CHUNKS = 48;   // single-workgroup path: few deletions in few chunks
 
+// LDS is kept to ~3.5 KB: on a GPU saturated by the LDS-heavy batched kernels a larger workgroup waits for a CU to drain.
 __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
-    constexpr int NT = 256, TILE = 4 * NT;      // 256-thread workgroups find a free CU quickly next to the batched kernels
+    constexpr int NT = 256, TILE = 4 * NT;
     __shared__ unsigned s_wave[33];
-    __shared__ unsigned s_ex[TILE];
-    __shared__ unsigned s_dl[SMALL_D];          // fast path: the deleted-slot list stays in LDS
+    __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
     __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
-    __shared__ unsigned s_last, s_upd, s_nzChunks;
-    __shared__ unsigned short s_nzList[SMALL_CHUNKS];   // fast path: the chunks that contain deletions
+    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk, s_extra;
+    __shared__ unsigned short s_nzList[SMALL_CHUNKS];   // the chunks that contain deletions
     __shared__ int s_fallback;
     __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
@@ -1057,65 +1081,82 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
     }
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    s_raw[threadIdx.x] = du;
-    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
-    __syncthreads();
-    // ---- scan of the chunk partials, 1024 per tile (4 consecutive per thread) ----
     const bool oneTile = nblk <= TILE;
-    unsigned carry = 0, Ku = 0, pos = 0;
-    bool small = false;
-    for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-        const long long c = t0 + 4 * threadIdx.x;
-        const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
-        const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
-        unsigned tot, ex;
-        if (t0 == 0) { block_excl_scan_pair(v[0] + v[1] + v[2] + v[3], cnt, s_wave, &tot, &Ku, ex, pos); ex += carry; }   // + emission scan
-        else ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+    s_raw[threadIdx.x] = du;
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; s_extra = 0; }
+    __syncthreads();
+    // ---- per-chunk deleted counts of the first tile (4 consecutive chunks per thread) + everything beyond it ----
+    unsigned v[4];
+    {
+        const long long c = 4 * threadIdx.x;
+        v[0] = c < nblk ? bs0.x : 0u; v[1] = c + 1 < nblk ? bs0.y : 0u; v[2] = c + 2 < nblk ? bs0.z : 0u; v[3] = c + 3 < nblk ? bs0.w : 0u;
+    }
+    if (oneTile) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) { s_ex[4 * threadIdx.x + j] = ex; ex += v[j]; }
-        if (oneTile)
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (v[j] > 0) { const unsigned q = atomicAdd(&s_nzChunks, 1u); if (q < SMALL_CHUNKS) s_nzList[q] = (unsigned short)(4 * threadIdx.x + j); }
-        __syncthreads();
-        // Fast path (steady state: a handful of deletions in a handful of chunks): workgroup 0 does everything alone -- no
-        // ticket, no write-through list -- and the other workgroups leave at once.
-        small = mode == 0 && oneTile && tot <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
-        if (small && blockIdx.x != 0) return;
-        if (small && tot <= LIST_D && !bad) {
-            // fastest path: k_fuse already handed over the (few) deleted slots, unordered; rank-sort them in LDS
-            if (threadIdx.x < tot) {
+        for (int j = 0; j < 4; j++)
+            if (v[j] > 0) { const unsigned q = atomicAdd(&s_nzChunks, 1u); if (q < SMALL_CHUNKS) s_nzList[q] = (unsigned short)(4 * threadIdx.x + j); }
+    } else {
+        unsigned extra = 0;
+        for (long long c2 = TILE + threadIdx.x; c2 < nblk; c2 += NT) extra += P.blockSums[c2];
+        if (extra) atomicAdd(&s_extra, extra);
+    }
+    unsigned tot0, Ku, ex0, pos;
+    block_excl_scan_pair(v[0] + v[1] + v[2] + v[3], cnt, s_wave, &tot0, &Ku, ex0, pos);   // chunk scan of tile 0 + emission scan
+    const long long D = (long long)tot0 + s_extra;
+    // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
+    const bool fastest = mode == 0 && D <= LIST_D;     // k_fuse already handed over the (few) deleted slots, unordered
+    const bool small = mode == 0 && !fastest && oneTile && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
+    const bool single = fastest || small;
+    if (single && blockIdx.x != 0) return;
+    if (mode == 0 && !bad) {
+        if (fastest) {
+            if (threadIdx.x < D) {   // rank-sort in LDS
                 unsigned r = 0;
-                for (unsigned j = 0; j < tot; j++) r += s_raw[j] < du ? 1u : 0u;
+                for (unsigned j = 0; j < (unsigned)D; j++) r += s_raw[j] < du ? 1u : 0u;
                 s_dl[r] = du;
             }
-            carry += tot;
-            __syncthreads();
-            continue;
-        }
-        if (mode == 0 && !bad) {
-            const long long nIter = small ? (long long)s_nzChunks : (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
-            for (long long it = 0; it < nIter; it++) {
-                const long long b = small ? t0 + s_nzList[it] : t0 + blockIdx.x + it * gridDim.x;
-                const unsigned base = s_ex[b - t0];
-                const unsigned next = (b - t0 + 1 < TILE && b + 1 < nblk) ? s_ex[b - t0 + 1] : carry + tot;
-                if (next == base) continue;   // nothing deleted in this chunk
-                const long long i0 = b * SCAN_ITEMS + 4 * threadIdx.x;   // 4 consecutive slots per thread keep the list ascending
-                unsigned f[4], c4 = 0;
+        } else {
+            // every workgroup lists the deleted slots of its own chunks in ascending order; a chunk's base offset lives
+            // in the registers of the thread that scanned it and is broadcast through one LDS word
+            unsigned carry = 0;
+            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+                unsigned ex, tot;
+                if (t0 == 0) { ex = ex0; tot = tot0; }
+                else {
+                    const long long c = t0 + 4 * threadIdx.x;
+                    const uint4 v4 = *reinterpret_cast<const uint4 *>(P.blockSums + c);
+                    v[0] = c < nblk ? v4.x : 0u; v[1] = c + 1 < nblk ? v4.y : 0u; v[2] = c + 2 < nblk ? v4.z : 0u; v[3] = c + 3 < nblk ? v4.w : 0u;
+                    ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+                }
+                const long long nIter = small ? (long long)s_nzChunks : (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
+                for (long long it = 0; it < nIter; it++) {
+                    const long long b = small ? t0 + s_nzList[it] : t0 + blockIdx.x + it * gridDim.x;
+                    const int q = (int)(b - t0);
+                    if ((int)threadIdx.x == (q >> 2)) {
+                        const int comp = q & 3;
+                        s_base = ex + (comp > 0 ? v[0] : 0u) + (comp > 1 ? v[1] : 0u) + (comp > 2 ? v[2] : 0u);
+                        s_cntChunk = v[comp];
+                    }
+                    __syncthreads();
+                    const unsigned base = s_base, cntChunk = s_cntChunk;
+                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this chunk
+                    const long long i0 = b * SCAN_ITEMS + 4 * threadIdx.x;   // 4 consecutive slots per thread keep the list ascending
+                    unsigned f[4], c4 = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) { f[j] = (i0 + j < n && P.map.hot[i0 + j].updateTimes == 0) ? 1u : 0u; c4 += f[j]; }
-                unsigned tt;
-                unsigned pos = base + block_excl_scan(c4, s_wave, &tt);
+                    for (int j = 0; j < 4; j++) { f[j] = (i0 + j < n && P.map.hot[i0 + j].updateTimes == 0) ? 1u : 0u; c4 += f[j]; }
+                    unsigned tt;
+                    unsigned w = base + block_excl_scan(c4, s_wave, &tt);   // (its barriers also protect s_base)
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (f[j]) { if (small) s_dl[pos++] = (unsigned)(i0 + j); else st_agent(&P.delList[pos++], (unsigned)(i0 + j)); }
+                    for (int j = 0; j < 4; j++)
+                        if (f[j]) { if (small) s_dl[w++] = (unsigned)(i0 + j); else st_agent(&P.delList[w++], (unsigned)(i0 + j)); }
+                }
+                carry += tot;
+                __syncthreads();
             }
         }
-        carry += tot;
-        __syncthreads();
     }
-    const long long D = carry;
-    if (mode == 0 && !small && !last_workgroup(&P.tickets[1], &s_last)) return;
+    __syncthreads();
+    if (mode == 0 && !single && !last_workgroup(&P.tickets[1], &s_last)) return;
     // ================= continuation: one workgroup =================
     // updated count
     {
@@ -1125,11 +1166,10 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (u) atomicAdd(&s_upd, u);
     }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
-    if (nblk == 0) pos = block_excl_scan(cnt, s_wave, &Ku);   // empty map: the tile loop (and its paired scan) did not run
     const long long K = Ku;
     const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
     const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
-    auto DL = [&](long long j) -> unsigned { return small ? s_dl[j] : ld_agent(&P.delList[j]); };
+    auto DL = [&](long long j) -> unsigned { return single ? s_dl[j] : ld_agent(&P.delList[j]); };
     if (cnt) {
         auto emit_one = [&](const msl_surfel &e) {
             const long long k = pos++;
@@ -1421,14 +1461,15 @@ int check_err(msl_sf *h) {
 // When kernel `kid` is being timed its dispatch carries its own start/stop events (hipExtLaunchKernelGGL), so the
 // measurement adds no extra packets to the stream.  (Cross-checked once against in-kernel 100 MHz device-clock stamps:
 // 64.3 us by events vs 62.1 us by stamps for the same launches.)
-#define LAUNCH(kid, st, kern, grid, block, ...)                                                        \
+#define LAUNCH_LDS(kid, st, kern, grid, block, lds, ...)                                               \
     do {                                                                                               \
         hipEvent_t _ea, _eb;                                                                           \
         if (h->prof.kernel_pair(kid, &_ea, &_eb))                                                      \
-            hipExtLaunchKernelGGL(kern, grid, block, 0, st, _ea, _eb, 0, __VA_ARGS__);                 \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, st, _ea, _eb, 0, __VA_ARGS__);               \
         else                                                                                           \
-            hipLaunchKernelGGL(kern, grid, block, 0, st, __VA_ARGS__);                                 \
+            hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);                               \
     } while (0)
+#define LAUNCH(kid, st, kern, grid, block, ...) LAUNCH_LDS(kid, st, kern, grid, block, 0, __VA_ARGS__)
 
 // Superpixel stage for slots [slot0, slot0+n) on the pre stream, then the map stage per keyframe on the map stream.
 int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t gs, size_t gfs, const float *depth, size_t ds, size_t dfs,
@@ -1508,7 +1549,10 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         LAUNCH(SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    LAUNCH(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), P, n);
+    // 1 KB of (unused) dynamic LDS caps the kernel at 10 waves per CU: with 11 only 2.9 KB of LDS stay free and the
+    // latency-critical map-stage workgroups (3.3 and 4.1 KB) wait for a wave to retire before they can start
+    constexpr unsigned planePad = 1024;
+    LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     if (sp != sm) {
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));

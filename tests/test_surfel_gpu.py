@@ -172,6 +172,7 @@ def test_compaction_matches_literal_loop(oracle):
     rng = np.random.default_rng(3)
     gray, depth, member, pose = synth.surfel_frame(0)
     for trial, (n, pdel) in enumerate([(5000, 0.0), (5000, 0.9), (20000, 0.5), (9000, 1.0), (4097, 0.3), (30000, 1.0), (30000, 0.95),
+                                       (3000, 0.05), (3000, 0.12), (2500000, 0.0005),
                                        (400000, 1.0)]):
         m = synth.surfel_map(n, ref=0, seed=100 + trial).astype(SURFEL_DTYPE)
         m["updateTimes"][rng.random(n) < pdel] = 0         # pre-deleted slots
