@@ -57,10 +57,17 @@ struct MapSoA {
 };
 
 // Per-keyframe parameters of one slot (device memory, uploaded per batch).
+// Image pointers travel through memory, so the compiler only knows them as generic pointers and would emit FLAT loads
+// (which also count against lgkmcnt and so serialise with LDS / scalar traffic); the accessors restore the global
+// address space.
+template <typename T> using gptr = const T __attribute__((address_space(1))) *;
 struct FrameDev {
     const uint8_t *gray; const float *depth; const int32_t *member;
     float pose[16], invPose[16];
     int ref, _pad;
+    __device__ __forceinline__ gptr<uint8_t> grayG() const { return (gptr<uint8_t>)gray; }
+    __device__ __forceinline__ gptr<float> depthG() const { return (gptr<float>)depth; }
+    __device__ __forceinline__ gptr<int32_t> memberG() const { return (gptr<int32_t>)member; }
 };
 
 struct SfDev {
@@ -97,13 +104,13 @@ __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_N
     const int c = seedI / step;
     return c > NCHUNK - 1 ? NCHUNK - 1 : c;
 }
-__device__ __forceinline__ uint8_t gray_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.gray[(size_t)y * P.gstride + x]; }
-__device__ __forceinline__ float depth_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.depth[(size_t)y * P.dstride + x]; }
+__device__ __forceinline__ uint8_t gray_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.grayG()[(size_t)y * P.gstride + x]; }
+__device__ __forceinline__ float depth_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.depthG()[(size_t)y * P.dstride + x]; }
 __device__ __forceinline__ void vec3b(const SfDev &P, const FrameDev &F, float row, float col, int &r, int &g, int &b) {
     const unsigned long long off = (unsigned long long)(int)row * P.gstride + 3ull * (unsigned long long)(int)col;
-    r = off < P.gbytes ? F.gray[off] : 0;
-    g = off + 1 < P.gbytes ? F.gray[off + 1] : 0;
-    b = off + 2 < P.gbytes ? F.gray[off + 2] : 0;
+    r = off < P.gbytes ? F.grayG()[off] : 0;
+    g = off + 1 < P.gbytes ? F.grayG()[off + 1] : 0;
+    b = off + 2 < P.gbytes ? F.grayG()[off + 2] : 0;
 }
 __device__ __forceinline__ void back_project(const SfDev &P, float u, float v, float d, float &x, float &y, float &z) {
     x = (u - P.cx) / P.fx * d;   // src/SurfelFusion.cpp:80-85 (float expression, stored to double there)
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     const int seedI = blockIdx.x * 256 + threadIdx.x;
     if (seedI >= P.nseeds) return;
     if (seedI == 0) P.wlCount[slot] = 0;
-    const FrameDev &F = P.frames[slot];
+    const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const int spX = seedI % P.spW, spY = seedI / P.spW;
     int imageX = spX * SP + SP / 2, imageY = spY * SP + SP / 2;
     imageX = imageX < (P.W - 1) ? imageX : (P.W - 1);
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     msl_seed s;
     memset(&s, 0, sizeof(s));
     P.fused[(size_t)slot * P.nseeds + seedI] = 0;
-    if (F.member[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
+    if (F.memberG()[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
         P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.invDepth[(size_t)slot * P.nseeds + seedI] = 0.0;
         return;
     }
@@ -251,10 +258,10 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
         if (threadIdx.x >= 64 && threadIdx.x < 64 + NCHUNK) P.chunkAbort[(slot * 2 + (it & 1)) * 16 + threadIdx.x - 64] = 0x7FFFFFFF;
     }
     if (colI >= P.W || rowI >= P.H) return;
-    const FrameDev &F = P.frames[slot];
+    const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const int p = rowI * P.W + colI;
     unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
-    if (F.member[(size_t)(rowI / 2) * P.mstride + colI / 2] != -1) {
+    if (F.memberG()[(size_t)(rowI / 2) * P.mstride + colI / 2] != -1) {
         if (it == 0) index[p] = 0; else amap[p] = IDX_PLANE;
         return;
     }
@@ -371,6 +378,52 @@ __global__ __launch_bounds__(1024) void kb_prop_finish(SfDev P) {
     }
 }
 
+// The whole relaxation in ONE launch: one workgroup per keyframe keeps t(s) in LDS (4 B per seed) and its share of the
+// worklist in registers, so a round costs a few LDS operations instead of a kernel boundary plus agent-scope round trips.
+// The min-fixpoint is unique, so the evaluation order does not matter.  (kb_prop / kb_prop_finish remain as the fallback
+// for seed counts whose t(s) does not fit the LDS.)
+constexpr int PROP_LDS_MAX_SEEDS = 36 * 1024;   // 144 KB
+__global__ __launch_bounds__(1024) void kb_prop_lds(SfDev P) {
+    extern __shared__ unsigned s_t[];
+    const int slot = blockIdx.x;
+    const unsigned nwl = P.wlCount[slot];
+    if (nwl == 0) return;
+    unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
+    const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
+    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    constexpr int R = 8;
+    unsigned ep[R];
+    unsigned short ec[R], ea[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned e = threadIdx.x + r * 1024;
+        ep[r] = 0xFFFFFFFFu; ec[r] = 0; ea[r] = 0;
+        if (e < nwl) { const unsigned p = wl[e]; ep[r] = p; ec[r] = index[p]; ea[r] = amap[p]; }
+    }
+    for (int i = threadIdx.x; i < P.nseeds; i += 1024) s_t[i] = tmin[i];
+    __syncthreads();
+    auto relax = [&](unsigned p, unsigned short cur, unsigned short a) -> bool {
+        if (a >= IDX_PLANE) return false;
+        const unsigned tc = s_t[cur];
+        if (tc == 0 || tc > p) return false;            // tc == 0: handled in round 0; tc > p: not processed (yet)
+        if (s_t[a] <= p + 1u) return false;
+        return atomicMin(&s_t[a], p + 1u) > p + 1u;
+    };
+    int any;
+    do {
+        bool ch = false;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (ep[r] != 0xFFFFFFFFu) ch |= relax(ep[r], ec[r], ea[r]);
+        for (unsigned e = threadIdx.x + R * 1024; e < nwl; e += 1024) { const unsigned p = wl[e]; ch |= relax(p, index[p], amap[p]); }
+        any = __syncthreads_or(ch ? 1 : 0);
+    } while (any);
+    for (int i = threadIdx.x; i < P.nseeds; i += 1024) {
+        const unsigned t = s_t[i];
+        if (t != tmin[i]) tmin[i] = t;
+    }
+}
+
 __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
     int slot, blk;
     if (!xcd_slot((P.npx + 255) / 256, nSlots, slot, blk)) return;
@@ -394,7 +447,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     if (!xcd_slot((P.nseeds + 15) / 16, nSlots, slot, blk)) return;
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int seedI = blk * 16 + g;
-    const FrameDev &F = P.frames[slot];
+    const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     msl_seed S;
     memset(&S, 0, sizeof(S));
@@ -425,7 +478,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const int jc = min(max(yb0 + k, 0), P.H - 1);
-            idv[k] = index[(size_t)jc * P.W + colc]; dloc[k] = F.depth[(size_t)jc * P.dstride + colc]; gv[k] = F.gray[(size_t)jc * P.gstride + colc];
+            idv[k] = index[(size_t)jc * P.W + colc]; dloc[k] = F.depthG()[(size_t)jc * P.dstride + colc]; gv[k] = F.grayG()[(size_t)jc * P.gstride + colc];
         }
         const int gsh = (g & 3) * 16;
 #pragma unroll
@@ -576,7 +629,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int spX = (blk % bW) * 2 + (g & 1), spY = (blk / bW) * 2 + (g >> 1);
     const bool inRange = spX < P.spW && spY < P.spH;
     const int seedI = inRange ? spY * P.spW + spX : 0;
-    const FrameDev &F = P.frames[slot];
+    const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     msl_seed S;
     memset(&S, 0, sizeof(S));
@@ -595,9 +648,9 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             const int pc = min(max(pixelIndex, 0), P.npx - 1);
             const int row = pc / P.W, col = pc - row * P.W;     // wrapped pixel (App. B.6)
             idv[k] = index[pc];
-            dv[k] = F.depth[(size_t)row * P.dstride + col];
-            dr[k] = F.depth[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
-            dd[k] = F.depth[(size_t)min(row + 1, P.H - 1) * P.dstride + col];
+            dv[k] = F.depthG()[(size_t)row * P.dstride + col];
+            dr[k] = F.depthG()[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
+            dd[k] = F.depthG()[(size_t)min(row + 1, P.H - 1) * P.dstride + col];
         }
         unsigned vm = 0;   // bit k: pixel (row k of the window, this lane's column) is a valid-depth pixel of the seed
 #pragma unroll
@@ -863,7 +916,7 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 //   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
-__global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
+__global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
     // One 4 KB list per workgroup keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
@@ -874,7 +927,6 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
     const long long n = P.ctr[0];
     const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     const MapSoA &M = P.map;
-    const FrameDev &F = P.frames[slot];
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
@@ -895,36 +947,47 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             for (int j = 0; j < 5; j++) q[j] = hp[j];
             const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
                                     q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
-            bool live[4];
+            // Branch-free up to the loads: the eight depth / superpixel lookups of the lane's (up to four) in-view surfels
+            // leave together (lanes without an in-view surfel read some valid pixel), so the lane pays ONE dependent round trip.
+            int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
             float pzv[4], dep[4];
-            int pix[4];
-            unsigned short spi[4];
+            unsigned spi[4];   // 32-bit on purpose: packing two 16-bit results into one register would wait for each load
+            unsigned offD[4], offI[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const long long i = i0 + k;
-                live[k] = false; pzv[k] = 0; dep[k] = 0; pix[k] = 0; spi[k] = 0;
-                if (i >= n) continue;
                 const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
                 const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
-                if (ref - lu > 5 && ut < 5) { if (ut != 0) M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                if (ut == 0) { mark_deleted(i); continue; }
                 float pc[4];
                 mul4(F.invPose, x, y, z, 1.0f, pc);
-                if (pc[2] < P.fuseNear || pc[2] > P.fuseFar) continue;
-                const float projectU = pc[0] * P.fx / pc[2] + P.cx, projectV = pc[1] * P.fy / pc[2] + P.cy;  // :75-78
-                const int pUInt = (int)((double)projectU + 0.5), pVInt = (int)((double)projectV + 0.5);
-                if (pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2) continue;
-                live[k] = true; pzv[k] = pc[2];
-                // depth / superpixel lookups of all (up to 4) in-view surfels of the lane are in flight together
-                dep[k] = F.depth[(size_t)pVInt * P.dstride + pUInt];
-                spi[k] = index[pVInt * P.W + pUInt];
+                const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
+                const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+                const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+                const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
+                // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of
+                // the image either way
+                const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
+                const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+                int st = 0;
+                if (i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+                state[k] = st; pzv[k] = pc[2];
+                const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+                offD[k] = (unsigned)pVc * (unsigned)P.dstride + (unsigned)pUc;   // images are far below 2^32 elements
+                offI[k] = (unsigned)(pVc * P.W + pUc);
             }
 #pragma unroll
+            for (int k = 0; k < 4; k++) { dep[k] = F.depthG()[offD[k]]; spi[k] = index[offI[k]]; }
+            // a common use of all eight results: keeps the compiler from sinking each load into its (conditional) consumer,
+            // which would turn one round trip back into up to eight dependent ones
+            asm volatile("" ::"v"(dep[0]), "v"(dep[1]), "v"(dep[2]), "v"(dep[3]), "v"(spi[0]), "v"(spi[1]), "v"(spi[2]), "v"(spi[3]));
+#pragma unroll
             for (int k = 0; k < 4; k++) {
-                if (!live[k]) continue;
                 const long long i = i0 + k;
+                if (state[k] == 0) continue;
+                if (state[k] == 1) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
+                if (state[k] == 2) { mark_deleted(i); continue; }
                 if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned)(i - c0) | ((unsigned)spi[k] << 16);
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned)(i - c0) | (spi[k] << 16);
             }
         }
         __syncthreads();
@@ -940,6 +1003,8 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot) {
             const msl_seed S = seeds[spIndex];
             const HotRec hr = M.hot[i];
             ColdRec C = M.cold[i];
+            // common use of one field per load instruction (see phase A): all three records are in flight together
+            asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
             const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
@@ -1349,6 +1414,7 @@ struct msl_sf {
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
     unsigned *d_tickets = nullptr, *d_delU = nullptr;
     float *d_projTab = nullptr;
+    bool propLds = false;        // t(s) of one keyframe fits the LDS: single-launch relaxation
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
@@ -1541,8 +1607,12 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
         if (it > 0) {
             h->prof.begin(SK_PROP, sp);
-            for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, dim3(xcd_grid(PROP_BLOCKS, n)), dim3(256), 0, sp, P, r, n);
-            hipLaunchKernelGGL(kb_prop_finish, dim3(un), dim3(1024), 0, sp, P);
+            if (h->propLds) {
+                hipLaunchKernelGGL(kb_prop_lds, dim3(un), dim3(1024), sizeof(unsigned) * D.nseeds, sp, P);
+            } else {
+                for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, dim3(xcd_grid(PROP_BLOCKS, n)), dim3(256), 0, sp, P, r, n);
+                hipLaunchKernelGGL(kb_prop_finish, dim3(un), dim3(1024), 0, sp, P);
+            }
             h->prof.end(sp);
             LAUNCH(SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
         }
@@ -1558,7 +1628,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
     for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f, h->h_frames[slot0 + f]);
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
@@ -1609,6 +1679,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         ok = ok && hipMemcpy(h->d_projTab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) == hipSuccess;
         D.colX = h->d_projTab; D.rowY = h->d_projTab + width + 1;
     }
+    if (ok && D.nseeds <= PROP_LDS_MAX_SEEDS)
+        h->propLds = hipFuncSetAttribute((const void *)kb_prop_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * D.nseeds)) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 8);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;
