@@ -383,7 +383,7 @@ __global__ __launch_bounds__(1024) void kb_prop_finish(SfDev P) {
 // The min-fixpoint is unique, so the evaluation order does not matter.  (kb_prop / kb_prop_finish remain as the fallback
 // for seed counts whose t(s) does not fit the LDS.)
 constexpr int PROP_LDS_MAX_SEEDS = 36 * 1024;   // 144 KB
-__global__ __launch_bounds__(1024) void kb_prop_lds(SfDev P) {
+__global__ __launch_bounds__(256) void kb_prop_lds(SfDev P) {
     extern __shared__ unsigned s_t[];
     const int slot = blockIdx.x;
     const unsigned nwl = P.wlCount[slot];
@@ -391,16 +391,16 @@ __global__ __launch_bounds__(1024) void kb_prop_lds(SfDev P) {
     unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
     const unsigned *wl = P.wl + (size_t)slot * P.npx;
-    constexpr int R = 8;
+    constexpr int NT = 256, R = 16;   // a 256-thread workgroup finds room on a busy GPU; a 16-wave one waits for a whole CU
     unsigned ep[R];
     unsigned short ec[R], ea[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const unsigned e = threadIdx.x + r * 1024;
+        const unsigned e = threadIdx.x + r * NT;
         ep[r] = 0xFFFFFFFFu; ec[r] = 0; ea[r] = 0;
         if (e < nwl) { const unsigned p = wl[e]; ep[r] = p; ec[r] = index[p]; ea[r] = amap[p]; }
     }
-    for (int i = threadIdx.x; i < P.nseeds; i += 1024) s_t[i] = tmin[i];
+    for (int i = threadIdx.x; i < P.nseeds; i += NT) s_t[i] = tmin[i];
     __syncthreads();
     auto relax = [&](unsigned p, unsigned short cur, unsigned short a) -> bool {
         if (a >= IDX_PLANE) return false;
@@ -415,10 +415,10 @@ __global__ __launch_bounds__(1024) void kb_prop_lds(SfDev P) {
 #pragma unroll
         for (int r = 0; r < R; r++)
             if (ep[r] != 0xFFFFFFFFu) ch |= relax(ep[r], ec[r], ea[r]);
-        for (unsigned e = threadIdx.x + R * 1024; e < nwl; e += 1024) { const unsigned p = wl[e]; ch |= relax(p, index[p], amap[p]); }
+        for (unsigned e = threadIdx.x + R * NT; e < nwl; e += NT) { const unsigned p = wl[e]; ch |= relax(p, index[p], amap[p]); }
         any = __syncthreads_or(ch ? 1 : 0);
     } while (any);
-    for (int i = threadIdx.x; i < P.nseeds; i += 1024) {
+    for (int i = threadIdx.x; i < P.nseeds; i += NT) {
         const unsigned t = s_t[i];
         if (t != tmin[i]) tmin[i] = t;
     }
@@ -1608,7 +1608,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         if (it > 0) {
             h->prof.begin(SK_PROP, sp);
             if (h->propLds) {
-                hipLaunchKernelGGL(kb_prop_lds, dim3(un), dim3(1024), sizeof(unsigned) * D.nseeds, sp, P);
+                hipLaunchKernelGGL(kb_prop_lds, dim3(un), dim3(256), sizeof(unsigned) * D.nseeds, sp, P);
             } else {
                 for (int r = 0; r < PROP_ROUNDS; r++) hipLaunchKernelGGL(kb_prop, dim3(xcd_grid(PROP_BLOCKS, n)), dim3(256), 0, sp, P, r, n);
                 hipLaunchKernelGGL(kb_prop_finish, dim3(un), dim3(1024), 0, sp, P);
