@@ -642,11 +642,16 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     {
         float dv[16], dr[16], dd[16];
         unsigned short idv[16];
+        // wrapped pixel (App. B.6) of the unclipped window position (yb + k, xb + l) without an integer division:
+        // a column left / right of the image belongs to the previous / next row of the flat index
+        const int cx0 = xb + l;
+        const int wrapRow = cx0 < 0 ? -1 : (cx0 >= P.W ? 1 : 0), wcol = cx0 - wrapRow * P.W;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int pixelIndex = (yb + k) * P.W + xb + l;
-            const int pc = min(max(pixelIndex, 0), P.npx - 1);
-            const int row = pc / P.W, col = pc - row * P.W;     // wrapped pixel (App. B.6)
+            const int wr = yb + k + wrapRow;
+            // flat index clamped to [0, npx - 1]: rows above / below the image collapse onto the first / last pixel
+            const int row = wr < 0 ? 0 : (wr >= P.H ? P.H - 1 : wr), col = wr < 0 ? 0 : (wr >= P.H ? P.W - 1 : wcol);
+            const int pc = row * P.W + col;
             idv[k] = index[pc];
             dv[k] = F.depthG()[(size_t)row * P.dstride + col];
             dr[k] = F.depthG()[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             const unsigned gm = (unsigned)((__ballot(valid) >> gsh) & 0xFFFFull);
             if (valid) {   // ordered compaction of the raw valid pixels: depth, right depth, down depth, pixel index
                 const int o = run + __popc(gm & ((1u << l) - 1u));
-                s_pool[2][o] = dv[k]; s_pool[3][o] = dr[k]; s_pool[4][o] = dd[k]; s_pool[5][o] = __int_as_float((yb + k) * P.W + xb + l);
+                s_pool[2][o] = dv[k]; s_pool[3][o] = dr[k]; s_pool[4][o] = dd[k]; s_pool[5][o] = __int_as_float(((yb + k + wrapRow) << 16) | wcol);
             }
             run += __popc(gm);
         }
@@ -692,8 +697,8 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     __builtin_amdgcn_wave_barrier();
     // balanced: entry e -> position + cross-product normal, written back in place (order preserved)
     for (int e = l; e < nvalid; e += 16) {
-        const int pixelIndex = __float_as_int(qZ[e]);
-        const int row = pixelIndex / P.W, col = pixelIndex - row * P.W;
+        const int rc = __float_as_int(qZ[e]);
+        const int row = rc >> 16, col = rc & 0xFFFF;     // a valid pixel lies inside the image: (row, col) of its flat index
         const float myDepth = pZ[e], rightD = qX[e], downD = qY[e];
         const float cxr = P.colX[col], cx1 = P.colX[col + 1], ryr = P.rowY[row], ry1 = P.rowY[row + 1];
         const float x = cxr * myDepth, y = ryr * myDepth;   // back_project(col, row, myDepth)
