@@ -131,12 +131,26 @@ __device__ __forceinline__ int fast_score16(const uint8_t *t, int tp) {
     return max(a, -b) - 1;
 }
 
+// Quick rejection (the classic FAST high-speed test on the 4 even opposite pairs): a 9-arc of 16 contains at least one pixel
+// of every opposite pair, so a pixel whose score reaches th has, for each pair, one member brighter (or darker) than th.
+// Pixels that fail cannot score >= th; their score is stored as 0, which changes neither the threshold tests nor the
+// non-maximum suppression of any kept pixel (a kept pixel scores >= th, above every such neighbour either way).
+__device__ __forceinline__ bool fast_candidate(const uint8_t *t, int tp, int th) {
+    const int v = t[0];
+    const int d0 = v - t[3 * tp], d8 = v - t[-3 * tp], d4 = v - t[3], d12 = v - t[-3];
+    const int d2 = v - t[2 * tp + 2], d10 = v - t[-2 * tp - 2], d6 = v - t[-2 * tp + 2], d14 = v - t[2 * tp - 2];
+    const bool bright = (d0 > th || d8 > th) && (d4 > th || d12 > th) && (d2 > th || d10 > th) && (d6 > th || d14 > th);
+    const bool dark = (d0 < -th || d8 < -th) && (d4 < -th || d12 < -th) && (d2 < -th || d10 < -th) && (d6 < -th || d14 < -th);
+    return bright || dark;
+}
+
 __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
     __shared__ uint8_t s_tile[(MAXCELL + 6) * (MAXCELL + 8)];
     __shared__ uint8_t s_score[(MAXCELL + 2) * (MAXCELL + 2)];
     __shared__ uint8_t s_flag[MAXCELL * MAXCELL];
+    __shared__ unsigned short s_list[MAXCELL * MAXCELL];   // pixels that pass the quick test
     __shared__ unsigned s_wave[17];
-    __shared__ unsigned s_cnt[2];
+    __shared__ unsigned s_cnt[3];
 
     const int frame = blockIdx.y;
     const CellDev C = P.cells[blockIdx.x];
@@ -149,30 +163,54 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
 
     // stage (cw+6) x (ch+6) pixels: rows y0-3.., cols x0-3..
     const int tw = cw + 6, th = ch + 6, tp = (tw + 3) & ~3;
+    // exact floor(i / w) for i < 2^13, w <= 2^7 by multiply-shift: one division per thread instead of one per pixel
+    const unsigned mTw = ((1u << 20) + tw - 1) / tw, mCw = ((1u << 20) + cw - 1) / cw;
     for (int i = tid; i < tw * th; i += 256) {
-        const int r = i / tw, c = i - r * tw;
+        const int r = (int)(((unsigned)i * mTw) >> 20), c = i - r * tw;
         s_tile[r * tp + c] = img[(size_t)(C.y0 - 3 + r) * pitch + (C.x0 - 3 + c)];
     }
     const int sp = cw + 2;
     for (int i = tid; i < sp * (ch + 2); i += 256) s_score[i] = 0;
-    if (tid < 2) s_cnt[tid] = 0;
+    if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
     const int npx = cw * ch;
-    for (int i = tid; i < npx; i += 256) {
-        const int r = i / cw, c = i - r * cw;
-        int s = fast_score16(&s_tile[(r + 3) * tp + c + 3], tp);
+    const int thQuick = min(P.iniTh, P.minTh);
+    for (int i0 = 0; i0 < npx; i0 += 256) {
+        const int i = i0 + tid;
+        bool cand = false;
+        if (i < npx) {
+            const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
+            cand = fast_candidate(&s_tile[(r + 3) * tp + c + 3], tp, thQuick);
+        }
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+            unsigned base = 0;
+            if ((tid & 63) == 0) base = atomicAdd(&s_cnt[2], (unsigned)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (cand) s_list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)i;
+        }
+    }
+    __syncthreads();
+    const int nlist = (int)s_cnt[2];
+    for (int j = tid; j < nlist; j += 256) {
+        const int i = s_list[j];
+        const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
+        const int s = fast_score16(&s_tile[(r + 3) * tp + c + 3], tp);
         s_score[(r + 1) * sp + c + 1] = (uint8_t)max(s, 0);
     }
     __syncthreads();
     // NMS + threshold flags: bit0 = kept at iniTh, bit1 = kept at minTh
     unsigned c_ini = 0, c_min = 0;
     for (int i = tid; i < npx; i += 256) {
-        const int r = i / cw, c = i - r * cw;
+        const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
         const uint8_t *q = &s_score[(r + 1) * sp + c + 1];
         const int s = q[0];
-        const bool lm = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] &&
-                        s > q[sp - 1] && s > q[sp] && s > q[sp + 1];
-        const int f = lm ? ((s >= P.iniTh ? 1 : 0) | (s >= P.minTh ? 2 : 0)) : 0;
+        int f = 0;
+        if (s >= thQuick) {
+            const bool lm = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] &&
+                            s > q[sp - 1] && s > q[sp] && s > q[sp + 1];
+            f = lm ? ((s >= P.iniTh ? 1 : 0) | (s >= P.minTh ? 2 : 0)) : 0;
+        }
         s_flag[i] = (uint8_t)f;
         c_ini += f & 1;
         c_min += (f >> 1) & 1;
@@ -193,7 +231,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
         unsigned tot;
         const unsigned pos = block_excl_scan(f, s_wave, &tot);
         if (f) {
-            const int r = i / cw, c = i - r * cw;
+            const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
             const unsigned kx = C.x0 + c - 16, ky = C.y0 + r - 16;  // border-frame coordinates (:773-774)
             out[base + pos] = kx | (ky << 12) | ((unsigned)s_score[(r + 1) * sp + c + 1] << 24);
         }

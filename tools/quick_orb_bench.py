@@ -19,7 +19,7 @@ for _ in range(K):
 ex.sync()
 dt = (time.time() - t) / K
 print(f"B={B}: {dt*1e3:.3f} ms/batch, {B/dt:.0f} fps, n={d_n[:4].tolist()}")
-ex.profile_enable(True)
+ex.profile_enable(-1)
 for _ in range(K):
     ex.extract_batch_device(d_img, d_kps, d_desc, d_n, B, 640, 480)
 prof = ex.profile_read()
