@@ -462,6 +462,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             active = false;
         }
     }
+    if (!__ballot(active)) return;   // all four seeds of the wave are skipped (stable or unused): nothing to gather
     const int spX = seedI % P.spW, spY = seedI / P.spW;
     const int xb0 = spX * SP + SP / 2 - SP, yb0 = spY * SP + SP / 2 - SP;
     const int xb = xb0 > 0 ? xb0 : 0, yb = yb0 > 0 ? yb0 : 0;
