@@ -435,6 +435,25 @@ __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
     if (P.tmin[(size_t)slot * P.nseeds + index[p]] <= (unsigned)p) index[p] = a;
 }
 
+// Four consecutive elements loaded as one access of whatever alignment the element type guarantees (global memory
+// tolerates dword-/byte-aligned wide loads).
+template <typename T> struct Quad { T v[4]; };
+template <typename T> __device__ __forceinline__ Quad<T> load_quad(const T *p) { Quad<T> q; __builtin_memcpy(&q, p, sizeof(q)); return q; }
+template <typename T> __device__ __forceinline__ Quad<T> load_quad(gptr<T> p) {
+    Quad<T> q;
+#pragma unroll
+    for (int e = 0; e < 4; e++) q.v[e] = p[e];
+    return q;
+}
+// Inclusive prefix sum over the 16 lanes of a DPP row (= one seed group); lanes without a source read 0.
+__device__ __forceinline__ int row_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    return v;
+}
+
 // kb_update_seeds (:428-515): 16 lanes per seed (lane = window row), 16 seeds per workgroup.
 // Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window
 // raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
@@ -469,28 +488,45 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     const int xe = (xb0 + SP * 2) < P.W - 1 ? (xb0 + SP * 2) : P.W - 1, ye = (yb0 + SP * 2) < P.H - 1 ? (yb0 + SP * 2) : P.H - 1;
     int sumX = 0, sumY = 0, sumI = 0, cnt = 0, nd = 0;
     {
-        // lane = window column, unrolled loop = window row: each load instruction reads 16 contiguous pixels per
-        // seed (coalesced); all 48 loads are issued up front with clamped addresses, ownership is resolved afterwards.
-        float dloc[16];
-        unsigned short idv[16];
-        uint8_t gv[16];
-        const int col = xb0 + l, colc = min(max(col, 0), P.W - 1);
-        const bool colOk = active && col >= xb && col < xe;
+        // Lane = (row r of a group of four window rows, quad q of four window columns): 12 wide loads per lane (8 B of
+        // index, 16 B of depth, 4 B of gray, four times) instead of 48 scalar ones.  Window columns start at a multiple
+        // of 4 and W is a multiple of 8, so a quad lies inside or outside the image as a whole.  Raster order of the
+        // window = (iteration, lane, element), which the ordered depth list below follows.
+        const int rq = l >> 2, cq = l & 3;
+        const int col0 = xb0 + 4 * cq;
+        const bool quadIn = col0 >= 0 && col0 + 3 < P.W;
+        const int colc = quadIn ? col0 : 0;
+        Quad<unsigned short> idq[4];
+        Quad<float> dq[4];
+        Quad<uint8_t> gq[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int jc = min(max(yb0 + k, 0), P.H - 1);
-            idv[k] = index[(size_t)jc * P.W + colc]; dloc[k] = F.depthG()[(size_t)jc * P.dstride + colc]; gv[k] = F.grayG()[(size_t)jc * P.gstride + colc];
+        for (int m = 0; m < 4; m++) {
+            const int jc = min(max(yb0 + 4 * m + rq, 0), P.H - 1);
+            idq[m] = load_quad(index + (size_t)jc * P.W + colc);
+            dq[m] = load_quad(F.depthG() + (size_t)jc * P.dstride + colc);
+            gq[m] = load_quad(F.grayG() + (size_t)jc * P.gstride + colc);
         }
-        const int gsh = (g & 3) * 16;
+        const int g15 = (threadIdx.x & 48) | 15;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {          // window raster order: row k, then the ballot's lane order = column order
-            const int j = yb0 + k;
-            const bool own = colOk && j >= yb && j < ye && idv[k] == seedI;
-            const bool hasd = own && dloc[k] > 0.1;
-            if (own) { sumX += col; sumY += j; sumI += gv[k]; cnt++; }
-            const unsigned gm = (unsigned)((__ballot(hasd) >> gsh) & 0xFFFFull);
-            if (hasd) s_depth[g][nd + __popc(gm & ((1u << l) - 1u))] = dloc[k];
-            nd += __popc(gm);
+        for (int m = 0; m < 4; m++) {
+            const int j = yb0 + 4 * m + rq;
+            const bool rowOk = active && quadIn && j >= yb && j < ye;
+            bool hd[4];
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int col = col0 + e;
+                const bool own = rowOk && col >= xb && col < xe && idq[m].v[e] == seedI;
+                hd[e] = own && dq[m].v[e] > 0.1;
+                if (own) { sumX += col; sumY += j; sumI += gq[m].v[e]; cnt++; }
+                c += hd[e] ? 1 : 0;
+            }
+            const int incl = row_incl_scan(c);
+            int o = nd + incl - c;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (hd[e]) s_depth[g][o++] = dq[m].v[e];
+            nd += __shfl(incl, g15, 64);
         }
     }
 #pragma unroll
