@@ -672,40 +672,43 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     memset(&S, 0, sizeof(S));
     if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
     const int xb = spX * SP + SP / 2 - SP, yb = spY * SP + SP / 2 - SP;
-    // ---- gather: lane = window column, unrolled loop = window row; unclipped window guarded by the flat index range
-    // (:680-684).  All loads (index, depth, right/down neighbours) are issued up front with clamped addresses. ----
+    // ---- gather: lane = (row r of a group of four window rows, quad q of four window columns), four iterations; the
+    // unclipped window is guarded by the flat index range (:680-684).  16 wide loads per lane: 8 B of index, 16 B of depth,
+    // 16 B of the row below, 4 B right of the quad (the other right neighbours are the quad's own elements). ----
     float maxDist = 0;
     int nvalid = 0, base = 0;
     {
-        float dv[16], dr[16], dd[16];
-        unsigned short idv[16];
-        // wrapped pixel (App. B.6) of the unclipped window position (yb + k, xb + l) without an integer division:
-        // a column left / right of the image belongs to the previous / next row of the flat index
-        const int cx0 = xb + l;
-        const int wrapRow = cx0 < 0 ? -1 : (cx0 >= P.W ? 1 : 0), wcol = cx0 - wrapRow * P.W;
+        const int rq = l >> 2, cq = l & 3;
+        // wrapped pixels (App. B.6) without an integer division: a quad left / right of the image (window columns start
+        // at a multiple of 4, W is a multiple of 8: never a partial quad) belongs to the previous / next row of the flat index
+        const int cx0 = xb + 4 * cq;
+        const int wrapRow = cx0 < 0 ? -1 : (cx0 >= P.W ? 1 : 0), wcol0 = cx0 - wrapRow * P.W;
+        Quad<unsigned short> idq[4];
+        Quad<float> dq[4], ddq[4];
+        float dr3[4];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int wr = yb + k + wrapRow;
-            // flat index clamped to [0, npx - 1]: rows above / below the image collapse onto the first / last pixel
-            const int row = wr < 0 ? 0 : (wr >= P.H ? P.H - 1 : wr), col = wr < 0 ? 0 : (wr >= P.H ? P.W - 1 : wcol);
-            const int pc = row * P.W + col;
-            idv[k] = index[pc];
-            dv[k] = F.depthG()[(size_t)row * P.dstride + col];
-            dr[k] = F.depthG()[(size_t)row * P.dstride + min(col + 1, P.W - 1)];
-            dd[k] = F.depthG()[(size_t)min(row + 1, P.H - 1) * P.dstride + col];
+        for (int m = 0; m < 4; m++) {
+            const int wr = yb + 4 * m + rq + wrapRow;
+            const int row = min(max(wr, 0), P.H - 1);     // rows outside the image fail the flat-index test below
+            idq[m] = load_quad(index + (size_t)row * P.W + wcol0);
+            dq[m] = load_quad(F.depthG() + (size_t)row * P.dstride + wcol0);
+            ddq[m] = load_quad(F.depthG() + (size_t)min(row + 1, P.H - 1) * P.dstride + wcol0);
+            dr3[m] = F.depthG()[(size_t)row * P.dstride + min(wcol0 + 4, P.W - 1)];
         }
-        unsigned vm = 0;   // bit k: pixel (row k of the window, this lane's column) is a valid-depth pixel of the seed
+        unsigned vm = 0;   // bit 4 m + e: pixel e of the quad in iteration m is a valid-depth pixel of the seed
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int i = xb + l, jrow = yb + k;
-            const int pixelIndex = jrow * P.W + i;
-            if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && idv[k] == seedI) {
-                const float xDiff = i - S.x, yDiff = jrow - S.y;
-                const float dist = xDiff * xDiff + yDiff * yDiff;
-                if (dist > maxDist) maxDist = dist;
-                if (dv[k] > 0.05) vm |= 1u << k;
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int i = xb + 4 * cq + e, jrow = yb + 4 * m + rq;
+                const int pixelIndex = jrow * P.W + i;
+                if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && idq[m].v[e] == seedI) {
+                    const float xDiff = i - S.x, yDiff = jrow - S.y;
+                    const float dist = xDiff * xDiff + yDiff * yDiff;
+                    if (dist > maxDist) maxDist = dist;
+                    if (dq[m].v[e] > 0.05) vm |= 1u << (4 * m + e);
+                }
             }
-        }
         nvalid = __popc(vm);
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
@@ -714,17 +717,23 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64);
             base = g == 0 ? 0 : g == 1 ? n0 : g == 2 ? n0 + n1 : n0 + n1 + n2;
         }
-        const int gsh = g * 16;
+        const int g15 = (lane & 48) | 15;
         int run = base;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const bool valid = (vm >> k) & 1u;
-            const unsigned gm = (unsigned)((__ballot(valid) >> gsh) & 0xFFFFull);
-            if (valid) {   // ordered compaction of the raw valid pixels: depth, right depth, down depth, pixel index
-                const int o = run + __popc(gm & ((1u << l) - 1u));
-                s_pool[2][o] = dv[k]; s_pool[3][o] = dr[k]; s_pool[4][o] = dd[k]; s_pool[5][o] = __int_as_float(((yb + k + wrapRow) << 16) | wcol);
-            }
-            run += __popc(gm);
+        for (int m = 0; m < 4; m++) {   // ordered compaction in window raster order = (iteration, lane, element)
+            const unsigned q = (vm >> (4 * m)) & 0xFu;
+            const int c = __popc(q);
+            const int incl = row_incl_scan(c);
+            int o = run + incl - c;
+            const int rc = ((yb + 4 * m + rq + wrapRow) << 16) | wcol0;   // a valid pixel lies inside the image
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (q & (1u << e)) {   // depth, right depth, down depth, (row, col)
+                    s_pool[2][o] = dq[m].v[e]; s_pool[3][o] = e < 3 ? dq[m].v[e < 3 ? e + 1 : 3] : dr3[m];
+                    s_pool[4][o] = ddq[m].v[e]; s_pool[5][o] = __int_as_float(rc + e);
+                    o++;
+                }
+            run += __shfl(incl, g15, 64);
         }
     }
     float *const pX = s_pool[0] + base, *const pY = s_pool[1] + base, *const pZ = s_pool[2] + base;
