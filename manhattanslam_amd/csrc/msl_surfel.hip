@@ -44,7 +44,8 @@ constexpr unsigned T_INF = 0xFFFFFFFFu;
 constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
-constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup chunk in the map-stage kernels
+constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-stage kernels
+constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted-slot partials
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
 // surfel's fate for the ~90 % that leave early) and touches the 36-byte cold record of the few it updates; an update
@@ -971,12 +972,15 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
     // One 4 KB list per workgroup keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
-    __shared__ unsigned s_cnt[5];
+    // Each wave owns one sub-block of 256 consecutive surfels, and the four waves of a workgroup take theirs from four
+    // different quarters of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
+    // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
+    __shared__ unsigned s_cnt[5], s_delSub[4];
     __shared__ unsigned s_surv[SCAN_ITEMS];
     __shared__ unsigned s_delBase;
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
-    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + 3) / 4;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
@@ -984,13 +988,23 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     static_assert(SCAN_ITEMS == 1024, "4 consecutive surfels per thread x 256 threads");
-    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int wv = threadIdx.x >> 6;
+    for (long long b = blockIdx.x; b < nW; b += gridDim.x) {
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 4) s_delSub[threadIdx.x] = 0;
         __syncthreads();
         unsigned nupd = 0;
-        const long long c0 = b * SCAN_ITEMS;
-        auto mark_deleted = [&](long long i) { s_surv[SCAN_ITEMS - 1 - atomicAdd(&s_cnt[0], 1u)] = (unsigned)(i - c0); };
-        const long long i0 = c0 + 4 * threadIdx.x;     // map capacity is a multiple of 4096: the 16-byte loads stay in bounds
+        // local index (10 bits) = wave << 8 | offset in the wave's sub-block
+        auto sub_base = [&](unsigned w) -> long long { return ((long long)w * nW + b) * SUB_ITEMS; };
+        auto global_of = [&](unsigned local) -> long long { return sub_base(local >> 8) + (local & 0xFFu); };
+        const long long c0 = sub_base(wv);
+        auto mark_deleted = [&](long long i) {
+            s_surv[SCAN_ITEMS - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
+            atomicAdd(&s_delSub[wv], 1u);
+        };
+        const bool hasSub = (long long)wv * nW + b < nSub;   // the last workgroups may own fewer than four sub-blocks
+        // map capacity is a multiple of 4096: the 16-byte loads of an existing sub-block stay in bounds
+        const long long i0 = (hasSub ? c0 : 0) + 4 * (threadIdx.x & 63);
         {
             const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
             uint4 q[5];
@@ -1020,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
                 const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
                 const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
                 int st = 0;
-                if (i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+                if (hasSub && i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
                 state[k] = st; pzv[k] = pc[2];
                 const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
                 offD[k] = (unsigned)pVc * (unsigned)P.dstride + (unsigned)pUc;   // images are far below 2^32 elements
@@ -1038,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
                 if (state[k] == 1) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
                 if (state[k] == 2) { mark_deleted(i); continue; }
                 if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = (unsigned)(i - c0) | (spi[k] << 16);
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (spi[k] << 16);
             }
         }
         __syncthreads();
@@ -1046,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         unsigned ndelB = 0;
         for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
             const unsigned sv = s_surv[sidx];
-            const long long i = c0 + (sv & 0xFFFFu);
+            const long long i = global_of(sv & 0xFFFFu);
             const int spIndex = (int)(sv >> 16);
             // seed, hot record (just streamed by this workgroup: cache hit) and cold record in ONE round trip; the cold
             // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
@@ -1066,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
             float nc[3];
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; ndelB++; continue; }
+            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
             const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
@@ -1101,21 +1115,22 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
         const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
+        if (threadIdx.x < 4 && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
         if (threadIdx.x == 0) {
-            P.blockSums[b] = ndelBlk; P.blockUpd[b] = s_cnt[1];
+            P.blockUpd[b] = s_cnt[1];
             if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per chunk that deleted something
         }
         __syncthreads();
         if (ndelBlk) {
             const unsigned base = s_delBase;
             for (unsigned j = threadIdx.x; j < ndelA; j += 256)
-                if (base + j < LIST_D) P.delU[base + j] = (unsigned)(c0 + s_surv[SCAN_ITEMS - 1 - j]);
+                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[SCAN_ITEMS - 1 - j]);
             if (ndelBlk != ndelA)
                 for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
                     const unsigned sv = s_surv[sidx];
                     if ((sv >> 16) != 0xFFFFu) continue;
                     const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
-                    if (j < LIST_D) P.delU[j] = (unsigned)(c0 + (sv & 0xFFFFu));
+                    if (j < LIST_D) P.delU[j] = (unsigned)global_of(sv & 0xFFFFu);
                 }
         }
         __syncthreads();
@@ -1153,8 +1168,8 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     __shared__ unsigned s_wave[33];
     __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
     __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
-    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk, s_extra;
-    __shared__ unsigned short s_nzList[SMALL_CHUNKS];   // the chunks that contain deletions
+    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk;
+    __shared__ unsigned s_nzIdx[SMALL_CHUNKS], s_nzCnt[SMALL_CHUNKS], s_nzSortIdx[SMALL_CHUNKS], s_nzSortCnt[SMALL_CHUNKS];   // sub-blocks with deletions
     __shared__ int s_fallback;
     __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
@@ -1196,32 +1211,32 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         const unsigned long long m1 = emit & (emit - 1);
         if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
     }
-    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    const bool oneTile = nblk <= TILE;
+    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
+    const long long nWg = (nblk + 3) / 4;                      // k_fuse workgroups (blockUpd entries)
     s_raw[threadIdx.x] = du;
-    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; s_extra = 0; }
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
-    // ---- per-chunk deleted counts of the first tile (4 consecutive chunks per thread) + everything beyond it ----
-    unsigned v[4];
-    {
-        const long long c = 4 * threadIdx.x;
-        v[0] = c < nblk ? bs0.x : 0u; v[1] = c + 1 < nblk ? bs0.y : 0u; v[2] = c + 2 < nblk ? bs0.z : 0u; v[3] = c + 3 < nblk ? bs0.w : 0u;
-    }
-    if (oneTile) {
+    // ---- pass over the per-sub-block deleted counts (4 consecutive per thread and tile): total, and the list of the
+    // sub-blocks that contain deletions ----
+    unsigned vsum = 0;
+    for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+        const long long c = t0 + 4 * threadIdx.x;
+        const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+        const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (v[j] > 0) { const unsigned q = atomicAdd(&s_nzChunks, 1u); if (q < SMALL_CHUNKS) s_nzList[q] = (unsigned short)(4 * threadIdx.x + j); }
-    } else {
-        unsigned extra = 0;
-        for (long long c2 = TILE + threadIdx.x; c2 < nblk; c2 += NT) extra += P.blockSums[c2];
-        if (extra) atomicAdd(&s_extra, extra);
+            if (x[j] > 0) {
+                vsum += x[j];
+                const unsigned q = atomicAdd(&s_nzChunks, 1u);
+                if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
+            }
     }
-    unsigned tot0, Ku, ex0, pos;
-    block_excl_scan_pair(v[0] + v[1] + v[2] + v[3], cnt, s_wave, &tot0, &Ku, ex0, pos);   // chunk scan of tile 0 + emission scan
-    const long long D = (long long)tot0 + s_extra;
+    unsigned Dtot, Ku, exUnused, pos;
+    block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
+    const long long D = Dtot;
     // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
     const bool fastest = mode == 0 && D <= LIST_D;     // k_fuse already handed over the (few) deleted slots, unordered
-    const bool small = mode == 0 && !fastest && oneTile && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
+    const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
     const bool single = fastest || small;
     if (single && blockIdx.x != 0) return;
     if (mode == 0 && !bad) {
@@ -1231,22 +1246,39 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                 for (unsigned j = 0; j < (unsigned)D; j++) r += s_raw[j] < du ? 1u : 0u;
                 s_dl[r] = du;
             }
+        } else if (small) {
+            // few sub-blocks hold all deletions: order them by index (rank sort); a sub-block's offset in the ascending
+            // list is the sum of the counts before it -- no scan over the (thousands of) empty sub-blocks
+            const unsigned nz = s_nzChunks;
+            if (threadIdx.x < nz) {
+                const unsigned me = s_nzIdx[threadIdx.x];
+                unsigned r = 0;
+                for (unsigned j = 0; j < nz; j++) r += s_nzIdx[j] < me ? 1u : 0u;
+                s_nzSortIdx[r] = me; s_nzSortCnt[r] = s_nzCnt[threadIdx.x];
+            }
+            __syncthreads();
+            unsigned base = 0;
+            for (unsigned it = 0; it < nz; it++) {
+                const long long i0 = (long long)s_nzSortIdx[it] * SUB_ITEMS + threadIdx.x;   // one slot per thread: ascending
+                const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
+                unsigned tt;
+                const unsigned w = base + block_excl_scan(f, s_wave, &tt);
+                if (f) s_dl[w] = (unsigned)i0;
+                base += s_nzSortCnt[it];
+            }
         } else {
-            // every workgroup lists the deleted slots of its own chunks in ascending order; a chunk's base offset lives
-            // in the registers of the thread that scanned it and is broadcast through one LDS word
+            // every workgroup lists the deleted slots of its own sub-blocks in ascending order; a sub-block's base offset
+            // lives in the registers of the thread that scanned it and is broadcast through one LDS word
             unsigned carry = 0;
             for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-                unsigned ex, tot;
-                if (t0 == 0) { ex = ex0; tot = tot0; }
-                else {
-                    const long long c = t0 + 4 * threadIdx.x;
-                    const uint4 v4 = *reinterpret_cast<const uint4 *>(P.blockSums + c);
-                    v[0] = c < nblk ? v4.x : 0u; v[1] = c + 1 < nblk ? v4.y : 0u; v[2] = c + 2 < nblk ? v4.z : 0u; v[3] = c + 3 < nblk ? v4.w : 0u;
-                    ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
-                }
-                const long long nIter = small ? (long long)s_nzChunks : (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
+                const long long c = t0 + 4 * threadIdx.x;
+                const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+                const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+                unsigned tot;
+                const unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+                const long long nIter = (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
                 for (long long it = 0; it < nIter; it++) {
-                    const long long b = small ? t0 + s_nzList[it] : t0 + blockIdx.x + it * gridDim.x;
+                    const long long b = t0 + blockIdx.x + it * gridDim.x;
                     const int q = (int)(b - t0);
                     if ((int)threadIdx.x == (q >> 2)) {
                         const int comp = q & 3;
@@ -1255,16 +1287,12 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                     }
                     __syncthreads();
                     const unsigned base = s_base, cntChunk = s_cntChunk;
-                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this chunk
-                    const long long i0 = b * SCAN_ITEMS + 4 * threadIdx.x;   // 4 consecutive slots per thread keep the list ascending
-                    unsigned f[4], c4 = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { f[j] = (i0 + j < n && P.map.hot[i0 + j].updateTimes == 0) ? 1u : 0u; c4 += f[j]; }
+                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this sub-block
+                    const long long i0 = b * SUB_ITEMS + threadIdx.x;       // one slot per thread keeps the list ascending
+                    const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
                     unsigned tt;
-                    unsigned w = base + block_excl_scan(c4, s_wave, &tt);   // (its barriers also protect s_base)
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (f[j]) { if (small) s_dl[w++] = (unsigned)(i0 + j); else st_agent(&P.delList[w++], (unsigned)(i0 + j)); }
+                    const unsigned w = base + block_excl_scan(f, s_wave, &tt);   // (its barriers also protect s_base)
+                    if (f) st_agent(&P.delList[w], (unsigned)i0);
                 }
                 carry += tot;
                 __syncthreads();
@@ -1277,8 +1305,8 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     // updated count
     {
         const long long c = 4 * threadIdx.x;
-        unsigned u = (c < nblk ? bu0.x : 0u) + (c + 1 < nblk ? bu0.y : 0u) + (c + 2 < nblk ? bu0.z : 0u) + (c + 3 < nblk ? bu0.w : 0u);
-        for (long long c2 = TILE + threadIdx.x; c2 < nblk; c2 += blockDim.x) u += P.blockUpd[c2];
+        unsigned u = (c < nWg ? bu0.x : 0u) + (c + 1 < nWg ? bu0.y : 0u) + (c + 2 < nWg ? bu0.z : 0u) + (c + 3 < nWg ? bu0.w : 0u);
+        for (long long c2 = TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
         if (u) atomicAdd(&s_upd, u);
     }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
@@ -1495,9 +1523,9 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
-    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));   // >= 1024 entries: k_new_scan reads its first tile unconditionally
+    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: k_compact reads its first tile unconditionally
     MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
-    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
     MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
     MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
