@@ -57,12 +57,16 @@ constexpr int WAVE = 64;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        unsigned t = __shfl_up(v, d, 64);
-        if (lane_id() >= d) v += t;
-    }
-    return v;
+    // DPP scan (VALU only, no LDS crossbar round trips): Hillis-Steele inside each row of 16 lanes, then the row totals
+    // are carried over with row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  Lanes without a source add 0.
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return (unsigned)x;
 }
 
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).

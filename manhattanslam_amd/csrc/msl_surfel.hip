@@ -1178,6 +1178,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     const uint4 bu0 = *reinterpret_cast<const uint4 *>(P.blockUpd + 4 * threadIdx.x);    // (arrays are padded by >= 1024 zeroed entries)
     static_assert(LIST_D == NT, "one hand-over entry per thread");
     const unsigned du = P.delU[threadIdx.x];
+    const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
     const long long n = P.ctr[0];
     const bool bad = P.ctr[5] == 20;
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
@@ -1216,26 +1217,28 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
-    // ---- pass over the per-sub-block deleted counts (4 consecutive per thread and tile): total, and the list of the
-    // sub-blocks that contain deletions ----
+    // k_fuse already counted the deleted slots; when they all fit its hand-over list (the steady state) the per-sub-block
+    // counts are not needed at all.  Otherwise one pass over them (4 consecutive per thread and tile) lists the sub-blocks
+    // that contain deletions.
+    const bool fastest = mode == 0 && dHand <= LIST_D;
     unsigned vsum = 0;
-    for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-        const long long c = t0 + 4 * threadIdx.x;
-        const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
-        const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+    if (!fastest)
+        for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+            const long long c = t0 + 4 * threadIdx.x;
+            const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+            const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (x[j] > 0) {
-                vsum += x[j];
-                const unsigned q = atomicAdd(&s_nzChunks, 1u);
-                if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
-            }
-    }
+            for (int j = 0; j < 4; j++)
+                if (x[j] > 0) {
+                    vsum += x[j];
+                    const unsigned q = atomicAdd(&s_nzChunks, 1u);
+                    if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
+                }
+        }
     unsigned Dtot, Ku, exUnused, pos;
     block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
-    const long long D = Dtot;
+    const long long D = fastest ? (long long)dHand : (long long)Dtot;
     // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
-    const bool fastest = mode == 0 && D <= LIST_D;     // k_fuse already handed over the (few) deleted slots, unordered
     const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
     const bool single = fastest || small;
     if (single && blockIdx.x != 0) return;
