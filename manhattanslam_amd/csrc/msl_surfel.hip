@@ -426,14 +426,28 @@ __global__ __launch_bounds__(256) void kb_prop_lds(SfDev P) {
 }
 
 __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
+    // 8 consecutive pixels per thread (16-byte loads of both maps; npx is a multiple of 64).  A pixel whose pick equals its
+    // current seed cannot change, so t(s) is only looked up for the few pixels that picked a different seed.
     int slot, blk;
-    if (!xcd_slot((P.npx + 255) / 256, nSlots, slot, blk)) return;
-    const int p = blk * 256 + threadIdx.x;
-    if (p >= P.npx) return;
+    if (!xcd_slot((P.npx / 8 + 255) / 256, nSlots, slot, blk)) return;
+    const int p0 = (blk * 256 + threadIdx.x) * 8;
+    if (p0 >= P.npx) return;
     unsigned short *index = P.index + (size_t)slot * P.npx;
-    const unsigned short a = P.amap[(size_t)slot * P.npx + p];
-    if (a >= IDX_PLANE) return;
-    if (P.tmin[(size_t)slot * P.nseeds + index[p]] <= (unsigned)p) index[p] = a;
+    const uint4 a4 = *reinterpret_cast<const uint4 *>(P.amap + (size_t)slot * P.npx + p0);
+    uint4 i4 = *reinterpret_cast<const uint4 *>(index + p0);
+    const unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
+    unsigned aw[4] = {a4.x, a4.y, a4.z, a4.w}, iw[4] = {i4.x, i4.y, i4.z, i4.w};
+    bool changed = false;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const unsigned a = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, cur = (iw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        if (a >= IDX_PLANE || a == cur) continue;
+        if (tmin[cur] <= (unsigned)(p0 + k)) {
+            iw[k >> 1] = (iw[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (a << (16 * (k & 1)));
+            changed = true;
+        }
+    }
+    if (changed) { i4.x = iw[0]; i4.y = iw[1]; i4.z = iw[2]; i4.w = iw[3]; *reinterpret_cast<uint4 *>(index + p0) = i4; }
 }
 
 // Four consecutive elements loaded as one access of whatever alignment the element type guarantees (global memory
@@ -1683,7 +1697,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 seedGrid((D.nseeds + 255) / 256, un);
-    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid((D.npx + 255) / 256, n));
+    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid((D.npx / 8 + 255) / 256, n));
     LAUNCH(SK_SEED_INIT, sp, kb_seed_init, seedGrid, dim3(256), P);
     for (int it = 0; it < 3; it++) {
         LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
