@@ -490,9 +490,14 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     if (active) {
         S = P.seeds[(size_t)slot * P.nseeds + seedI];
         stable = it > 0 ? (P.tmin[(size_t)slot * P.nseeds + seedI] == T_INF) : (S.stable != 0);
-        // seedsTmp[]._pad: 0 = skipped (old seed with the post-pixel-pass stable flag), 1 = chunk abort, 2 = processed
+        // Seeds are updated in place.  A processed seed first saves its old record in seedsTmp[] (marked _pad = 2), so the
+        // commit pass can restore it when the chunk turns out to have ended earlier; everyone else clears that mark.
         if (!S.use || stable) {
-            if (l == 0) { msl_seed t = S; t.stable = stable; t._pad = 0; P.seedsTmp[(size_t)slot * P.nseeds + seedI] = t; }
+            if (l == 0) {   // skipped: only the stable flag (as left by the pixel pass) and t(s) change
+                P.seeds[(size_t)slot * P.nseeds + seedI].stable = stable;
+                P.seedsTmp[(size_t)slot * P.nseeds + seedI]._pad = 0;
+                P.tmin[(size_t)slot * P.nseeds + seedI] = stable ? T_INF : 0u;
+            }
             active = false;
         }
     }
@@ -551,13 +556,12 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     }
     __builtin_amdgcn_wave_barrier();
     msl_seed T = S;
-    T._pad = 2;
-    bool depthLoop = false;
+    bool depthLoop = false, aborted = false;
     if (l == 0) {
         if (active) {
-            if (cnt == 0) {  // `return`: ends the chunk (:473-474)
+            if (cnt == 0) {  // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable
                 atomicMin(&P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)], seedI);
-                T.stable = 0; T._pad = 1;
+                aborted = true;
             } else {
                 const float sumIntensityNum = (float)cnt;
                 const float sumIntensity = (float)sumI / sumIntensityNum, mX = (float)sumX / sumIntensityNum, mY = (float)sumY / sumIntensityNum;
@@ -604,26 +608,37 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         __builtin_amdgcn_wave_barrier();
     }
     if (active && l == 0) {
-        if (depthLoop) T.meanDepth = s_mean[g];
-        P.seedsTmp[(size_t)slot * P.nseeds + seedI] = T;
+        const size_t si = (size_t)slot * P.nseeds + seedI;
+        if (aborted) {
+            P.seeds[si].stable = 0; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
+        } else {
+            if (depthLoop) T.meanDepth = s_mean[g];
+            msl_seed old = S;
+            old._pad = 2;
+            P.seedsTmp[si] = old;
+            T._pad = 0;
+            P.seeds[si] = T;
+            P.tmin[si] = T.stable ? T_INF : 0u;
+            P.invDepth[si] = T.meanDepth > 0 ? 1.0 / (double)T.meanDepth : 0.0;
+        }
     }
 }
 
-// kb_commit_seeds: apply the chunk-abort rule and prepare t(s) for the next pixel pass.
+// kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
+// although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
 __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;
     if (seedI >= P.nseeds) return;
     if (seedI == 0) P.wlCount[slot] = 0;   // the next pixel pass rebuilds the relaxation worklist
-    const msl_seed T = P.seedsTmp[(size_t)slot * P.nseeds + seedI];
-    msl_seed out;
-    if (T._pad == 0) out = T;                                                                                          // skipped
-    else if (T._pad == 2 && seedI < P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)]) out = T;  // processed
-    else { out = P.seeds[(size_t)slot * P.nseeds + seedI]; out.stable = 0; }   // chunk ended earlier: values untouched, unstable
-    out._pad = 0;
-    P.seeds[(size_t)slot * P.nseeds + seedI] = out;
-    P.tmin[(size_t)slot * P.nseeds + seedI] = out.stable ? T_INF : 0u;
-    P.invDepth[(size_t)slot * P.nseeds + seedI] = out.meanDepth > 0 ? 1.0 / (double)out.meanDepth : 0.0;
+    if (seedI < P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)]) return;
+    const size_t si = (size_t)slot * P.nseeds + seedI;
+    if (P.seedsTmp[si]._pad != 2) return;   // skipped, or the seed that ended the chunk: already as it should be
+    msl_seed out = P.seedsTmp[si];
+    out.stable = 0; out._pad = 0;
+    P.seeds[si] = out;
+    P.tmin[si] = 0u;
+    P.invDepth[si] = out.meanDepth > 0 ? 1.0 / (double)out.meanDepth : 0.0;
 }
 
 // kb_seed_plane: calculateNorms (:775-803) fused per seed, 16 lanes per seed, 4 seeds per wave/workgroup.
