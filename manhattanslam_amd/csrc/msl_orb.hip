@@ -106,29 +106,27 @@ __global__ __launch_bounds__(256) void k_resize(OrbDev P, int l) {
 // ---------------------------------------------------------------------------------------------
 // k_fast: one workgroup (256 threads) per FAST cell.
 // ---------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ int fast_score16(const uint8_t *t, int tp) {
-    // t points at the centre pixel inside the LDS tile (pitch tp)
+    // t points at the centre pixel inside the LDS tile (pitch tp).
+    // score = max(a, -b) - 1 with a = max over the 16 nine-arcs of min(d), b = min over arcs of max(d); since
+    // -b = max over arcs of min(-d), both halves are the same min/max network: run it once on packed (d, -d) pairs.
     const int v = t[0];
-    int d[16];
-    d[0] = v - t[3 * tp];          d[1] = v - t[3 * tp + 1];   d[2] = v - t[2 * tp + 2];   d[3] = v - t[tp + 3];
-    d[4] = v - t[3];               d[5] = v - t[-tp + 3];      d[6] = v - t[-2 * tp + 2];  d[7] = v - t[-3 * tp + 1];
-    d[8] = v - t[-3 * tp];         d[9] = v - t[-3 * tp - 1];  d[10] = v - t[-2 * tp - 2]; d[11] = v - t[-tp - 3];
-    d[12] = v - t[-3];             d[13] = v - t[tp - 3];      d[14] = v - t[2 * tp - 2];  d[15] = v - t[3 * tp - 1];
-    // a = max over the 16 nine-arcs of min(d), b = min over arcs of max(d)  (score = max(a, -b) - 1)
-    int lo2[16], hi2[16], lo4[16], hi4[16];
+    const int ring[16] = {t[3 * tp], t[3 * tp + 1], t[2 * tp + 2], t[tp + 3], t[3], t[-tp + 3], t[-2 * tp + 2], t[-3 * tp + 1],
+                          t[-3 * tp], t[-3 * tp - 1], t[-2 * tp - 2], t[-tp - 3], t[-3], t[tp - 3], t[2 * tp - 2], t[3 * tp - 1]};
+    s16x2 x[16], lo2[16], lo4[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; k++) { const int d = v - ring[k]; x[k] = (s16x2){(short)d, (short)-d}; }
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-    int a = -256, b = 256;
+    for (int k = 0; k < 16; k++) lo2[k] = pk_min(x[k], x[(k + 1) & 15]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);
-        int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        a = max(a, lo9);
-        b = min(b, hi9);
-    }
-    return max(a, -b) - 1;
+    for (int k = 0; k < 16; k++) lo4[k] = pk_min(lo2[k], lo2[(k + 2) & 15]);
+    s16x2 a = (s16x2){(short)-256, (short)-256};
+#pragma unroll
+    for (int k = 0; k < 16; k++) a = pk_max(a, pk_min(pk_min(lo4[k], lo4[(k + 4) & 15]), x[(k + 8) & 15]));
+    return max((int)a.x, (int)a.y) - 1;
 }
 
 // Quick rejection (the classic FAST high-speed test on the 4 even opposite pairs): a 9-arc of 16 contains at least one pixel
@@ -147,7 +145,7 @@ __device__ __forceinline__ bool fast_candidate(const uint8_t *t, int tp, int th)
 __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
     __shared__ uint8_t s_tile[(MAXCELL + 6) * (MAXCELL + 8)];
     __shared__ uint8_t s_score[(MAXCELL + 2) * (MAXCELL + 2)];
-    __shared__ uint8_t s_flag[MAXCELL * MAXCELL];
+    __shared__ unsigned s_bits[2][MAXCELL * MAXCELL / 32];   // kept-pixel bitmaps: [0] at iniTh, [1] at minTh
     __shared__ unsigned short s_list[MAXCELL * MAXCELL];   // pixels that pass the quick test
     __shared__ unsigned s_wave[17];
     __shared__ unsigned s_cnt[3];
@@ -171,6 +169,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
     }
     const int sp = cw + 2;
     for (int i = tid; i < sp * (ch + 2); i += 256) s_score[i] = 0;
+    if (tid < MAXCELL * MAXCELL / 32) { s_bits[0][tid] = 0; s_bits[1][tid] = 0; }
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
     const int npx = cw * ch;
@@ -199,43 +198,40 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
         s_score[(r + 1) * sp + c + 1] = (uint8_t)max(s, 0);
     }
     __syncthreads();
-    // NMS + threshold flags: bit0 = kept at iniTh, bit1 = kept at minTh
+    // NMS + threshold flags over the candidates only (everything else scores 0): one bit per pixel and threshold
     unsigned c_ini = 0, c_min = 0;
-    for (int i = tid; i < npx; i += 256) {
+    for (int j = tid; j < nlist; j += 256) {
+        const int i = s_list[j];
         const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
         const uint8_t *q = &s_score[(r + 1) * sp + c + 1];
         const int s = q[0];
-        int f = 0;
-        if (s >= thQuick) {
-            const bool lm = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] &&
-                            s > q[sp - 1] && s > q[sp] && s > q[sp + 1];
-            f = lm ? ((s >= P.iniTh ? 1 : 0) | (s >= P.minTh ? 2 : 0)) : 0;
-        }
-        s_flag[i] = (uint8_t)f;
-        c_ini += f & 1;
-        c_min += (f >> 1) & 1;
+        if (s < thQuick) continue;
+        const bool lm = s > q[-1] && s > q[1] && s > q[-sp - 1] && s > q[-sp] && s > q[-sp + 1] &&
+                        s > q[sp - 1] && s > q[sp] && s > q[sp + 1];
+        if (!lm) continue;
+        if (s >= P.iniTh) { atomicOr(&s_bits[0][i >> 5], 1u << (i & 31)); c_ini++; }   // kept at iniTh
+        if (s >= P.minTh) { atomicOr(&s_bits[1][i >> 5], 1u << (i & 31)); c_min++; }   // kept at minTh
     }
     if (c_ini) atomicAdd(&s_cnt[0], c_ini);
     if (c_min) atomicAdd(&s_cnt[1], c_min);
     __syncthreads();
-    const int bit = s_cnt[0] ? 1 : 2;  // fallback to minTh when nothing survives at iniTh (:766-769)
+    const int sel = s_cnt[0] ? 0 : 1;  // fallback to minTh when nothing survives at iniTh (:766-769)
     const unsigned total = s_cnt[0] ? s_cnt[0] : s_cnt[1];
     if (tid == 0) *cnt_out = total;
     if (total == 0) return;
-    // ordered compaction, row-major inside the cell
+    // ordered compaction, row-major inside the cell: thread t owns the 32 pixels of bitmap word t; its keys follow those
+    // of the lower words (one scan of the word popcounts) in ascending bit order
     uint32_t *out = P.cellKeys + (size_t)frame * P.keysPerFrame + C.keyOff;
-    unsigned base = 0;
-    for (int i0 = 0; i0 < npx; i0 += 256) {
-        const int i = i0 + tid;
-        const unsigned f = (i < npx && (s_flag[i] & bit)) ? 1u : 0u;
-        unsigned tot;
-        const unsigned pos = block_excl_scan(f, s_wave, &tot);
-        if (f) {
-            const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
-            const unsigned kx = C.x0 + c - 16, ky = C.y0 + r - 16;  // border-frame coordinates (:773-774)
-            out[base + pos] = kx | (ky << 12) | ((unsigned)s_score[(r + 1) * sp + c + 1] << 24);
-        }
-        base += tot;
+    static_assert(MAXCELL * MAXCELL / 32 <= 256, "one bitmap word per thread");
+    unsigned word = tid < MAXCELL * MAXCELL / 32 ? s_bits[sel][tid] : 0u;
+    unsigned tot;
+    unsigned pos = block_excl_scan((unsigned)__popc(word), s_wave, &tot);
+    while (word) {
+        const int i = tid * 32 + __builtin_ctz(word);
+        word &= word - 1;
+        const int r = (int)(((unsigned)i * mCw) >> 20), c = i - r * cw;
+        const unsigned kx = C.x0 + c - 16, ky = C.y0 + r - 16;  // border-frame coordinates (:773-774)
+        out[pos++] = kx | (ky << 12) | ((unsigned)s_score[(r + 1) * sp + c + 1] << 24);
     }
 }
 
