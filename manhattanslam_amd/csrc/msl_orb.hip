@@ -508,8 +508,11 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 }
 
 __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
-    __shared__ uint8_t s_in[(BT_H + 6) * (BT_W + 8)];
-    __shared__ unsigned short s_row[(BT_H + 6) * BT_W];
+    // 64 x 32 output tile, four horizontally adjacent pixels per thread in both passes: dword traffic to LDS and memory
+    // instead of bytes.  Arithmetic as before: u16 row sums (<= 65535), 32-bit column sums, (acc + 32768) >> 16.
+    constexpr int IP = BT_W + 8;                                   // staged bytes per row: x = tx0 - 4 .. tx0 + 67
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[(BT_H + 6) * IP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_row[(BT_H + 6) * BT_W];
     const int frame = blockIdx.y, tid = threadIdx.x;
     int l = 0;
     while (l + 1 < P.nlevels && (int)blockIdx.x >= P.lv[l + 1].tileBase) l++;
@@ -518,27 +521,57 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
     const int tx0 = (t % D.tilesX) * BT_W, ty0 = (t / D.tilesX) * BT_H;
     int pitch;
     const uint8_t *img = level_ptr(P, frame, l, pitch);
-    constexpr int IP = BT_W + 8;
-    for (int i = tid; i < (BT_H + 6) * (BT_W + 6); i += 256) {
-        const int r = i / (BT_W + 6), c = i - r * (BT_W + 6);
-        const int y = reflect101(ty0 + r - 3, D.h), x = reflect101(tx0 + c - 3, D.w);
-        s_in[r * IP + c] = img[(size_t)y * pitch + x];
+    if (tx0 >= 4 && tx0 + BT_W + 4 <= D.w && ty0 >= 3 && ty0 + BT_H + 3 <= D.h) {
+        // interior tile: 18 dwords per row, no reflection
+        for (int i = tid; i < (BT_H + 6) * (IP / 4); i += 256) {
+            const int r = i / (IP / 4), q = i - r * (IP / 4);
+            unsigned v;
+            __builtin_memcpy(&v, img + (size_t)(ty0 - 3 + r) * pitch + (tx0 - 4 + 4 * q), 4);
+            reinterpret_cast<unsigned *>(s_in)[r * (IP / 4) + q] = v;
+        }
+    } else {
+        for (int i = tid; i < (BT_H + 6) * IP; i += 256) {
+            const int r = i / IP, c = i - r * IP;
+            const int y = reflect101(ty0 + r - 3, D.h), x = reflect101(tx0 + c - 4, D.w);
+            s_in[i] = img[(size_t)y * pitch + x];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < (BT_H + 6) * BT_W; i += 256) {
-        const int r = i / BT_W, c = i - r * BT_W;
-        const uint8_t *p = &s_in[r * IP + c];
-        s_row[i] = (unsigned short)(18 * (p[0] + p[6]) + 34 * (p[1] + p[5]) + 49 * (p[2] + p[4]) + 55 * p[3]);
+    for (int i = tid; i < (BT_H + 6) * (BT_W / 4); i += 256) {
+        const int r = i / (BT_W / 4), j = i - r * (BT_W / 4);
+        const unsigned *p = reinterpret_cast<const unsigned *>(s_in) + r * (IP / 4) + j;
+        const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
+        const int bb[12] = {(int)(w0 & 255), (int)((w0 >> 8) & 255), (int)((w0 >> 16) & 255), (int)(w0 >> 24),
+                            (int)(w1 & 255), (int)((w1 >> 8) & 255), (int)((w1 >> 16) & 255), (int)(w1 >> 24),
+                            (int)(w2 & 255), (int)((w2 >> 8) & 255), (int)((w2 >> 16) & 255), (int)(w2 >> 24)};
+        unsigned o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++)   // output column 4 j + k reads staged bytes 4 j + k + 1 .. + 7
+            o[k] = (unsigned)(18 * (bb[k + 1] + bb[k + 7]) + 34 * (bb[k + 2] + bb[k + 6]) + 49 * (bb[k + 3] + bb[k + 5]) + 55 * bb[k + 4]);
+        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
+        *reinterpret_cast<uint2 *>(&s_row[r * BT_W + 4 * j]) = pk;
     }
     __syncthreads();
     uint8_t *out = P.blur + (size_t)frame * P.blurStride + D.boff;
-    for (int i = tid; i < BT_H * BT_W; i += 256) {
-        const int r = i / BT_W, c = i - r * BT_W;
-        const int x = tx0 + c, y = ty0 + r;
+    for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
+        const int r = i / (BT_W / 4), j = i - r * (BT_W / 4);
+        const int x = tx0 + 4 * j, y = ty0 + r;
         if (x >= D.w || y >= D.h) continue;
-        const unsigned short *p = &s_row[r * BT_W + c];
-        const int acc = 18 * (p[0] + p[6 * BT_W]) + 34 * (p[BT_W] + p[5 * BT_W]) + 49 * (p[2 * BT_W] + p[4 * BT_W]) + 55 * p[3 * BT_W];
-        out[(size_t)y * D.pitch + x] = (uint8_t)min((acc + 32768) >> 16, 255);
+        int acc[4] = {0, 0, 0, 0};
+        constexpr int K7[7] = {18, 34, 49, 55, 49, 34, 18};
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(&s_row[(r + k) * BT_W + 4 * j]);
+            acc[0] += K7[k] * (int)(q.x & 0xFFFFu); acc[1] += K7[k] * (int)(q.x >> 16);
+            acc[2] += K7[k] * (int)(q.y & 0xFFFFu); acc[3] += K7[k] * (int)(q.y >> 16);
+        }
+        unsigned res = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) res |= (unsigned)min((acc[k] + 32768) >> 16, 255) << (8 * k);
+        uint8_t *dst = out + (size_t)y * D.pitch + x;
+        if (x + 3 < D.w) __builtin_memcpy(dst, &res, 4);
+        else
+            for (int k = 0; k < 4 && x + k < D.w; k++) dst[k] = (uint8_t)(res >> (8 * k));
     }
 }
 
