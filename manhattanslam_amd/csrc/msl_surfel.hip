@@ -83,6 +83,7 @@ struct SfDev {
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
+    float *pxInv;                // [slots][npx] (float)(1.0 / (double)depth) of every pixel (0 when depth <= 0.01): pass 0 writes, passes 1-2 read
     unsigned *wl;                // [slots][npx] relaxation worklist: pixels on a stable seed that pick a different seed
     unsigned *wlCount;           // [slots]
     int *chunkAbort;             // [slots][2][16]
@@ -258,6 +259,19 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
         if (it > 0 && threadIdx.x < 8) P.changed[slot * 8 + threadIdx.x] = threadIdx.x == 0 ? 1 : 0;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + NCHUNK) P.chunkAbort[(slot * 2 + (it & 1)) * 16 + threadIdx.x - 64] = 0x7FFFFFFF;
     }
+    // stage the 6 x 3 seeds any pixel of this 32 x 8 tile can pick (fields the cost needs: x, y, meanDepth, meanIntensity,
+    // reciprocal depth); clamped at the lattice border -- out-of-lattice candidates are skipped by the range test below
+    __shared__ float2 s_xy[18], s_di[18];
+    __shared__ double s_inv[18];
+    const int sx0 = (blk % tilesX) * 4 - 1, sy0 = (blk / tilesX) - 1;
+    if (threadIdx.x < 18) {
+        const int sxI = min(max(sx0 + (int)threadIdx.x % 6, 0), P.spW - 1), syI = min(max(sy0 + (int)threadIdx.x / 6, 0), P.spH - 1);
+        const msl_seed *sp = P.seeds + (size_t)slot * P.nseeds + syI * P.spW + sxI;
+        s_xy[threadIdx.x] = *reinterpret_cast<const float2 *>(&sp->x);
+        s_di[threadIdx.x] = *reinterpret_cast<const float2 *>(&sp->meanDepth);   // (meanDepth, meanIntensity)
+        s_inv[threadIdx.x] = P.invDepth[(size_t)slot * P.nseeds + syI * P.spW + sxI];   // 1.0 / (double)meanDepth, the value the divide gives
+    }
+    __syncthreads();
     if (colI >= P.W || rowI >= P.H) return;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const int p = rowI * P.W + colI;
@@ -268,9 +282,15 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
     }
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const float myIntensity = gray_at(P, F, rowI, colI);
+    // (float)(1.0 / (double)depth) is the same in all three passes: computed (one f64 divide) in pass 0, read back afterwards
     float myInvDepth = 0.0f;
-    const float dpx = depth_at(P, F, rowI, colI);
-    if (dpx > 0.01) myInvDepth = (float)(1.0 / (double)dpx);
+    if (it == 0) {
+        const float dpx = depth_at(P, F, rowI, colI);
+        if (dpx > 0.01) myInvDepth = (float)(1.0 / (double)dpx);
+        P.pxInv[(size_t)slot * P.npx + p] = myInvDepth;
+    } else {
+        myInvDepth = P.pxInv[(size_t)slot * P.npx + p];
+    }
     const int baseSpX = colI / SP, baseSpY = rowI / SP;
     float minDistDepth = 1e6f, minDistNodepth = 1e6f;
     int minSpIndexDepth = -1, minSpIndexNodepth = -1;
@@ -281,17 +301,13 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
     const int rx = colI - baseSpX * SP, ry = rowI - baseSpY * SP;
     const int x0 = baseSpX - (rx < SP / 2 ? 1 : 0), nx = (rx == SP / 2) ? 1 : 2;
     const int y0 = baseSpY - (ry < SP / 2 ? 1 : 0), ny = (ry == SP / 2) ? 1 : 2;
-    const double *invDepth = P.invDepth + (size_t)slot * P.nseeds;
-    // load the (up to) four candidates up front with clamped indices
+    // the (up to) four candidates of every pixel of the tile are among the 6 x 3 seeds staged in LDS
     float2 cxy[4], cdi[4];
     double cinv[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        const int sxI = min(max(x0 + (c >> 1), 0), P.spW - 1), syI = min(max(y0 + (c & 1), 0), P.spH - 1);
-        const msl_seed *sp = &seeds[syI * P.spW + sxI];
-        cxy[c] = *reinterpret_cast<const float2 *>(&sp->x);
-        cdi[c] = *reinterpret_cast<const float2 *>(&sp->meanDepth);   // (meanDepth, meanIntensity)
-        cinv[c] = invDepth[syI * P.spW + sxI];                        // 1.0 / (double)meanDepth, the value the divide gives
+        const int li = (y0 + (c & 1) - sy0) * 6 + (x0 + (c >> 1) - sx0);
+        cxy[c] = s_xy[li]; cdi[c] = s_di[li]; cinv[c] = s_inv[li];
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -1519,6 +1535,7 @@ struct msl_sf {
     msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
     double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
+    float *d_pxInv = nullptr;
     // staged images (host input mode), per slot
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
@@ -1578,7 +1595,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
     h->grayCap = h->depthCap = h->memberCap = 0;
 }
@@ -1598,6 +1615,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_invDepth, sizeof(double) * ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_pxInv, sizeof(float) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_wl, sizeof(unsigned) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_wlCount, sizeof(unsigned) * slots));
     MSL_HIP_TRY(hipMemset(h->d_wlCount, 0, sizeof(unsigned) * slots));
@@ -1609,7 +1627,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
-    D.invDepth = h->d_invDepth; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
+    D.invDepth = h->d_invDepth; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
     h->maxBatch = maxBatch;
     h->evMapValid[0] = h->evMapValid[1] = false;
     h->evCopyValid[0] = h->evCopyValid[1] = false;
@@ -1708,7 +1726,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
-    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
+    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.npx; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 seedGrid((D.nseeds + 255) / 256, un);
