@@ -60,7 +60,11 @@ def pmc_traffic(kernel):
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json."""
     import glob
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime)
+    cur = os.path.join(ROOT, "profiles", "current.txt")   # tag of the profile that matches the committed kernels
+    if os.path.exists(cur):
+        files.append(os.path.join(ROOT, "profiles", open(cur).read().strip() + "_summary.json"))
+    for f in files:
         try:
             e = json.load(open(f)).get(kernel)
         except Exception:
