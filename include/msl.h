@@ -213,6 +213,30 @@ MSL_API int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t
 MSL_API int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n);
 MSL_API int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out);
 
+/* ---- widening, SURVEY.md 8(f) rank 2: the data-parallel front of the PEAC plane extractor (producer of membershipImg) ----
+ * msl_peac_block_stats: for n_frames raw 16-bit depth images
+ *   (a) the organised half-resolution point cloud of PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:44-76):
+ *       vertex (i/2, j/2) = (((double)j - cx) * z / fx, ((double)i - cy) * z / fy, z), z = (double)depth(i, j) * depthMapFactor,
+ *       for even i, j; cloud_out[frame][(h/2... ceil) * (w/2 ... ceil)][3] doubles (may be NULL);
+ *   (b) the initial node of every window_w x window_h block, i.e. the body of ahc::PlaneSeg::PlaneSeg
+ *       (include/peac/AHCPlaneSeg.hpp:237-285) as ahc::PlaneFitter::initGraph calls it (include/peac/AHCPlaneFitter.hpp:756-776):
+ *       points with z == 0 are missing data (include/PlaneExtractor.h:47-55), a block with missing data (INIT_STRICT; more
+ *       than half missing for init_loose != 0) or a depth discontinuity |z - z_nb| > depth_alpha * |z| + depth_change_tol
+ *       towards the right / lower neighbour (AHCPlaneSeg.hpp:41-43, AHCParamSet.hpp:140-142) is rejected (nouse = 1, N = 0,
+ *       sums 0); otherwise the nine FP64 sums of ahc::PlaneSeg::Stats::push (AHCPlaneSeg.hpp:81-92) in window raster order.
+ *       stats_out[frame][(H / window_h) * (W / window_w)], H = ceil(height / 2), W = ceil(width / 2), block (i, j) at i * Nw + j.
+ * The PCA plane fit of each block (a 3x3 symmetric eigen-solve through Eigen), the graph and the agglomerative clustering stay
+ * host code.  Synchronous; depth / outputs in host or device memory as `mem` / `out_mem` say. */
+typedef struct msl_peac_stats {
+    double sx, sy, sz, sxx, syy, szz, sxy, syz, sxz;   /* ahc::PlaneSeg::Stats (AHCPlaneSeg.hpp:59-63) */
+    int32_t N;
+    int32_t nouse;
+} msl_peac_stats;
+MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
+                                 int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, int window_w,
+                                 int window_h, double depth_alpha, double depth_change_tol, int init_loose, double *cloud_out,
+                                 msl_peac_stats *stats_out, msl_mem out_mem);
+
 /* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
  * Keyframe f's images start at base + f * <frame_stride> bytes (member_frame_stride may be 0: one shared
  * membership image); refs[n_frames] and poses (16 * n_frames floats, column-major Twc each) are host arrays.

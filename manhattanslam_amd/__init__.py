@@ -8,3 +8,5 @@ compute classes without the built library, or constructing them without an MI355
 from ._lib import lib, MslError, KEYPOINT_DTYPE, SURFEL_DTYPE, SEED_DTYPE, device_count  # noqa: F401
 from .orb import ORBextractor, frame_params  # noqa: F401
 from .surfel import SurfelFusion, SurfelMap  # noqa: F401
+from . import peac  # noqa: F401
+from ._lib import PEAC_STATS_DTYPE  # noqa: F401

@@ -22,6 +22,7 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
                        ("viewCos", "<f4"), ("meanDepth", "<f4"), ("meanIntensity", "<f4"), ("r", "<i4"),
                        ("g", "<i4"), ("b", "<i4"), ("fused", "u1"), ("stable", "u1"), ("use", "u1"),
                        ("_pad", "u1")])
+PEAC_STATS_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")])
 FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
 assert KEYPOINT_DTYPE.itemsize == 28 and SURFEL_DTYPE.itemsize == 56 and SEED_DTYPE.itemsize == 64
 
@@ -61,6 +62,7 @@ SIGNATURES = {
     "msl_sf_map_detach": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
     "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
     "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),

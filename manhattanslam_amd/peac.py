@@ -1,0 +1,26 @@
+"""Host mirror of the PEAC front: organised point cloud + initial block statistics.
+
+Mirrors PlaneDetection::readDepthImage (src/PlaneExtractor.cpp:44-76) and the per-block ahc::PlaneSeg initialisation of
+ahc::PlaneFitter::initGraph (include/peac/AHCPlaneFitter.hpp:756-776, include/peac/AHCPlaneSeg.hpp:237-285) through the C ABI.
+"""
+import numpy as np
+
+from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, MSL_MEM_HOST
+
+
+def block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), depth_alpha=0.04, depth_change_tol=0.02,
+                init_loose=False, want_cloud=True, device=0):
+    """depth_u16: [H, W] or [F, H, W] uint16.  Returns (cloud [F, ch*cw, 3] f64 or None, stats [F, Nh*Nw] PEAC_STATS_DTYPE)."""
+    d = np.asarray(depth_u16)
+    if d.ndim == 2:
+        d = d[None]
+    d = np.ascontiguousarray(d, np.uint16)
+    F, H, W = d.shape
+    cw, ch = (W + 1) // 2, (H + 1) // 2
+    nb = (cw // window[0]) * (ch // window[1])
+    stats = np.zeros((F, nb), PEAC_STATS_DTYPE)
+    cloud = np.zeros((F, cw * ch, 3), np.float64) if want_cloud else None
+    check(lib.msl_peac_block_stats(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor,
+                                   window[0], window[1], depth_alpha, depth_change_tol, 1 if init_loose else 0,
+                                   ptr(cloud) if want_cloud else None, ptr(stats), MSL_MEM_HOST), "msl_peac_block_stats")
+    return cloud, stats

@@ -259,3 +259,20 @@ def frame_epilogue(params, kps, depth):
     un = np.zeros((n, 2), np.float32); dep = np.zeros(n, np.float32); ur = np.zeros(n, np.float32); cell = np.zeros(n, np.int32)
     d.mslo_frame_epilogue(_p(params), _p(kps), n, _p(depth), depth.strides[0], _p(un), _p(dep), _p(ur), _p(cell))
     return un, dep, ur, cell
+
+
+def peac_block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), depth_alpha=0.04, depth_change_tol=0.02, init_loose=False):
+    """oracle/peac_oracle.cpp on one [H, W] uint16 depth image -> (cloud [ch*cw, 3], stats)."""
+    from manhattanslam_amd import PEAC_STATS_DTYPE
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    H, W = d.shape
+    cw, ch = (W + 1) // 2, (H + 1) // 2
+    stats = np.zeros((cw // window[0]) * (ch // window[1]), PEAC_STATS_DTYPE)
+    cloud = np.zeros((cw * ch, 3), np.float64)
+    f = load().dll.mslo_peac_block_stats
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                  C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+    f(_p(d), d.strides[0], W, H, fx, fy, cx, cy, depth_map_factor, window[0], window[1], depth_alpha, depth_change_tol, 1 if init_loose else 0,
+      _p(cloud), _p(stats))
+    return cloud, stats

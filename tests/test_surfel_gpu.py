@@ -252,3 +252,35 @@ def test_map_maintenance_matches_literal_loops(oracle):
     o.fuse_map(9, gray, depth, member, pose)
     assert_surfels_close(g.map_download(), o.map_get(), "after maintenance")
     g.close()
+
+
+def test_peac_block_stats_match_oracle(oracle):
+    """organised cloud + initial PEAC block statistics, bit-identical FP64 (batched, strict and loose init)."""
+    from manhattanslam_amd import synth, peac
+    from tests.oracle_lib import peac_block_stats
+    I = synth.TUM1
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(3):
+        _, depth, _, _ = synth.surfel_frame(k, variant="B" if k == 1 else "A")
+        d16 = np.clip(np.round(depth * 5000.0), 0, 65535).astype(np.uint16)
+        d16[rng.random(d16.shape) < 0.002] = 0                      # missing returns
+        if k == 2:
+            d16[100:300, 200:420] += 5000                           # a box 1 m further away: depth discontinuities
+        frames.append(d16)
+    frames = np.stack(frames)
+    factor = np.float32(1.0 / 5000.0)
+    for loose in (False, True):
+        cloud, st = peac.block_stats(frames, I["fx"], I["fy"], I["cx"], I["cy"], factor, init_loose=loose)
+        assert st.shape == (3, 24 * 32)
+        for k in range(3):
+            c_ref, s_ref = peac_block_stats(frames[k], I["fx"], I["fy"], I["cx"], I["cy"], factor, init_loose=loose)
+            assert cloud[k].tobytes() == c_ref.tobytes()
+            assert st[k].tobytes() == s_ref.tobytes(), (loose, k)
+        assert (st["nouse"] == 0).sum() > 0 and (loose or (st["nouse"] == 1).sum() > 0)
+    assert (st[2]["nouse"] == 1).sum() > 0                          # loose init still rejects the depth steps of frame 2
+    # odd sizes and a non-default window
+    d = frames[0][:431, :517]
+    cloud, st = peac.block_stats(d, I["fx"], I["fy"], I["cx"], I["cy"], factor, window=(8, 12))
+    c_ref, s_ref = peac_block_stats(d, I["fx"], I["fy"], I["cx"], I["cy"], factor, window=(8, 12))
+    assert cloud[0].tobytes() == c_ref.tobytes() and st[0].tobytes() == s_ref.tobytes()
