@@ -284,3 +284,27 @@ def test_peac_block_stats_match_oracle(oracle):
     cloud, st = peac.block_stats(d, I["fx"], I["fy"], I["cx"], I["cy"], factor, window=(8, 12))
     c_ref, s_ref = peac_block_stats(d, I["fx"], I["fy"], I["cx"], I["cy"], factor, window=(8, 12))
     assert cloud[0].tobytes() == c_ref.tobytes() and st[0].tobytes() == s_ref.tobytes()
+
+
+def test_full_size_map_batched_matches_oracle(oracle):
+    """BASELINE config 3 at full size: ~1 M live surfels, a batch of keyframes on the resident map vs the oracle run keyframe by keyframe."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    n, F = 1_000_000, 4
+    m = synth.surfel_map(n, ref=0, min_update_times=1).astype(SURFEL_DTYPE)     # includes young surfels: real deletions
+    g.set_batch_capacity(F)
+    g.map_reserve(n + 100_000)
+    g.map_upload(m)
+    o.map_set(m)
+    frames = [synth.surfel_frame(k, variant="B" if k == 2 else "A") for k in range(F)]
+    refs = np.arange(7, 7 + F)                                                  # ref - lastUpdate > 5 for part of the map
+    g.fuse_resident_batch(refs, np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]),
+                          [f[3] for f in frames])
+    for k in range(F):
+        o.fuse_map(int(refs[k]), *frames[k])
+    mg, mo = g.map_download(), o.map_get()
+    assert len(mg) == len(mo)
+    assert_surfels_close(mg, mo, "1M map after 4 keyframes")
+    c = g.counters()
+    assert c["n_live_after"] == len(mo) and c["n_deleted"] > 0
+    g.close()
