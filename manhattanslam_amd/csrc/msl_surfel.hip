@@ -1231,27 +1231,49 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
     unsigned cnt = 0;
     unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
-    for (int i = s0; i < s1; i += 4) {
-        unsigned c4, f4;
-        if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
-            c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
-        } else {
-            c4 = f4 = 0;
-            for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
-        }
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
+    if (per <= 32 && (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0) {
+        // common geometry: all flag words of the thread in ONE round trip
+        unsigned cw[8], fw[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
-            cnt += e;
-            if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+        for (int q = 0; q < 8; q++) {
+            const int i = s0 + 4 * q;
+            const bool in = 4 * q < per && i < s1;
+            cw[q] = in ? *reinterpret_cast<const unsigned *>(candOk + i) : 0u;
+            fw[q] = in ? *reinterpret_cast<const unsigned *>(fused + i) : 0u;
+        }
+        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]), "v"(cw[7]),
+                     "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3]), "v"(fw[4]), "v"(fw[5]), "v"(fw[6]), "v"(fw[7]));
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (s0 + 4 * q + j < s1 && ((cw[q] >> (8 * j)) & 0xFF) && !((fw[q] >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                emit |= (unsigned long long)e << (4 * q + j);
+            }
+    } else {
+        for (int i = s0; i < s1; i += 4) {
+            unsigned c4, f4;
+            if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
+                c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
+            } else {
+                c4 = f4 = 0;
+                for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+            }
         }
     }
     // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
     // that this round trip overlaps the scans below instead of following them.
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
     msl_surfel e0, e1;
     memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
-    const bool pf = blockIdx.x == 0 || mode == 1;
     if (pf && emit) {
         e0 = cand[s0 + __builtin_ctzll(emit)];
         const unsigned long long m1 = emit & (emit - 1);
