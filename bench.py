@@ -27,6 +27,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8
 W, H = 640, 480
 SURFEL_BYTES = 56              # sizeof(Surfel), reference include/Surfel.h:28-37
 K_FUSE = 7                     # kernel id of k_fuse in msl_sf_kernel_name()
+ORB_READ_BYTES = 2 * 950532    # 2 * sum of the 8 pyramid level areas at 640x480, scale 1.2
 
 
 def parse():
@@ -216,6 +217,12 @@ def main():
                      "algorithmic_bytes_per_launch": int(SURFEL_BYTES * n_live_avg), "avg_launch_us": round(fuse_s * 1e6, 2),
                      "timer": "HIP events carried by the k_fuse dispatch (hipExtLaunchKernelGGL) on the map stream, timed region",
                      "launches": int(fuse_launches)},
+        # whole-pipeline algorithmic HBM reads per frame (ORB 2 * sum P_l + surfel 56 N + 5 W H + 4 (W/2)(H/2))
+        # times the per-GPU frame rate, against the same peak
+        "pipeline_roofline": {"algorithmic_read_bytes_per_frame": int(ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 5 * W * H + W * H),
+                              "achieved": round((ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 6 * W * H) * value / world / 1e9, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round((ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 6 * W * H) * value / world / 1e9 / HBM_PEAK_GBS, 4)},
         "counters_per_rank": gathered,
     }
 
