@@ -45,6 +45,14 @@ constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-stage kernels
+// Waves (= sub-blocks) per k_fuse workgroup.  Measured (1 M surfels, surfel-only): 4 -> k_fuse 20.8 us / k_compact 9.0 us in
+// region, 2 -> 16.7 / 9.9, 1 -> 16.3 / 11.8 (k_compact sums one blockUpd entry per workgroup); end-to-end the three are equal
+// (37.3-37.8 us per keyframe) because the superpixel chain then limits, so the default stays at 4.
+#ifndef MSL_FUSE_WAVES
+#define MSL_FUSE_WAVES 4
+#endif
+constexpr int FUSE_WAVES = MSL_FUSE_WAVES;
+constexpr int FUSE_NT = 64 * FUSE_WAVES;
 constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted-slot partials
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
@@ -1013,7 +1021,7 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 //   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
-__global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
+__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
     // One 4 KB list per workgroup keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
@@ -1021,22 +1029,23 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
     // different quarters of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
     // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
     __shared__ unsigned s_cnt[5], s_delSub[4];
-    __shared__ unsigned s_surv[SCAN_ITEMS];
+    constexpr int LISTN = 4 * FUSE_NT;
+    __shared__ unsigned s_surv[LISTN];
     __shared__ unsigned s_delBase;
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
-    const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + 3) / 4;   // sub-blocks, workgroups with work
+    const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + FUSE_WAVES - 1) / FUSE_WAVES;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
-    static_assert(SCAN_ITEMS == 1024, "4 consecutive surfels per thread x 256 threads");
     const int wv = threadIdx.x >> 6;
-    for (long long b = blockIdx.x; b < nW; b += gridDim.x) {
+    for (long long bq = blockIdx.x; bq < nW; bq += gridDim.x) {
+        const long long b = nW - 1 - bq;   // the newest surfels (most phase-B work) are dispatched first
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
-        if (threadIdx.x < 4) s_delSub[threadIdx.x] = 0;
+        if (threadIdx.x < FUSE_WAVES) s_delSub[threadIdx.x] = 0;
         __syncthreads();
         unsigned nupd = 0;
         // local index (10 bits) = wave << 8 | offset in the wave's sub-block
@@ -1044,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         auto global_of = [&](unsigned local) -> long long { return sub_base(local >> 8) + (local & 0xFFu); };
         const long long c0 = sub_base(wv);
         auto mark_deleted = [&](long long i) {
-            s_surv[SCAN_ITEMS - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
+            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
             atomicAdd(&s_delSub[wv], 1u);
         };
         const bool hasSub = (long long)wv * nW + b < nSub;   // the last workgroups may own fewer than four sub-blocks
@@ -1103,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         __syncthreads();
         const unsigned nsurv = s_cnt[2];
         unsigned ndelB = 0;
-        for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
+        for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
             const unsigned sv = s_surv[sidx];
             const long long i = global_of(sv & 0xFFFFu);
             const int spIndex = (int)(sv >> 16);
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
         const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
-        if (threadIdx.x < 4 && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
+        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
         if (threadIdx.x == 0) {
             P.blockUpd[b] = s_cnt[1];
             if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per chunk that deleted something
@@ -1168,10 +1177,10 @@ __global__ __launch_bounds__(256) void k_fuse(SfDev P, int slot, FrameDev F) {  
         __syncthreads();
         if (ndelBlk) {
             const unsigned base = s_delBase;
-            for (unsigned j = threadIdx.x; j < ndelA; j += 256)
-                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[SCAN_ITEMS - 1 - j]);
+            for (unsigned j = threadIdx.x; j < ndelA; j += FUSE_NT)
+                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[LISTN - 1 - j]);
             if (ndelBlk != ndelA)
-                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += 256) {
+                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
                     const unsigned sv = s_surv[sidx];
                     if ((sv >> 16) != 0xFFFFu) continue;
                     const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
@@ -1280,7 +1289,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
     }
     const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
-    const long long nWg = (nblk + 3) / 4;                      // k_fuse workgroups (blockUpd entries)
+    const long long nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;   // k_fuse workgroups (blockUpd entries)
     s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
@@ -1595,9 +1604,9 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
     MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: k_compact reads its first tile unconditionally
-    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
     MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
-    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SCAN_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
     MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
     if (keep && h->d_mapStore) {
@@ -1779,7 +1788,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
     for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048), dim3(256), P, f, h->h_frames[slot0 + f]);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048 * 4 / FUSE_WAVES), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f]);
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
