@@ -47,9 +47,10 @@ constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-stage kernels
 // Waves (= sub-blocks) per k_fuse workgroup.  Measured (1 M surfels, surfel-only): 4 -> k_fuse 20.8 us / k_compact 9.0 us in
 // region, 2 -> 16.7 / 9.9, 1 -> 16.3 / 11.8 (k_compact sums one blockUpd entry per workgroup); end-to-end the three are equal
-// (37.3-37.8 us per keyframe) because the superpixel chain then limits, so the default stays at 4.
+// (37.3-37.8 us per keyframe) because the superpixel chain then limits; with ORB running next to it (bench.py) 2 waves give
+// +3 % frames/s and k_fuse 19.8 instead of 26.4 us in region, hence the default.
 #ifndef MSL_FUSE_WAVES
-#define MSL_FUSE_WAVES 4
+#define MSL_FUSE_WAVES 2
 #endif
 constexpr int FUSE_WAVES = MSL_FUSE_WAVES;
 constexpr int FUSE_NT = 64 * FUSE_WAVES;
@@ -1229,7 +1230,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
-    const uint4 bu0 = *reinterpret_cast<const uint4 *>(P.blockUpd + 4 * threadIdx.x);    // (arrays are padded by >= 1024 zeroed entries)
+    uint4 bu[4];   // the first 4096 per-workgroup updated counts (arrays are padded by >= 4096 zeroed entries)
+#pragma unroll
+    for (int q = 0; q < 4; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
     static_assert(LIST_D == NT, "one hand-over entry per thread");
     const unsigned du = P.delU[threadIdx.x];
     const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
@@ -1383,9 +1386,13 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     // ================= continuation: one workgroup =================
     // updated count
     {
-        const long long c = 4 * threadIdx.x;
-        unsigned u = (c < nWg ? bu0.x : 0u) + (c + 1 < nWg ? bu0.y : 0u) + (c + 2 < nWg ? bu0.z : 0u) + (c + 3 < nWg ? bu0.w : 0u);
-        for (long long c2 = TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
+        unsigned u = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long c = TILE * q + 4 * threadIdx.x;
+            u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
+        }
+        for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
         if (u) atomicAdd(&s_upd, u);
     }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
@@ -1604,9 +1611,9 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
     MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: k_compact reads its first tile unconditionally
-    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
     MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
-    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
+    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
     MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
     MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
     if (keep && h->d_mapStore) {
