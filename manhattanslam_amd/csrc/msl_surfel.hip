@@ -11,15 +11,15 @@
 //   pre stream, one launch per batch of F keyframes:
 //     kb_seed_init                        one thread per 8x8 superpixel seed                  (:528-584)
 //     3 x { kb_assign                     one thread per pixel: argmin over <= 9 seeds        (:333-415)
-//           [kb_prop x6, kb_prop_finish,  raster-order `stable` semantics as a min-fixpoint   (App. B.7.1)
-//            kb_commit_px]                  over a compact worklist of the only pixels that can extend a chain
+//           [kb_prop_lds,                 raster-order `stable` semantics as a min-fixpoint   (App. B.7.1)
+//            kb_commit_px]                  over a compact worklist of the only pixels that can extend a chain (one launch, LDS)
 //           kb_update_seeds               16 lanes per seed: ordered window gather, Huber mean (:428-515)
-//           kb_commit_seeds }             chunk-abort (`return`) semantics                    (App. B.7.2)
+//           kb_commit_seeds }             chunk-abort (`return`) semantics: restore-only      (App. B.7.2)
 //     kb_seed_plane                       16 lanes per seed: back-projection, pixel normals, Huber plane
 //                                         fit with FP64 4x4 normal equations                  (:91-165, :597-773)
 //   map stream, per keyframe (two launches):
 //     k_fuse                              live surfels, hot/cold record map resident in HBM   (:167-283)
-//     k_compact                           chunk scan, deleted-slot list, ordered emission of un-fused seeds (:285-331),
+//     k_compact                           deleted-slot list (handed over by k_fuse / sub-block scan), ordered emission of un-fused seeds (:285-331),
 //                                         deleted-slot refill + tail compaction               (SurfelMapping.cpp:366-391)
 //
 // HBM-bound integer/float streaming; no MFMA.  Every float expression keeps the reference's evaluation
@@ -44,7 +44,7 @@ constexpr unsigned T_INF = 0xFFFFFFFFu;
 constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
-constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-stage kernels
+constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-maintenance kernels (k_select_*)
 // Waves (= sub-blocks) per k_fuse workgroup.  Measured (1 M surfels, surfel-only): 4 -> k_fuse 20.8 us / k_compact 9.0 us in
 // region, 2 -> 16.7 / 9.9, 1 -> 16.3 / 11.8 (k_compact sums one blockUpd entry per workgroup); end-to-end the three are equal
 // (37.3-37.8 us per keyframe) because the superpixel chain then limits; with ORB running next to it (bench.py) 2 waves give
@@ -1023,11 +1023,11 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
 __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
-    // One 4 KB list per workgroup keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
+    // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
-    // Each wave owns one sub-block of 256 consecutive surfels, and the four waves of a workgroup take theirs from four
-    // different quarters of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
+    // Each wave owns one sub-block of 256 consecutive surfels, and the FUSE_WAVES waves of a workgroup take theirs from
+    // different parts of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
     // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
     __shared__ unsigned s_cnt[5], s_delSub[4];
     constexpr int LISTN = 4 * FUSE_NT;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
         if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
         if (threadIdx.x == 0) {
             P.blockUpd[b] = s_cnt[1];
-            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per chunk that deleted something
+            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per workgroup that deleted something
         }
         __syncthreads();
         if (ndelBlk) {
