@@ -308,3 +308,22 @@ def test_full_size_map_batched_matches_oracle(oracle):
     c = g.counters()
     assert c["n_live_after"] == len(mo) and c["n_deleted"] > 0
     g.close()
+
+
+@pytest.mark.parametrize("w,h", [(328, 248), (320, 240), (72, 64)])
+def test_odd_seed_lattices_and_small_images(oracle, w, h):
+    """Seed lattices with odd extents (41 x 31: partial 2x2 seed blocks, partial tiles) and tiny images, two keyframes."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    intr = {k: v * (w / 640.0) for k, v in synth.TUM1.items()}
+    g, o = _mk(intr, w, h)
+    m = synth.surfel_map(20000, ref=0).astype(SURFEL_DTYPE)
+    g.map_upload(m)
+    o.map_set(m)
+    for k in range(2):
+        gray, depth, member, pose = synth.surfel_frame(k, w, h, intr=intr, variant="B" if k == 1 else "A")
+        g.fuse_resident(k, gray, depth, member, pose)
+        o.fuse_map(k, gray, depth, member, pose)
+        assert np.array_equal(g.debug_index(), o.index()), (w, h, k)
+        assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(g.map_download(), o.map_get(), f"{w}x{h} map")
+    g.close()
