@@ -327,3 +327,23 @@ def test_odd_seed_lattices_and_small_images(oracle, w, h):
         assert_seeds_close(g.debug_seeds(), o.seeds())
     assert_surfels_close(g.map_download(), o.map_get(), f"{w}x{h} map")
     g.close()
+
+
+def test_large_image_uses_relaxation_fallback(oracle):
+    """2048 x 1536: 49 152 seeds exceed the LDS-resident relaxation kernel, so the multi-launch fallback runs (two keyframes)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    w, h = 2048, 1536
+    intr = {k: v * (w / 640.0) for k, v in synth.TUM1.items()}
+    g, o = _mk(intr, w, h)
+    m = synth.surfel_map(30000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(200000)
+    g.map_upload(m)
+    o.map_set(m)
+    for k in range(2):
+        gray, depth, member, pose = synth.surfel_frame(k, w, h, intr=intr, variant="B" if k == 1 else "A")
+        g.fuse_resident(k, gray, depth, member, pose)
+        o.fuse_map(k, gray, depth, member, pose)
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(g.map_download(), o.map_get(), "2048x1536 map")
+    g.close()
