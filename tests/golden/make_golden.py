@@ -39,4 +39,10 @@ changed = np.flatnonzero((lo.view(np.uint8).reshape(len(lo), -1) != local.view(n
 np.savez_compressed(os.path.join(OUT, "surfel_640x480_B.npz"), frame=2, n_local=len(local),
                     depth_sha256=hashlib.sha256(depth.tobytes()).hexdigest(), new_surfels=no, changed_index=changed.astype(np.int32),
                     changed_surfels=lo[changed], seeds=sf.seeds(), index_sha256=hashlib.sha256(sf.index().tobytes()).hexdigest())
+# organised cloud + initial PEAC block statistics of the same frame (16-bit depth, factor 1/5000)
+d16 = np.clip(np.round(depth * 5000.0), 0, 65535).astype(np.uint16)
+d16[200:320, 300:420] += 4000          # a box 0.8 m further away: depth discontinuities
+cloud, stats = oracle_lib.peac_block_stats(d16, I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+np.savez_compressed(os.path.join(OUT, "peac_640x480.npz"), frame=2, depth16_sha256=hashlib.sha256(d16.tobytes()).hexdigest(),
+                    cloud_sha256=hashlib.sha256(cloud.tobytes()).hexdigest(), stats=stats)
 print("golden vectors written:", os.listdir(OUT))

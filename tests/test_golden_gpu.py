@@ -1,4 +1,5 @@
 """GPU vs the committed golden vectors (tests/golden/*.npz) -- independent of the oracle library at run time."""
+import hashlib
 import os
 
 import numpy as np
@@ -39,3 +40,17 @@ def test_surfel_golden_within_tolerance():
     untouched = np.setdiff1d(np.arange(len(local)), ci)
     assert local[untouched].tobytes() == before[untouched].tobytes()
     sf.close()
+
+
+def test_peac_golden_bit_exact():
+    from manhattanslam_amd import synth, peac
+    g = np.load(os.path.join(GOLD, "peac_640x480.npz"))
+    _, depth, _, _ = synth.surfel_frame(int(g["frame"]), variant="B")
+    d16 = np.clip(np.round(depth * 5000.0), 0, 65535).astype(np.uint16)
+    d16[200:320, 300:420] += 4000
+    assert hashlib.sha256(d16.tobytes()).hexdigest() == str(g["depth16_sha256"])
+    I = synth.TUM1
+    cloud, st = peac.block_stats(d16, I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+    assert hashlib.sha256(cloud[0].tobytes()).hexdigest() == str(g["cloud_sha256"])
+    assert st[0].tobytes() == g["stats"].tobytes()
+    assert 0 < int((st[0]["nouse"] == 1).sum()) < st.shape[1]

@@ -49,3 +49,19 @@ def test_blocks_that_do_not_fit_are_dropped():
     d = np.full((50, 70), 5000, np.uint16)                   # cloud 25 x 35 -> 2 x 3 blocks of 10 x 10
     cloud, st = peac_block_stats(d, FX, FY, CX, CY, FACTOR)
     assert cloud.shape[0] == 25 * 35 and len(st) == 6
+
+
+def test_golden_peac():
+    """Committed golden vector (tests/golden/make_golden.py) pins the oracle's behaviour."""
+    import hashlib
+    import os
+    from manhattanslam_amd import synth
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "peac_640x480.npz"))
+    _, depth, _, _ = synth.surfel_frame(int(g["frame"]), variant="B")
+    d16 = np.clip(np.round(depth * 5000.0), 0, 65535).astype(np.uint16)
+    d16[200:320, 300:420] += 4000
+    assert hashlib.sha256(d16.tobytes()).hexdigest() == str(g["depth16_sha256"])
+    I = synth.TUM1
+    cloud, st = peac_block_stats(d16, I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+    assert hashlib.sha256(cloud.tobytes()).hexdigest() == str(g["cloud_sha256"])
+    assert st.tobytes() == g["stats"].tobytes()
