@@ -4,6 +4,8 @@
 //   blocks : ahc::PlaneSeg::PlaneSeg(points, ...)     (/root/reference/include/peac/AHCPlaneSeg.hpp:237-285), one block per thread
 #include "msl_common.h"
 
+#include <mutex>
+
 namespace {
 using namespace msl;
 
@@ -88,6 +90,10 @@ __global__ __launch_bounds__(64) void k_peac_blocks(PeacDev P) {
     P.stats[(size_t)frame * P.Nw * P.Nh + b] = S;
 }
 
+struct Scratch { void *depth = nullptr, *stats = nullptr, *cloud = nullptr; size_t depthCap = 0, statsCap = 0, cloudCap = 0; };
+Scratch g_scratch[16];
+std::mutex g_scratchMutex;
+
 }  // namespace
 
 extern "C" {
@@ -111,15 +117,23 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
     P.strideBytes = depth_stride_bytes; P.frameStrideBytes = frame_stride_bytes;
     const size_t nBlocks = (size_t)P.Nw * P.Nh, nVert = (size_t)P.cw * P.ch;
     if (nBlocks == 0) { set_error("msl_peac_block_stats: image smaller than one block"); return MSL_ERR_INVALID; }
+    // staging buffers for host-memory calls: cached per device (grow-only), so a per-frame caller pays no hipMalloc
     uint16_t *dDepth = nullptr; double *dCloud = nullptr; msl_peac_stats *dStats = nullptr;
-    auto cleanup = [&]() {
-        if (mem == MSL_MEM_HOST && dDepth) (void)hipFree(dDepth);
-        if (out_mem == MSL_MEM_HOST) { if (dCloud) (void)hipFree(dCloud); if (dStats) (void)hipFree(dStats); }
+#define PEAC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_peac_block_stats: %s", hipGetErrorString(e_)); return MSL_ERR_HIP; } } while (0)
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    Scratch &sc = g_scratch[device & 15];
+    auto grow = [&](void *&p, size_t &cap, size_t need) -> hipError_t {
+        if (need <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        const hipError_t e = hipMalloc(&p, need);
+        if (e == hipSuccess) cap = need;
+        return e;
     };
-#define PEAC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_peac_block_stats: %s", hipGetErrorString(e_)); cleanup(); return MSL_ERR_HIP; } } while (0)
     if (mem == MSL_MEM_HOST) {
         const size_t frameBytes = depth_stride_bytes * (size_t)height;
-        PEAC_TRY(hipMalloc(&dDepth, frameBytes * n_frames));
+        PEAC_TRY(grow(sc.depth, sc.depthCap, frameBytes * n_frames));
+        dDepth = (uint16_t *)sc.depth;
         for (int f = 0; f < n_frames; f++)
             PEAC_TRY(hipMemcpy((uint8_t *)dDepth + f * frameBytes, (const uint8_t *)depth + f * frame_stride_bytes, frameBytes, hipMemcpyHostToDevice));
         P.depth = dDepth; P.frameStrideBytes = frameBytes;
@@ -127,8 +141,9 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
         P.depth = depth;
     }
     if (out_mem == MSL_MEM_HOST) {
-        PEAC_TRY(hipMalloc(&dStats, sizeof(msl_peac_stats) * nBlocks * n_frames));
-        if (cloud_out) PEAC_TRY(hipMalloc(&dCloud, sizeof(double) * 3 * nVert * n_frames));
+        PEAC_TRY(grow(sc.stats, sc.statsCap, sizeof(msl_peac_stats) * nBlocks * n_frames));
+        dStats = (msl_peac_stats *)sc.stats;
+        if (cloud_out) { PEAC_TRY(grow(sc.cloud, sc.cloudCap, sizeof(double) * 3 * nVert * n_frames)); dCloud = (double *)sc.cloud; }
     } else {
         dStats = stats_out; dCloud = cloud_out;
     }
@@ -143,7 +158,6 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
         PEAC_TRY(hipDeviceSynchronize());
     }
 #undef PEAC_TRY
-    cleanup();
     return MSL_OK;
 }
 
