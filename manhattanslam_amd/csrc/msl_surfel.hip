@@ -1846,8 +1846,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         ok = ok && hipMemcpy(h->d_projTab, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice) == hipSuccess;
         D.colX = h->d_projTab; D.rowY = h->d_projTab + width + 1;
     }
-    if (ok && D.nseeds <= PROP_LDS_MAX_SEEDS)
-        h->propLds = hipFuncSetAttribute((const void *)kb_prop_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * D.nseeds)) == hipSuccess;
+    if (ok && D.nseeds <= PROP_LDS_MAX_SEEDS)   // the attribute belongs to the function, not to this handle: always ask for the largest size any handle may use
+        h->propLds = hipFuncSetAttribute((const void *)kb_prop_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * PROP_LDS_MAX_SEEDS)) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 8);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;

@@ -347,3 +347,21 @@ def test_large_image_uses_relaxation_fallback(oracle):
     assert_seeds_close(g.debug_seeds(), o.seeds())
     assert_surfels_close(g.map_download(), o.map_get(), "2048x1536 map")
     g.close()
+
+
+def test_handles_of_different_sizes_coexist(oracle):
+    """A large-image handle keeps working after a small-image handle is created (per-function launch attributes are shared)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    big_i = {k: v * 2 for k, v in synth.TUM1.items()}
+    gb, ob = _mk(big_i, 1280, 960)
+    gs, os_ = _mk(synth.TUM1)                                    # created second: must not shrink anything the first one needs
+    m = synth.surfel_map(20000, ref=0).astype(SURFEL_DTYPE)
+    for g, o, (w, h, intr) in ((gb, ob, (1280, 960, big_i)), (gs, os_, (640, 480, synth.TUM1))):
+        g.map_upload(m)
+        o.map_set(m)
+        for k in range(2):
+            f = synth.surfel_frame(k, w, h, intr=intr)
+            g.fuse_resident(k, *f)
+            o.fuse_map(k, *f)
+        assert_surfels_close(g.map_download(), o.map_get(), f"{w}x{h}")
+    gb.close(); gs.close()
