@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames-per-step", type=int, default=32)
     ap.add_argument("--surfels", type=int, default=1_000_000)
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample, ~14 s on one core (0 = skip)")
     ap.add_argument("--no-breakdown", action="store_true")
     return ap.parse_args()
 
