@@ -1,20 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native RGB-D front end (ORB extractor + surfel fusion).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config frontend|2|3|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One *step* = one batch of F synthetic 640x480 RGB-D frames through the whole front end on each GPU:
-ORB extraction of the F gray frames (one frame-batched launch sequence) and, frame after frame, surfel
-fusion of every frame (every frame is treated as a keyframe, the most demanding cadence) into a
-device-resident map of ~1 M live surfels.  Inputs are resident in HBM before the timed region.  Each
-rank owns an independent sequence (weak scaling); the only inter-GPU traffic is one RCCL all_gather of
-per-sequence counters after the timed loop.  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
+torch.distributed.run (one rank per GPU, RCCL); the printed n_gpus always equals --gpus.
+
+One *step* = one batch of F synthetic RGB-D frames through the hot path on each GPU, inputs resident in HBM:
+
+  --config frontend (default, the BASELINE.json metric): ORB extraction of the F gray frames (one frame-batched launch
+        sequence) + surfel fusion of every frame (keyframe_every = 1, the most demanding cadence) into a device-resident
+        map of ~1 M live surfels, 640x480, TUM1 intrinsics.
+  --config 2: ORBextractor only.                      --config 3: SurfelFusion only (~1 M live surfels).
+  --config 4: ICL-NUIM intrinsics (fy = -480), ORB on every frame, SurfelFusion on every k-th frame (--keyframe-every,
+        default 4; the reference's cadence is data dependent, src/Tracking.cc:1433-1508), plane membership variant B
+        (three rectangular plane regions) standing in for the PEAC output.
+  --config 5: the frontend workload on 1280x960 frames (2x TUM1 intrinsics); meant for --gpus 8, one sequence per GPU.
+
+Each rank owns an independent sequence (weak scaling); the only inter-GPU traffic is one RCCL all_gather of per-sequence
+counters after the timed loop.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,32 +36,64 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8.0 TB/s
-W, H = 640, 480
 SURFEL_BYTES = 56              # sizeof(Surfel), reference include/Surfel.h:28-37
-K_FUSE = 7                     # kernel id of k_fuse in msl_sf_kernel_name()
-ORB_READ_BYTES = 2 * 950532    # 2 * sum of the 8 pyramid level areas at 640x480, scale 1.2
+
+CONFIGS = {
+    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1,
+                     name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
+    "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 2: ORBextractor only"),
+    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 3: SurfelFusion only"),
+    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="B", kfe=4,
+              name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + SurfelFusion every k-th frame, "
+                   "plane membership variant B in place of the PEAC output"),
+    "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1,
+              name="BASELINE config 5: ORB + SurfelFusion on every frame, 1280x960 sequences"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames-per-step", type=int, default=32)
+    ap.add_argument("--config", default="frontend", choices=sorted(CONFIGS))
+    ap.add_argument("--size", default=None, help="WxH override (multiples of 8)")
+    ap.add_argument("--keyframe-every", type=int, default=None, help="SurfelFusion on every k-th frame")
+    ap.add_argument("--frames-per-step", type=int, default=128)
+    ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames generated per sequence (tiled to a step)")
     ap.add_argument("--surfels", type=int, default=1_000_000)
-    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample, ~14 s on one core (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the single-thread CPU-baseline sample (0 = no CPU baseline)")
     ap.add_argument("--no-breakdown", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true", help="launcher / aggregation check on CPU (gloo), no GPU work, fabricated timings")
+    return ap.parse_args(argv)
 
 
-def build_inputs(rank, F, n_surfels):
-    """F RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host)."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (no rendezvous in the environment): become the launcher of N ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def build_inputs(rank, D, n_surfels, W, H, intr, variant, need_orb_texture=True):
+    """D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host)."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
     grays, depths, poses = [], [], []
     member = None
-    for f in range(F):
-        _, depth, member, pose = synth.surfel_frame(f, seed=7 + 1000 * rank)
-        grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f))     # one gray image per frame, used by both stages
+    for f in range(D):
+        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=7 + 1000 * rank)
+        # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
+        grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f, W, H) if need_orb_texture else g)
         depths.append(depth)
         poses.append(pose)
     smap = synth.surfel_map(n_surfels, ref=0, seed=11 + rank, min_update_times=5).astype(SURFEL_DTYPE)
@@ -59,20 +103,17 @@ def build_inputs(rank, F, n_surfels):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json."""
-    import glob
-    best = None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json")), key=os.path.getmtime)
     cur = os.path.join(ROOT, "profiles", "current.txt")   # tag of the profile that matches the committed kernels
-    if os.path.exists(cur):
-        files.append(os.path.join(ROOT, "profiles", open(cur).read().strip() + "_summary.json"))
-    for f in files:
-        try:
-            e = json.load(open(f)).get(kernel)
-        except Exception:
-            continue
-        if e and "fetch_bytes_corrected" in e and "write_bytes" in e:
-            best = (e["fetch_bytes_corrected"] + e["write_bytes"], os.path.basename(f))
-    return best
+    if not os.path.exists(cur):
+        return None
+    f = os.path.join(ROOT, "profiles", open(cur).read().strip() + "_summary.json")
+    try:
+        e = json.load(open(f)).get(kernel)
+    except Exception:  # noqa: BLE001
+        return None
+    if e and "fetch_bytes_corrected" in e and "write_bytes" in e:
+        return e["fetch_bytes_corrected"] + e["write_bytes"], os.path.basename(f)
+    return None
 
 
 def aggregate(local_ms, counters, world, device=None):
@@ -89,43 +130,64 @@ def aggregate(local_ms, counters, world, device=None):
     return float(t.item()), [o.tolist() for o in out]
 
 
-def cpu_baseline(grays, depths, member, poses, smap, n_frames):
-    """The CPU oracle (a port: the reference itself cannot be built without OpenCV/Eigen) on a bounded sample."""
-    from tests import oracle_lib
-    from manhattanslam_amd import synth
-    o = oracle_lib.load()
-    ex = o.orb_create(1000, 1.2, 8, 20, 7)
-    I = synth.TUM1
-    sf = oracle_lib.OracleSurfel(W, H, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
-    sf.map_set(smap)
-    F = len(grays)
-    t_orb = t_sf = 0.0
-    for i in range(n_frames):
-        f = i % F
-        t0 = time.perf_counter()
-        ex.extract(grays[f])
-        t1 = time.perf_counter()
-        sf.fuse_map(i, grays[f], depths[f], member, poses[f])
-        t2 = time.perf_counter()
-        t_orb += t1 - t0
-        t_sf += t2 - t1
-    tot = t_orb + t_sf
-    return {"value": round(n_frames / tot, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_frames} frames of the same workload (ORB + surfel fusion per frame, {len(smap)} seeded surfels), "
-                      f"single thread, oracle/libmsl_oracle.so (g++ -O3, no -march=native)",
-            "orb_ms_per_frame": round(1e3 * t_orb / n_frames, 2), "surfel_ms_per_keyframe": round(1e3 * t_sf / n_frames, 2),
-            "host_cpus": os.cpu_count()}
+def cpu_baseline(args, cfg, W, H, kfe):
+    """tools/cpu_baseline.py in its own interpreter: the oracle (a port: the reference cannot be built without OpenCV/Eigen)
+    on bounded samples of the same workload -- 1 thread, the reference's 10-thread SurfelFusion, one sequence per host core."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--frames", str(args.cpu_frames), "--size", f"{W}x{H}",
+           "--intrinsics", cfg["intr"], "--surfels", str(args.surfels), "--keyframe-every", str(kfe)]
+    if not cfg["orb"]:
+        cmd.append("--no-orb")
+    if not cfg["sf"]:
+        cmd.append("--no-surfel")
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        res = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"cpu baseline failed: {e!r}"}
+    top = res.get("throughput") if "value" in res.get("throughput", {}) else res.get("single_thread", {})
+    out = {"value": top.get("value"), "unit": top.get("unit", "frames/s"), "cores": top.get("cores"), "kind": "port", "sample": top.get("sample"),
+           "host_cpus": res.get("host_cpus"), "code": res.get("code")}
+    for k in ("single_thread", "surfel_10_threads", "throughput"):
+        if k in res:
+            out[k] = res[k]
+    return out
+
+
+def dry_run(args, world, rank):
+    """Launcher / aggregation path without a GPU: gloo, fabricated per-rank timings and counters."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    F = args.frames_per_step
+    local_ms = 10.0 + 5.0 * rank
+    counters = [args.steps * F, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
+    total_ms, gathered = aggregate(local_ms, counters, world, None)
+    if rank == 0:
+        frames = sum(g[0] for g in gathered)
+        print(json.dumps({"metric": "RGB-D frames/sec at 640x480 (ORB+surfel front end)", "value": round(frames / (total_ms * 1e-3), 1),
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(total_ms / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dry_run": True, "data": "none (fabricated timings: launcher / gloo aggregation check only)",
+                          "counters_per_rank": gathered}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line whose n_gpus differs from --gpus")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front end has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -134,46 +196,75 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from manhattanslam_amd import ORBextractor, SurfelFusion, synth
+    cfg = CONFIGS[args.config]
+    W, H = (int(v) for v in (args.size or cfg["size"]).lower().split("x"))
+    kfe = args.keyframe_every or cfg["kfe"]
+    do_orb, do_sf = cfg["orb"], cfg["sf"]
     F = args.frames_per_step
-    grays, depths, member, poses, smap = build_inputs(rank, F, args.surfels)
-    I = synth.TUM1
-    orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=F, device=local_rank)
-    sf = SurfelFusion(W, H, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5, device=local_rank)
-    sf.set_batch_capacity(F)
-    sf.map_reserve(2 * args.surfels + 65536)
-    sf.map_upload(smap)
+    if F % kfe:
+        raise SystemExit("--frames-per-step must be a multiple of --keyframe-every")
+    D = min(args.distinct_frames, F)
+    if F % D:
+        raise SystemExit("--frames-per-step must be a multiple of --distinct-frames")
+    nkf = F // kfe if do_sf else 0
+    intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
+    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg["variant"])
 
-    d_gray = torch.from_numpy(grays).to(dev)
-    d_depth = torch.from_numpy(depths).to(dev)
-    d_member = torch.from_numpy(member).to(dev)
-    cap = orb.capacity
-    d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
-    d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
-    d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    orb = sf = None
+    d_gray = torch.from_numpy(grays).to(dev).repeat(F // D, 1, 1).contiguous()
+    if do_orb:
+        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=F, device=local_rank)
+        cap = orb.capacity
+        d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
+        d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
+        d_n = torch.zeros(F, dtype=torch.int32, device=dev)
+    if do_sf:
+        sf = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=local_rank)
+        sf.set_batch_capacity(nkf)
+        sf.map_reserve(2 * args.surfels + 65536)
+        sf.map_upload(smap)
+        d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
+        d_member = torch.from_numpy(member).to(dev)
+        kf_poses = [poses[(j * kfe) % D] for j in range(nkf)]
     torch.cuda.synchronize()
 
-    frame_no = [0]
+    kf_no = [0]
+
+    def step_orb():
+        orb.extract_batch_device(d_gray, d_kps, d_desc, d_n, F, W, H)
+
+    def step_sf():
+        # the superpixel stage of the step's keyframes is frame-batched, the map stage runs keyframe after keyframe
+        sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray, d_depth, d_member, kf_poses, device=True, member_shared=True,
+                               frame_step=kfe)
+        kf_no[0] += nkf
 
     def step():
-        # ORB: one frame-batched launch sequence.  Surfel fusion: every frame is a keyframe; the superpixel stage of the
-        # F keyframes is frame-batched, the map stage (fuse / new surfels / compaction) runs keyframe after keyframe.
-        orb.extract_batch_device(d_gray, d_kps, d_desc, d_n, F, W, H)
-        sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True,
-                               member_shared=True)
-        frame_no[0] += F
+        if do_orb:
+            step_orb()
+        if do_sf:
+            step_sf()
 
     def sync_all():
-        orb.sync()
-        sf.sync()
+        if do_orb:
+            orb.sync()
+        if do_sf:
+            sf.sync()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
     sync_all()
-    n_live_start = sf.counters()["n_live_after"]
+    n_live_start = sf.counters()["n_live_after"] if do_sf else 0
 
-    # ---- timed region: exactly K steps, bracketed by barrier + synchronize; only k_fuse carries HIP events ----
-    sf.profile_enable(1 << K_FUSE)
+    # ---- timed region: exactly K steps, bracketed by barrier + synchronize; only the roofline kernel carries HIP events ----
+    sf_names = {v: k for k, v in enumerate(sf.kernel_names())} if do_sf else {}
+    orb_names = {v: k for k, v in enumerate(orb.kernel_names())} if do_orb else {}
+    roof_kernel = "k_fuse" if do_sf else "k_fast"
+    if do_sf:
+        sf.profile_enable(1 << sf_names[roof_kernel])
+    else:
+        orb.profile_enable(1 << orb_names[roof_kernel])
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -185,10 +276,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     local_ms = (time.perf_counter() - t0) * 1e3
-    fuse_ms, fuse_launches = sf.profile_read()["k_fuse"]
-    sf.profile_enable(0)
-    ctr = sf.counters()
-    n_kp = int(d_n.sum().item())
+    if do_sf:
+        roof_ms, roof_launches = sf.profile_read()[roof_kernel]
+        sf.profile_enable(0)
+    else:
+        roof_ms, roof_launches = orb.profile_read()[roof_kernel]
+        orb.profile_enable(0)
+    ctr = sf.counters() if do_sf else dict(n_live_after=0, n_new=0, n_updated=0, n_deleted=0)
+    n_kp = int(d_n.sum().item()) if do_orb else 0
     counters = [args.steps * F, n_kp, ctr["n_live_after"], ctr["n_new"], ctr["n_updated"], ctr["n_deleted"], int(local_ms * 1e6), n_live_start]
     total_ms, gathered = aggregate(local_ms, counters, world, dev)
 
@@ -200,78 +295,115 @@ def main():
     frames_total = args.steps * F * world
     value = frames_total / (total_ms * 1e-3)
     n_live_avg = 0.5 * (n_live_start + ctr["n_live_after"])
-    fuse_s = fuse_ms * 1e-3 / max(fuse_launches, 1)
-    achieved = SURFEL_BYTES * n_live_avg / fuse_s / 1e9 if fuse_launches else 0.0
+    sum_pl = sum(w * h for w, h in (orb.level_size(l) for l in range(8))) if do_orb else 0   # sum of the pyramid level areas
+    launch_s = roof_ms * 1e-3 / max(roof_launches, 1)
+    # algorithmic bytes per launch of the roofline kernel: k_fuse reads the live surfels (56 B each) once per
+    # keyframe; k_fast reads every pyramid level of the F frames of a step once
+    alg_bytes = SURFEL_BYTES * n_live_avg if do_sf else float(sum_pl * F)
+    achieved = alg_bytes / launch_s / 1e9 if roof_launches else 0.0
+    alg_frame = (2 * sum_pl if do_orb else 0) + ((SURFEL_BYTES * n_live_avg + 5 * W * H + W * H) / kfe if do_sf else 0)
+    traffic = pmc_traffic(roof_kernel) if args.config == "frontend" else None
     out = {
-        "metric": "RGB-D frames/sec at 640x480 (ORB+surfel front end)",
+        "metric": f"RGB-D frames/sec at {W}x{H} (ORB+surfel front end)" if do_orb and do_sf else
+                  (f"frames/sec at {W}x{H} (ORBextractor only)" if do_orb else f"keyframes/sec at {W}x{H} (SurfelFusion only)"),
         "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(total_ms / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u8/i32 (ORB), f32+f64 (surfel)", "data": "synthetic",
-        "config": {"workload": "ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame (keyframe_every=1), "
-                               "640x480, one independent sequence per GPU",
-                   "frames_per_step": F, "seeded_surfels": args.surfels, "n_live_surfels": int(n_live_avg),
-                   "intrinsics": "TUM1", "sequences_per_gpu": 1},
-        "roofline": {"bound": "hbm", "kernel": "k_fuse", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": (pmc_traffic("k_fuse") or (None, None))[0],
-                     "traffic_source": (pmc_traffic("k_fuse") or (None, "no committed PMC summary"))[1],
-                     "algorithmic_bytes_per_launch": int(SURFEL_BYTES * n_live_avg), "avg_launch_us": round(fuse_s * 1e6, 2),
-                     "timer": "HIP events carried by the k_fuse dispatch (hipExtLaunchKernelGGL) on the map stream, timed region",
-                     "launches": int(fuse_launches)},
-        # whole-pipeline algorithmic HBM reads per frame (ORB 2 * sum P_l + surfel 56 N + 5 W H + 4 (W/2)(H/2))
-        # times the per-GPU frame rate, against the same peak
-        "pipeline_roofline": {"algorithmic_read_bytes_per_frame": int(ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 5 * W * H + W * H),
-                              "achieved": round((ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 6 * W * H) * value / world / 1e9, 1),
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round((ORB_READ_BYTES + SURFEL_BYTES * n_live_avg + 6 * W * H) * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+        "dtype": "/".join((["u8/i32 (ORB)"] if do_orb else []) + (["f32+f64 (surfel)"] if do_sf else [])), "data": "synthetic",
+        "config": {"workload": f"{cfg['name']} (keyframe_every={kfe}), {W}x{H}, one independent sequence per GPU",
+                   "config": args.config, "frames_per_step": F, "keyframes_per_step": nkf, "keyframe_every": kfe, "distinct_frames": D,
+                   "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg), "intrinsics": cfg["intr"],
+                   "membership": cfg["variant"], "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4)},
+        "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else "no committed PMC summary for this config",
+                     "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(launch_s * 1e6, 2),
+                     "timer": f"HIP events carried by the {roof_kernel} dispatch (hipExtLaunchKernelGGL) on its own stream, timed region",
+                     "launches": int(roof_launches)},
+        # whole-pipeline algorithmic HBM reads per frame (ORB 2 * sum P_l + surfel (56 N + 5 W H + 4 (W/2)(H/2)) per
+        # keyframe) times the per-GPU frame rate, against the same peak
+        "pipeline_roofline": {"algorithmic_read_bytes_per_frame": int(alg_frame),
+                              "achieved": round(alg_frame * value / world / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(alg_frame * value / world / 1e9 / HBM_PEAK_GBS, 4)},
         "counters_per_rank": gathered,
     }
 
     if not args.no_breakdown:
         # per-kernel HIP-event breakdown (outside the timed region) + stage-only rates
-        sf.profile_enable(-1)
-        orb.profile_enable(-1)
+        if do_sf:
+            sf.profile_enable(-1)
+        if do_orb:
+            orb.profile_enable(-1)
         for _ in range(2):
             step()
         sync_all()
         nfr = 2 * F
         out["kernel_us_per_frame"] = {
-            **{k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in sf.profile_read().items() if c},
-            **{"orb:" + k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in orb.profile_read().items() if c}}
-        sf.profile_enable(0)
-        orb.profile_enable(0)
-        t0 = time.perf_counter()
-        for _ in range(10):
-            orb.extract_batch_device(d_gray, d_kps, d_desc, d_n, F, W, H)
-        orb.sync()
-        out["orb_only_fps"] = round(10 * F / (time.perf_counter() - t0), 1)
-        t0 = time.perf_counter()
-        for _ in range(4):
-            sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True, member_shared=True)
-            frame_no[0] += F
-        sf.sync()
-        out["surfel_only_keyframes_per_sec"] = round(4 * F / (time.perf_counter() - t0), 1)
-
-    if not args.no_breakdown:
-        # the same kernel without co-running work: put the whole surfel pipeline on ONE stream (no overlap with the batched
-        # superpixel stage or ORB) and time k_fuse again.  Reported next to, never instead of, the in-region roofline.
-        sf.set_stream(torch.cuda.current_stream().cuda_stream)
-        sf.profile_enable(1 << K_FUSE)
-        for _ in range(2):
-            sf.fuse_resident_batch(np.arange(frame_no[0], frame_no[0] + F), d_gray, d_depth, d_member, poses, device=True, member_shared=True)
-            frame_no[0] += F
-        ms_iso, n_iso = sf.profile_read()["k_fuse"]
-        sf.profile_enable(0)
-        n_now = sf.counters()["n_live_after"]
-        iso = SURFEL_BYTES * n_now / (ms_iso * 1e-3 / max(n_iso, 1)) / 1e9
-        out["roofline_isolated"] = {"kernel": "k_fuse", "achieved": round(iso, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(iso / HBM_PEAK_GBS, 4), "avg_launch_us": round(ms_iso * 1e3 / max(n_iso, 1), 2),
-                                    "note": "single stream, no co-running kernels; HIP events carried by the dispatch"}
+            **({k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in sf.profile_read().items() if c} if do_sf else {}),
+            **({"orb:" + k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in orb.profile_read().items() if c} if do_orb else {})}
+        if do_sf:
+            sf.profile_enable(0)
+        if do_orb:
+            orb.profile_enable(0)
+            t0 = time.perf_counter()
+            for _ in range(4):
+                step_orb()
+            orb.sync()
+            out["orb_only_fps"] = round(4 * F / (time.perf_counter() - t0), 1)
+        if do_sf:
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step_sf()
+            sf.sync()
+            out["surfel_only_keyframes_per_sec"] = round(2 * nkf / (time.perf_counter() - t0), 1)
+            # the same kernel without co-running work: the whole surfel pipeline on ONE stream (no overlap with the batched
+            # superpixel stage or ORB), k_fuse timed again.  Reported next to, never instead of, the in-region roofline.
+            sf.set_stream(torch.cuda.current_stream().cuda_stream)
+            sf.profile_enable(1 << sf_names["k_fuse"])
+            step_sf()
+            ms_iso, n_iso = sf.profile_read()["k_fuse"]
+            sf.profile_enable(0)
+            n_now = sf.counters()["n_live_after"]
+            iso = SURFEL_BYTES * n_now / (ms_iso * 1e-3 / max(n_iso, 1)) / 1e9
+            out["roofline_isolated"] = {"kernel": "k_fuse", "achieved": round(iso, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(iso / HBM_PEAK_GBS, 4), "avg_launch_us": round(ms_iso * 1e3 / max(n_iso, 1), 2),
+                                        "note": "single stream, no co-running kernels; HIP events carried by the dispatch"}
+        if world == 1:
+            out["dropin"] = dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf, local_rank)
 
     if args.cpu_frames > 0 and world == 1:
-        out["cpu_baseline"] = cpu_baseline(grays, depths, member, poses, smap, args.cpu_frames)
+        out["cpu_baseline"] = cpu_baseline(args, cfg, W, H, kfe)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf, device):
+    """The call shapes the reference's unchanged call sites use (adapter/ORBextractor.cc, adapter/SurfelFusion.cpp): synchronous,
+    host buffers in and out, PCIe inclusive.  Never part of `value`."""
+    from manhattanslam_amd import ORBextractor, SurfelFusion
+    out = {}
+    if do_orb:
+        ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=1, device=device)
+        ex(grays[0])
+        t0 = time.perf_counter()
+        n = 20
+        for i in range(n):
+            ex(grays[i % len(grays)])
+        out["msl_orb_extract_ms"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
+        ex.close()
+    if do_sf:
+        s2 = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=device)
+        local = smap.copy()
+        s2.fuseInitializeMap(0, grays[0], depths[0], member, poses[0], local)
+        t0 = time.perf_counter()
+        n = 3
+        for i in range(n):
+            s2.fuseInitializeMap(1 + i, grays[(1 + i) % len(grays)], depths[(1 + i) % len(grays)], member, poses[(1 + i) % len(grays)], local)
+        out["msl_sf_fuse_host_vector_ms"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
+        out["msl_sf_fuse_host_vector_surfels"] = len(local)
+        s2.close()
+    out["note"] = "synchronous drop-in entry points with host buffers (PCIe in and out included); one frame / one keyframe per call"
+    return out
 
 
 if __name__ == "__main__":

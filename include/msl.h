@@ -194,9 +194,12 @@ MSL_API int msl_sf_map_size(msl_sf *h, size_t *n_out);
 
 /* fuseInitializeMap + the SurfelMapping::fuseMap slot refill / tail compaction
  * (src/SurfelMapping.cpp:353-392) on the resident map.  Image pointers may be host or device
- * (img_mem).  Asynchronous on the handle's stream; msl_sf_sync() (or map_size/download) waits.
- * counters_out (may be NULL; host) receives after sync {n_live_before, n_new, n_deleted, n_updated,
- * n_live_after}; pass it to msl_sf_last_counters instead to stay asynchronous. */
+ * (img_mem).  Asynchronous on the handle's streams: only argument errors are reported by the call itself;
+ * device-side errors are DEFERRED to the next msl_sf_sync / map_size / download / detach / append / export
+ * / last_counters, which return MSL_ERR_OVERFLOW once.  The resident map grows on demand (like the
+ * reference's std::vector): when the host-side upper bound of the live count reaches the capacity the call
+ * syncs once and reallocates; msl_sf_map_reserve avoids that pause.  msl_sf_last_counters gives
+ * {n_live_before, n_new, n_deleted, n_updated, n_live_after} of the last keyframe. */
 MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8_t *gray,
                                  size_t gray_stride, const float *depth, size_t depth_stride,
                                  const int32_t *member, size_t member_stride, msl_mem img_mem,

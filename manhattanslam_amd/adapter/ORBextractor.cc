@@ -1,8 +1,10 @@
 // Adapter: ORB_SLAM2::ORBextractor on top of the msl C ABI (replaces the reference's src/ORBextractor.cc).
 #include "ORBextractor.h"
 
+#include <cassert>
 #include <cstring>
 #include <stdexcept>
+#include <string>
 
 namespace ORB_SLAM2 {
 

@@ -51,3 +51,5 @@ void SurfelFusion::fuseMapResident(const int referenceFrameIndex, const cv::Mat 
                                pose.data()),
           "msl_sf_fuse_resident");
 }
+
+void SurfelFusion::sync() { check(msl_sf_sync(mHandle), "msl_sf_sync"); }

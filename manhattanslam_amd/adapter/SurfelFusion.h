@@ -35,6 +35,10 @@ public:
     void downloadMap(std::vector<Surfel> &localSurfels);
     void fuseMapResident(const int referenceFrameIndex, const cv::Mat &inputImage, const cv::Mat &inputDepth,
                          const cv::Mat &inputPlaneMembershipImg, const Eigen::Matrix4f &pose);
+    // Waits for the enqueued keyframes and throws if a device-side bound was exceeded (errors of the asynchronous
+    // resident calls are deferred to the next sync).
+    void sync();
+    msl_sf *handle() const { return mHandle; }   // for adapter/SurfelMapping.cpp (map maintenance on the resident map)
 
 private:
     msl_sf *mHandle;

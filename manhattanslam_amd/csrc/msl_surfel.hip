@@ -1583,6 +1583,7 @@ struct msl_sf {
     bool propLds = false;        // t(s) of one keyframe fits the LDS: single-launch relaxation
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
+    size_t liveBound = 0;        // host-side upper bound of the live count: last synced count + nseeds per keyframe enqueued since
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
@@ -1609,18 +1610,30 @@ int sync_all(msl_sf *h) {
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
-    MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
-    MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: k_compact reads its first tile unconditionally
-    MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
-    MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
-    MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
-    MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
-    MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
-    if (keep && h->d_mapStore) {
-        int rc = sync_all(h);
-        if (rc != MSL_OK) return rc;
-        MSL_HIP_TRY(hipMemcpy(nstore, h->d_mapStore, sizeof(HotRec) * keep, hipMemcpyDeviceToDevice));
-        MSL_HIP_TRY(hipMemcpy(nstore + 5 * cap, h->d_mapStore + 5 * h->mapCap, sizeof(ColdRec) * keep, hipMemcpyDeviceToDevice));
+    auto attempt = [&]() -> int {
+        MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
+        MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
+        MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
+        MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
+        MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
+        MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
+        MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
+        if (keep && h->d_mapStore) {
+            int rc = sync_all(h);
+            if (rc != MSL_OK) return rc;
+            MSL_HIP_TRY(hipMemcpy(nstore, h->d_mapStore, sizeof(HotRec) * keep, hipMemcpyDeviceToDevice));
+            MSL_HIP_TRY(hipMemcpy(nstore + 5 * cap, h->d_mapStore + 5 * h->mapCap, sizeof(ColdRec) * keep, hipMemcpyDeviceToDevice));
+        }
+        return MSL_OK;
+    };
+    const int arc = attempt();
+    if (arc != MSL_OK) {   // nothing of a failed attempt stays allocated; the old map is untouched
+        if (nstore) (void)hipFree(nstore);
+        if (nbs) (void)hipFree(nbs);
+        if (nbu) (void)hipFree(nbu);
+        if (ndl) (void)hipFree(ndl);
+        if (nso) (void)hipFree(nso);
+        return arc;
     }
     if (h->d_mapStore) {
         (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
@@ -1667,6 +1680,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
     D.invDepth = h->d_invDepth; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
     h->maxBatch = maxBatch;
+    h->lastSlot = 0;            // the debug accessors must never index beyond the reallocated slot buffers
     h->evMapValid[0] = h->evMapValid[1] = false;
     h->evCopyValid[0] = h->evCopyValid[1] = false;
     return MSL_OK;
@@ -1677,6 +1691,7 @@ int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 8, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
+    h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
     return MSL_OK;
 }
 
@@ -1713,6 +1728,23 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     if (!gray || !depth || !member || !poses || !refs || gs < (size_t)W || ds < (size_t)W * 4 || ms < (size_t)(W / 2) * 4 || (ds & 3) || (ms & 3)) {
         set_error("msl_sf: bad image pointers or strides");
         return MSL_ERR_INVALID;
+    }
+    if (compact) {
+        // The reference's mvLocalSurfels is an unbounded std::vector (include/Map.h:130): grow the resident map before a batch could
+        // overflow it.  Every keyframe adds at most nseeds surfels, so the host only needs an upper bound of the live count; the
+        // exact count is read back (one sync) only when that bound reaches the capacity.
+        const size_t need = (size_t)n * (size_t)D.nseeds;
+        if (h->liveBound + need > h->mapCap) {
+            int rc = read_ctr(h);
+            if (rc != MSL_OK) return rc;
+            rc = check_err(h);
+            if (rc != MSL_OK) return rc;
+            if (h->liveBound + need > h->mapCap) {
+                rc = map_realloc(h, 2 * h->liveBound + 2 * need + 65536, h->liveBound);
+                if (rc != MSL_OK) return rc;
+            }
+        }
+        h->liveBound += need;
     }
     const int set = (int)(h->batchNo & 1), slot0 = set * h->maxBatch;
     hipStream_t sp = h->preStream, sm = h->mapStream;
@@ -1935,6 +1967,7 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     }
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipStreamSynchronize(s));
+    h->liveBound = n;
     return MSL_OK;
 }
 
@@ -2019,6 +2052,7 @@ int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     hipLaunchKernelGGL(k_aos_to_soa_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev.map, h->d_aos, (long long)n, h->d_ctr);
     hipLaunchKernelGGL(k_add_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n);
     MSL_HIP_TRY(hipStreamSynchronize(s));
+    h->liveBound = cur + n;
     return MSL_OK;
 }
 
@@ -2119,6 +2153,8 @@ int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {
     return MSL_OK;
 }
 int msl_debug_div100(const float *x_host, double *out_host, size_t n) {
+    if (n == 0) return MSL_OK;
+    if (!x_host || !out_host) return MSL_ERR_INVALID;
     float *dx = nullptr; double *dout = nullptr;
     MSL_HIP_TRY(hipMalloc(&dx, sizeof(float) * n)); MSL_HIP_TRY(hipMalloc(&dout, sizeof(double) * n));
     MSL_HIP_TRY(hipMemcpy(dx, x_host, sizeof(float) * n, hipMemcpyHostToDevice));

@@ -146,6 +146,10 @@ class ORBextractor:
     def profile_enable(self, mode=-1):
         check(lib.msl_orb_profile_enable(self._h, int(mode)))
 
+    @staticmethod
+    def kernel_names():
+        return [lib.msl_orb_kernel_name(k).decode() for k in range(MSL_ORB_NKERNELS)]
+
     def profile_read(self):
         ms = np.zeros(MSL_ORB_NKERNELS, np.float32)
         cnt = np.zeros(MSL_ORB_NKERNELS, np.int32)

@@ -62,6 +62,14 @@ def orb_frames(n, seed=ORB_SEED, w=640, h=480):
 # ------------------------------------------------------------------------------------------------
 TUM1 = dict(fx=517.306408, fy=516.469215, cx=318.643040, cy=255.313989)   # Example/TUM1.yaml:8-11
 ICL = dict(fx=481.20, fy=-480.00, cx=319.50, cy=239.50)                   # Example/ICL.yaml:8-11
+
+
+def scaled_intrinsics(intr, w):
+    """Intrinsics of the same camera at image width w (the 1280x960 sequences of BASELINE config 5 use 2x TUM1)."""
+    s = w / 640.0
+    return {k: v * s for k, v in intr.items()}
+
+
 ROOM = np.array([3.0, 1.5, 2.5])  # half extents: x in [-3,3], y in [-1.5,1.5], z in [-2.5,2.5]
 
 SURFEL_FIELDS = ("px", "py", "pz", "nx", "ny", "nz", "size", "color", "r", "g", "b", "weight", "updateTimes", "lastUpdate")

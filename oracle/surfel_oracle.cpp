@@ -18,11 +18,20 @@
 //   * Eigen 4x4 inverses (float pose, double Hessian) = adjugate / determinant, products accumulate
 //     column by column left to right.
 //   * unqualified fabs() on floats = std::fabs(float).
+//
+// Threads.  Every stage is written over the reference's THREAD_NUM = 10 partitions (row bands / seed chunks / surfel
+// ranges, src/SurfelFusion.cpp:359-363, 430-434, 530-534, 598-602, 616-621, 664-668, 173-177).  The checker runs the
+// partitions one after another on one thread (the pinned semantics above).  mslo_sf_set_threads(h, 1) instead forks one
+// std::thread per partition and stage exactly like the reference's launchers (:417-426, :517-526, :586-595, :775-803,
+// :59-70); that mode exists ONLY as the 10-thread CPU timing baseline of bench.py -- updatePixels then has the
+// reference's own `stable` race, so its output is not used for parity.
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <thread>
 #include <vector>
 
 #include "../include/msl.h"
@@ -70,6 +79,19 @@ struct Fusion {
     std::vector<float> normMap;
     std::vector<Seed> seeds;
     std::vector<int> index;
+    bool threaded = false;   // timing baseline only (see header)
+
+    // fork/join of THREAD_NUM partitions (the reference's stage launchers), or the same partitions in order on this thread
+    void run_parts(const std::function<void(int)> &part) {
+        if (!threaded) { for (int t = 0; t < THREAD_NUM; t++) part(t); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < THREAD_NUM; t++) pool.emplace_back(part, t);
+        for (auto &th : pool) th.join();
+    }
+    static void part_range(int total, int t, int &b, int &e) {   // step = total / threadNum; the last thread takes the rest
+        const int step = total / THREAD_NUM;
+        b = step * t; e = t == THREAD_NUM - 1 ? total : b + step;
+    }
 
     Fusion(int w, int h, float fx_, float fy_, float cx_, float cy_, float far_, float near_)
         : W(w), H(h), spW(w / SP_SIZE), spH(h / SP_SIZE), fx(fx_), fy(fy_), cx(cx_), cy(cy_), fuseFar(far_), fuseNear(near_) {
@@ -102,8 +124,11 @@ struct Fusion {
     static float getWeight(float d) { return (float)std::min(1.0 / d / d, 1.0); }  // :87-89
 
     // ---- :528-584 ----
-    void initializeSeeds() {
-        for (int seedI = 0; seedI < (int)seeds.size(); seedI++) {
+    void initializeSeeds() { run_parts([this](int t) { initializeSeedsKernel(t); }); }
+    void initializeSeedsKernel(int thread) {
+        int beginIndex, endIndex;
+        part_range((int)seeds.size(), thread, beginIndex, endIndex);
+        for (int seedI = beginIndex; seedI < endIndex; seedI++) {
             const int spX = seedI % spW, spY = seedI / spW;
             int imageX = spX * SP_SIZE + SP_SIZE / 2, imageY = spY * SP_SIZE + SP_SIZE / 2;
             imageX = imageX < (W - 1) ? imageX : (W - 1);
@@ -152,8 +177,11 @@ struct Fusion {
     }
 
     // ---- :357-415, raster order ----
-    void updatePixels() {
-        for (int rowI = 0; rowI < H; rowI++)
+    void updatePixels() { run_parts([this](int t) { updatePixelsKernel(t); }); }
+    void updatePixelsKernel(int thread) {
+        int startRow, endRow;
+        part_range(H, thread, startRow, endRow);
+        for (int rowI = startRow; rowI < endRow; rowI++)
             for (int colI = 0; colI < W; colI++) {
                 if (plane(rowI / 2, colI / 2) != -1) continue;
                 if (seeds[index[rowI * W + colI]].stable) continue;
@@ -186,11 +214,11 @@ struct Fusion {
     }
 
     // ---- :428-515, THREAD_NUM chunks with the early `return` ----
-    void updateSeeds() {
-        const int total = (int)seeds.size(), step = total / THREAD_NUM;
-        for (int thread = 0; thread < THREAD_NUM; thread++) {
-            const int beginIndex = step * thread;
-            const int endIndex = thread == THREAD_NUM - 1 ? total : beginIndex + step;
+    void updateSeeds() { run_parts([this](int t) { updateSeedsKernel(t); }); }
+    void updateSeedsKernel(int thread) {
+        {
+            int beginIndex, endIndex;
+            part_range((int)seeds.size(), thread, beginIndex, endIndex);
             for (int seedI = beginIndex; seedI < endIndex; seedI++) {
                 Seed &S = seeds[seedI];
                 if (!S.use) continue;
@@ -242,8 +270,11 @@ struct Fusion {
     }
 
     // ---- :597-613 ----
-    void calculateSpaces() {
-        for (int rowI = 0; rowI < H; rowI++)
+    void calculateSpaces() { run_parts([this](int t) { calculateSpacesKernel(t); }); }
+    void calculateSpacesKernel(int thread) {
+        int startRow, endRow;
+        part_range(H, thread, startRow, endRow);
+        for (int rowI = startRow; rowI < endRow; rowI++)
             for (int colI = 0; colI < W; colI++) {
                 const int i = rowI * W + colI;
                 double x, y, z;
@@ -253,8 +284,14 @@ struct Fusion {
     }
 
     // ---- :615-661 ----
-    void calculatePixelsNorms() {
-        for (int rowI = 1; rowI < H - 1; rowI++)
+    void calculatePixelsNorms() { run_parts([this](int t) { calculatePixelsNormsKernel(t); }); }
+    void calculatePixelsNormsKernel(int thread) {
+        const int stepRow = H / THREAD_NUM;   // :616-621 (thread 0 starts at row 1 and so also covers the first row of thread 1)
+        int startRow = stepRow * thread;
+        startRow = startRow > 1 ? startRow : 1;
+        int endRow = startRow + stepRow;
+        if (thread == THREAD_NUM - 1) endRow = H - 1;
+        for (int rowI = startRow; rowI < endRow; rowI++)
             for (int colI = 1; colI < W - 1; colI++) {
                 const int i = rowI * W + colI;
                 float myX = (float)spaceMap[i * 3], myY = (float)spaceMap[i * 3 + 1], myZ = (float)spaceMap[i * 3 + 2];
@@ -320,9 +357,12 @@ struct Fusion {
     }
 
     // ---- :663-773 ----
-    void calculateSpDepthNorms() {
+    void calculateSpDepthNorms() { run_parts([this](int t) { calculateSpDepthNormsKernel(t); }); }
+    void calculateSpDepthNormsKernel(int thread) {
         const int total = (int)index.size();
-        for (int seedI = 0; seedI < (int)seeds.size(); seedI++) {
+        int beginIndex, endIndex;
+        part_range((int)seeds.size(), thread, beginIndex, endIndex);
+        for (int seedI = beginIndex; seedI < endIndex; seedI++) {
             Seed &S = seeds[seedI];
             const int spX = seedI % spW, spY = seedI / spW;
             const int xb = spX * SP_SIZE + SP_SIZE / 2 - SP_SIZE, yb = spY * SP_SIZE + SP_SIZE / 2 - SP_SIZE;
@@ -393,13 +433,17 @@ struct Fusion {
 
     // ---- :167-283 ----
     void fuseSurfels(int referenceFrameIndex, const float *pose, const float *invPose, Surfel *local, size_t n) {
+        run_parts([=](int t) { fuseSurfelsKernel(t, referenceFrameIndex, pose, invPose, local, n); });
+    }
+    void fuseSurfelsKernel(int thread, int referenceFrameIndex, const float *pose, const float *invPose, Surfel *local, size_t n) {
+        const size_t step = n / THREAD_NUM, beginIndex = step * thread, endIndex = thread == THREAD_NUM - 1 ? n : beginIndex + step;   // :173-177
         auto mul4 = [](const float *m, const float v[4], float out[4]) {
             for (int r = 0; r < 4; r++) out[r] = ((m[r] * v[0] + m[4 + r] * v[1]) + m[8 + r] * v[2]) + m[12 + r] * v[3];
         };
         auto mul3 = [](const float *m, const float v[3], float out[3]) {
             for (int r = 0; r < 3; r++) out[r] = (m[r] * v[0] + m[4 + r] * v[1]) + m[8 + r] * v[2];
         };
-        for (size_t i = 0; i < n; i++) {
+        for (size_t i = beginIndex; i < endIndex; i++) {
             Surfel &L = local[i];
             if (referenceFrameIndex - L.lastUpdate > 5 && L.updateTimes < 5) { L.updateTimes = 0; continue; }
             if (L.updateTimes == 0) continue;
@@ -528,6 +572,9 @@ MSLO_API mslo_sf *mslo_sf_create(int w, int h, float fx, float fy, float cx, flo
     return new mslo_sf(w, h, fx, fy, cx, cy, far_, near_);
 }
 MSLO_API void mslo_sf_destroy(mslo_sf *h) { delete h; }
+// 0 = the checker (partitions in order on one thread); 1 = the reference's fork/join of THREAD_NUM std::threads per stage
+// (CPU timing baseline only: updatePixels then races exactly like the reference)
+MSLO_API void mslo_sf_set_threads(mslo_sf *h, int threaded) { h->f.threaded = threaded != 0; }
 
 // SurfelFusion::fuseInitializeMap: local updated in place, returns number of new surfels (or -1)
 MSLO_API long mslo_sf_fuse(mslo_sf *h, int ref, const uint8_t *gray, size_t gstride, const float *depth, size_t dstride,

@@ -183,6 +183,7 @@ class OracleSurfel:
         d.mslo_sf_fuse_map.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                        C.c_void_p]
         d.mslo_sf_seeds.argtypes = [C.c_void_p, C.c_void_p]
+        d.mslo_sf_set_threads.argtypes = [C.c_void_p, C.c_int]
         d.mslo_sf_index.argtypes = [C.c_void_p, C.c_void_p]
         d.mslo_fuse_map_compact.restype = C.c_size_t
         d.mslo_fuse_map_compact.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
@@ -202,6 +203,10 @@ class OracleSurfel:
                                     member.strides[0], _p(pose), _p(local), len(local), _p(new), len(new))
         assert n >= 0
         return local, new[:n].copy()
+
+    def set_threads(self, threaded):
+        """True: the reference's THREAD_NUM = 10 std::threads per stage (CPU timing baseline only; racy like the reference)."""
+        self.o.dll.mslo_sf_set_threads(self.hd, 1 if threaded else 0)
 
     def map_set(self, m):
         m = np.ascontiguousarray(m)

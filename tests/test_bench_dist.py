@@ -46,3 +46,30 @@ def test_aggregate_single_rank_passthrough():
     sys.path.insert(0, ROOT)
     import bench
     assert bench.aggregate(3.5, [1, 2, 3], 1) == (3.5, [[1, 2, 3]])
+
+
+def _run_bench(*argv, env=None):
+    import json
+    import subprocess
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=300, env=e)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment must start 2 ranks itself (torch.distributed.run) and
+    report n_gpus = 2 with one counter record per rank; --dry-run swaps RCCL for gloo and skips the GPU work."""
+    rc, line, err = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--frames-per-step", "8")
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert len(line["counters_per_rank"]) == 2 and [c[1] for c in line["counters_per_rank"]] == [1000, 2000]
+    assert line["value"] == round(2 * 2 * 8 / 0.015, 1)          # frames of all ranks / max-over-ranks time
+
+
+def test_bench_refuses_gpus_world_mismatch():
+    rc, line, err = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and line is None and "refusing" in err

@@ -84,6 +84,24 @@ def test_edge_cases(gpu_orb, oracle):
     _assert_same(kg, dg, ko, do)
 
 
+def test_scale_tables_match_oracle(oracle):
+    """a13: the getters of include/ORBextractor.h:58-80 (f32 cumulative products of src/ORBextractor.cc:416-430) and
+    mnFeaturesPerLevel (:433-445), bit for bit, for the default and two other parameter sets."""
+    from manhattanslam_amd import ORBextractor
+    for nf, sc, nl in ((1000, 1.2, 8), (500, 1.2, 6), (2000, 1.5, 5)):
+        ex = ORBextractor(nf, sc, nl, 20, 7)
+        sf, isf, s2, is2, per, _ = oracle.orb_create(nf, sc, nl, 20, 7).tables()
+        for got, want in ((ex.GetScaleFactors(), sf), (ex.GetInverseScaleFactors(), isf), (ex.GetScaleSigmaSquares(), s2),
+                          (ex.GetInverseScaleSigmaSquares(), is2)):
+            assert np.array_equal(got.view(np.int32), want.view(np.int32))
+        assert np.array_equal(ex.features_per_level(), per) and ex.GetLevels() == nl
+        assert np.float32(ex.GetScaleFactor()) == np.float32(sc) and ex.capacity == nf + 2 * nl
+        ex.close()
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    assert list(ex.features_per_level()) == [217, 181, 151, 126, 105, 87, 73, 60]      # SURVEY.md section 8 table
+    ex.close()
+
+
 def test_other_sizes_and_params(oracle):
     """Smaller frame, fewer features/levels, other thresholds."""
     from manhattanslam_amd import ORBextractor, synth

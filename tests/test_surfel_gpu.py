@@ -365,3 +365,74 @@ def test_handles_of_different_sizes_coexist(oracle):
             o.fuse_map(k, *f)
         assert_surfels_close(g.map_download(), o.map_get(), f"{w}x{h}")
     gb.close(); gs.close()
+
+
+def test_config4_icl_live_map_negative_fy(oracle):
+    """BASELINE config 4 as a parity case: ICL intrinsics (fy = -480, Example/ICL.yaml:8-11) on a NON-empty resident map with plane
+    membership variant B, four keyframes: k_fuse's projection / cameraF = (|fx| + |fy|) / 2 path (src/SurfelFusion.cpp:75-78,
+    204-221) under negative fy, incl. deletions, updates, new surfels and compaction."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.ICL)
+    m = synth.surfel_map(150000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(300000)
+    g.map_upload(m)
+    o.map_set(m)
+    tot_upd = tot_del = 0
+    for k in range(4):
+        gray, depth, member, pose = synth.surfel_frame(k, intr=synth.ICL, variant="B")
+        g.fuse_resident(k, gray, depth, member, pose)
+        n_new = o.fuse_map(k, gray, depth, member, pose)
+        c = g.counters()
+        assert c["n_new"] == n_new
+        tot_upd += c["n_updated"]; tot_del += c["n_deleted"]
+        assert np.array_equal(g.debug_index(), o.index())
+        assert_seeds_close(g.debug_seeds(), o.seeds())
+        assert_surfels_close(g.map_download(), o.map_get(), f"ICL map after keyframe {k}")
+    assert tot_upd > 10000 and tot_del > 100      # the live map really is fused under fy < 0
+    g.close()
+
+
+def test_keyframe_every_k_frame_step(oracle):
+    """fuse_resident_batch(frame_step=k): keyframe j = frame j*k of a device-resident sequence (bench config 4's cadence)."""
+    import torch
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.ICL)
+    g.set_batch_capacity(3)
+    m = synth.surfel_map(60000, ref=0).astype(SURFEL_DTYPE)
+    g.map_reserve(200000); g.map_upload(m); o.map_set(m)
+    frames = [synth.surfel_frame(k, intr=synth.ICL, variant="B") for k in range(5)]
+    dg, dd = (torch.from_numpy(np.stack([f[i] for f in frames])).cuda() for i in (0, 1))
+    dm = torch.from_numpy(frames[0][2]).cuda()
+    g.fuse_resident_batch([0, 1, 2], dg, dd, dm, [frames[j][3] for j in (0, 2, 4)], device=True, member_shared=True, frame_step=2)
+    for r, j in enumerate((0, 2, 4)):
+        o.fuse_map(r, frames[j][0], frames[j][1], frames[j][2], frames[j][3])
+    assert_surfels_close(g.map_download(), o.map_get(), "map after keyframes 0, 2, 4")
+    g.close()
+
+
+def test_resident_map_grows_without_reserve(oracle):
+    """The reference's mvLocalSurfels is an unbounded std::vector: fusing keyframes past the initial 65 536-slot capacity without
+    any msl_sf_map_reserve call must keep every new surfel (the map silently stopped growing)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(60000, ref=0).astype(SURFEL_DTYPE)
+    g.map_upload(m)          # capacity = what upload chose; no reserve
+    o.map_set(m)
+    for k in range(6):       # ~4 k new surfels per keyframe on a sparse map: crosses 65 536 and the upload slack
+        gray, depth, member, pose = synth.surfel_frame(3 * k)
+        g.fuse_resident(k, gray, depth, member, pose)
+        o.fuse_map(k, gray, depth, member, pose)
+    mo = o.map_get()
+    assert len(mo) > 65536 + 4800
+    assert_surfels_close(g.map_download(), mo, "map grown past its initial capacity")
+    # batched form: several keyframes enqueued at once must reserve for all of them up front
+    g.set_batch_capacity(4)
+    frames = [synth.surfel_frame(20 + 5 * k) for k in range(8)]
+    for b in range(2):
+        fr = frames[4 * b:4 * b + 4]
+        g.fuse_resident_batch([6 + 4 * b + j for j in range(4)], np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]),
+                              np.stack([f[2] for f in fr]), [f[3] for f in fr])
+        for j, f in enumerate(fr):
+            o.fuse_map(6 + 4 * b + j, f[0], f[1], f[2], f[3])
+    assert_surfels_close(g.map_download(), o.map_get(), "map grown by batches")
+    g.close()

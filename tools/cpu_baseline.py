@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""CPU baseline of bench.py: the oracle restatement (oracle/libmsl_oracle.so, g++ -O3, no -march=native --
+the reference itself needs OpenCV/Eigen and cannot be built) timed on this host's cores on a bounded sample of the SAME
+synthetic workload.  Runs in its own interpreter (no HIP runtime in the process that forks workers) and prints one JSON object:
+
+  single_thread      ORB 1 thread per frame (src/Frame.cc:100) + SurfelFusion on one thread, frame after frame
+  surfel_10_threads  SurfelFusion with the reference's THREAD_NUM = 10 fork/join per stage (include/SurfelFusion.h:34)
+  throughput         one independent sequence per host core (P worker processes, each ORB + SurfelFusion, single-threaded)
+
+Test infrastructure / reported baseline only; nothing here is on the product path.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def build_inputs(F, n_surfels, W, H, intr_name, rank=0):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("msl_synth", os.path.join(ROOT, "manhattanslam_amd", "synth.py"))
+    synth = importlib.util.module_from_spec(spec)   # synth.py alone: importing the package would load libmsl.so / HIP
+    spec.loader.exec_module(synth)
+    intr = synth.scaled_intrinsics(getattr(synth, intr_name), W)
+    grays, depths, poses = [], [], []
+    member = None
+    for f in range(F):
+        _, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, seed=7 + 1000 * rank)
+        grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f, W, H))
+        depths.append(depth)
+        poses.append(pose)
+    smap = synth.surfel_map(n_surfels, ref=0, seed=11 + rank, min_update_times=5)
+    return np.stack(grays), np.stack(depths), member, poses, smap, intr
+
+
+def run_sequence(inp, W, H, n_frames, do_orb=True, do_sf=True, threads10=False, keyframe_every=1):
+    from tests import oracle_lib
+    grays, depths, member, poses, smap, intr = inp
+    o = oracle_lib.load()
+    ex = o.orb_create(1000, 1.2, 8, 20, 7) if do_orb else None
+    sf = None
+    if do_sf:
+        sf = oracle_lib.OracleSurfel(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5)
+        sf.map_set(smap.astype(oracle_lib.SURFEL_DTYPE))
+        if threads10:
+            sf.set_threads(True)
+    F = len(grays)
+    t_orb = t_sf = 0.0
+    n_kf = 0
+    t_begin = time.perf_counter()
+    for i in range(n_frames):
+        f = i % F
+        t0 = time.perf_counter()
+        if ex is not None:
+            ex.extract(grays[f])
+        t1 = time.perf_counter()
+        if sf is not None and i % keyframe_every == 0:
+            sf.fuse_map(i, grays[f], depths[f], member, poses[f])
+            n_kf += 1
+        t2 = time.perf_counter()
+        t_orb += t1 - t0
+        t_sf += t2 - t1
+    return t_begin, time.perf_counter(), t_orb, t_sf, n_kf
+
+
+def _worker(inp, W, H, n_frames, do_orb, do_sf, kfe, barrier, q):
+    try:
+        barrier.wait()
+        q.put(run_sequence(inp, W, H, n_frames, do_orb, do_sf, False, kfe))
+    except Exception as e:  # noqa: BLE001
+        q.put(("error", repr(e)))
+
+
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 8 << 30
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=48, help="frames of the single-thread sample")
+    ap.add_argument("--frames-10t", type=int, default=32, help="keyframes of the 10-thread SurfelFusion sample")
+    ap.add_argument("--frames-per-proc", type=int, default=4, help="frames each process of the throughput run handles")
+    ap.add_argument("--procs", type=int, default=0, help="processes of the throughput run (0 = one per logical CPU, memory permitting)")
+    ap.add_argument("--surfels", type=int, default=1_000_000)
+    ap.add_argument("--size", default="640x480")
+    ap.add_argument("--intrinsics", default="TUM1")
+    ap.add_argument("--distinct-frames", type=int, default=16)
+    ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--no-surfel", action="store_true")
+    ap.add_argument("--keyframe-every", type=int, default=1)
+    args = ap.parse_args()
+    W, H = (int(v) for v in args.size.lower().split("x"))
+    do_orb, do_sf, kfe = not args.no_orb, not args.no_surfel, args.keyframe_every
+    inp = build_inputs(args.distinct_frames, args.surfels if do_sf else 16, W, H, args.intrinsics)
+    ncpu = os.cpu_count() or 1
+    out = {"host_cpus": ncpu, "kind": "port",
+           "code": "oracle/libmsl_oracle.so (CPU restatement of src/ORBextractor.cc + src/SurfelFusion.cpp + SurfelMapping::fuseMap; g++ -O3, no -march=native)"}
+    what = ("ORB + " if do_orb else "") + (f"SurfelFusion every {kfe} frame(s), {args.surfels} seeded surfels" if do_sf else "no surfel stage")
+
+    if args.frames > 0:
+        tb, te, t_orb, t_sf, nkf = run_sequence(inp, W, H, args.frames, do_orb, do_sf, False, kfe)
+        out["single_thread"] = {"value": round(args.frames / (te - tb), 3), "unit": "frames/s", "cores": 1,
+                                "sample": f"{args.frames} frames, {what}, {W}x{H}",
+                                "orb_ms_per_frame": round(1e3 * t_orb / args.frames, 2),
+                                "surfel_ms_per_keyframe": round(1e3 * t_sf / max(nkf, 1), 2)}
+    if args.frames_10t > 0 and do_sf:
+        tb, te, _, t_sf, nkf = run_sequence(inp, W, H, args.frames_10t, False, True, True, 1)
+        out["surfel_10_threads"] = {"value": round(nkf / t_sf, 3), "unit": "keyframes/s", "cores": 10,
+                                    "sample": f"{nkf} keyframes, SurfelFusion only with the reference's THREAD_NUM=10 fork/join per stage, "
+                                              f"{args.surfels} seeded surfels, {W}x{H}",
+                                    "surfel_ms_per_keyframe": round(1e3 * t_sf / max(nkf, 1), 2)}
+    if args.frames_per_proc > 0:
+        per_proc = 96 * W * H * 3 + 2 * 56 * (args.surfels if do_sf else 0) + (64 << 20)   # oracle scratch + map + copy + interpreter
+        P = args.procs or max(1, min(ncpu, int(0.5 * mem_available_bytes() // per_proc)))
+        ctx = mp.get_context("fork")
+        barrier = ctx.Barrier(P)
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker, args=(inp, W, H, args.frames_per_proc, do_orb, do_sf, kfe, barrier, q)) for _ in range(P)]
+        for p in procs:
+            p.start()
+        res = [q.get() for _ in procs]
+        for p in procs:
+            p.join()
+        err = [r for r in res if r[0] == "error"]
+        if err:
+            out["throughput"] = {"error": err[0][1]}
+        else:
+            wall = max(r[1] for r in res) - min(r[0] for r in res)
+            out["throughput"] = {"value": round(P * args.frames_per_proc / wall, 2), "unit": "frames/s", "cores": P,
+                                 "sample": f"{P} independent sequences (one single-threaded process per logical CPU) x {args.frames_per_proc} frames, "
+                                           f"{what}, {W}x{H}",
+                                 "wall_s": round(wall, 3)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
