@@ -54,12 +54,14 @@ CONFIGS = {
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="frontend", choices=sorted(CONFIGS))
     ap.add_argument("--size", default=None, help="WxH override (multiples of 8)")
     ap.add_argument("--keyframe-every", type=int, default=None, help="SurfelFusion on every k-th frame")
-    ap.add_argument("--frames-per-step", type=int, default=128)
+    ap.add_argument("--frames-per-step", type=int, default=256, help="frames one step pushes through the hot path (each with its own input memory)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per library call; a step issues frames-per-step / batch calls.  The scratch of "
+                    "2 x batch keyframe slots plus the map should stay inside the 256 MB Infinity Cache: 128-frame batches measured 35 %% slower")
     ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames generated per sequence (tiled to a step)")
     ap.add_argument("--surfels", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the single-thread CPU-baseline sample (0 = no CPU baseline)")
@@ -201,19 +203,19 @@ def main():
     kfe = args.keyframe_every or cfg["kfe"]
     do_orb, do_sf = cfg["orb"], cfg["sf"]
     F = args.frames_per_step
-    if F % kfe:
-        raise SystemExit("--frames-per-step must be a multiple of --keyframe-every")
+    B = min(args.batch, F)
     D = min(args.distinct_frames, F)
-    if F % D:
-        raise SystemExit("--frames-per-step must be a multiple of --distinct-frames")
-    nkf = F // kfe if do_sf else 0
+    if F % B or B % kfe or F % D:
+        raise SystemExit("--frames-per-step must be a multiple of --batch and --distinct-frames, --batch a multiple of --keyframe-every")
+    nsub = F // B
+    nkf = B // kfe if do_sf else 0   # keyframes per library call
     intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
     grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg["variant"])
 
     orb = sf = None
     d_gray = torch.from_numpy(grays).to(dev).repeat(F // D, 1, 1).contiguous()
     if do_orb:
-        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=F, device=local_rank)
+        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=local_rank)
         cap = orb.capacity
         d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
         d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
@@ -225,25 +227,35 @@ def main():
         sf.map_upload(smap)
         d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
         d_member = torch.from_numpy(member).to(dev)
-        kf_poses = [poses[(j * kfe) % D] for j in range(nkf)]
+        kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
     torch.cuda.synchronize()
 
     kf_no = [0]
+    cap_ = orb.capacity if do_orb else 0
 
-    def step_orb():
-        orb.extract_batch_device(d_gray, d_kps, d_desc, d_n, F, W, H)
+    def sub_orb(sb):
+        orb.extract_batch_device(d_gray[sb * B:], d_kps[sb * B * cap_ * 28:], d_desc[sb * B * cap_ * 32:], d_n[sb * B:], B, W, H)
 
-    def step_sf():
-        # the superpixel stage of the step's keyframes is frame-batched, the map stage runs keyframe after keyframe
-        sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray, d_depth, d_member, kf_poses, device=True, member_shared=True,
-                               frame_step=kfe)
+    def sub_sf(sb):
+        # the superpixel stage of a call's keyframes is frame-batched, the map stage runs keyframe after keyframe
+        sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], d_member, kf_poses[sb], device=True,
+                               member_shared=True, frame_step=kfe)
         kf_no[0] += nkf
 
+    def step_orb():
+        for sb in range(nsub):
+            sub_orb(sb)
+
+    def step_sf():
+        for sb in range(nsub):
+            sub_sf(sb)
+
     def step():
-        if do_orb:
-            step_orb()
-        if do_sf:
-            step_sf()
+        for sb in range(nsub):
+            if do_orb:
+                sub_orb(sb)
+            if do_sf:
+                sub_sf(sb)
 
     def sync_all():
         if do_orb:
@@ -299,7 +311,7 @@ def main():
     launch_s = roof_ms * 1e-3 / max(roof_launches, 1)
     # algorithmic bytes per launch of the roofline kernel: k_fuse reads the live surfels (56 B each) once per
     # keyframe; k_fast reads every pyramid level of the F frames of a step once
-    alg_bytes = SURFEL_BYTES * n_live_avg if do_sf else float(sum_pl * F)
+    alg_bytes = SURFEL_BYTES * n_live_avg if do_sf else float(sum_pl * B)
     achieved = alg_bytes / launch_s / 1e9 if roof_launches else 0.0
     alg_frame = (2 * sum_pl if do_orb else 0) + ((SURFEL_BYTES * n_live_avg + 5 * W * H + W * H) / kfe if do_sf else 0)
     traffic = pmc_traffic(roof_kernel) if args.config == "frontend" else None
@@ -310,7 +322,7 @@ def main():
         "ms_per_step": round(total_ms / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "/".join((["u8/i32 (ORB)"] if do_orb else []) + (["f32+f64 (surfel)"] if do_sf else [])), "data": "synthetic",
         "config": {"workload": f"{cfg['name']} (keyframe_every={kfe}), {W}x{H}, one independent sequence per GPU",
-                   "config": args.config, "frames_per_step": F, "keyframes_per_step": nkf, "keyframe_every": kfe, "distinct_frames": D,
+                   "config": args.config, "frames_per_step": F, "frames_per_call": B, "keyframes_per_step": nkf * nsub, "keyframe_every": kfe, "distinct_frames": D,
                    "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg), "intrinsics": cfg["intr"],
                    "membership": cfg["variant"], "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4)},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -333,10 +345,9 @@ def main():
             sf.profile_enable(-1)
         if do_orb:
             orb.profile_enable(-1)
-        for _ in range(2):
-            step()
+        step()
         sync_all()
-        nfr = 2 * F
+        nfr = F
         out["kernel_us_per_frame"] = {
             **({k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in sf.profile_read().items() if c} if do_sf else {}),
             **({"orb:" + k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in orb.profile_read().items() if c} if do_orb else {})}
@@ -345,21 +356,20 @@ def main():
         if do_orb:
             orb.profile_enable(0)
             t0 = time.perf_counter()
-            for _ in range(4):
+            for _ in range(2):
                 step_orb()
             orb.sync()
-            out["orb_only_fps"] = round(4 * F / (time.perf_counter() - t0), 1)
+            out["orb_only_fps"] = round(2 * F / (time.perf_counter() - t0), 1)
         if do_sf:
             t0 = time.perf_counter()
-            for _ in range(2):
-                step_sf()
+            step_sf()
             sf.sync()
-            out["surfel_only_keyframes_per_sec"] = round(2 * nkf / (time.perf_counter() - t0), 1)
+            out["surfel_only_keyframes_per_sec"] = round(nkf * nsub / (time.perf_counter() - t0), 1)
             # the same kernel without co-running work: the whole surfel pipeline on ONE stream (no overlap with the batched
             # superpixel stage or ORB), k_fuse timed again.  Reported next to, never instead of, the in-region roofline.
             sf.set_stream(torch.cuda.current_stream().cuda_stream)
             sf.profile_enable(1 << sf_names["k_fuse"])
-            step_sf()
+            sub_sf(0)
             ms_iso, n_iso = sf.profile_read()["k_fuse"]
             sf.profile_enable(0)
             n_now = sf.counters()["n_live_after"]

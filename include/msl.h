@@ -240,6 +240,43 @@ MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth
                                  int window_h, double depth_alpha, double depth_change_tol, int init_loose, double *cloud_out,
                                  msl_peac_stats *stats_out, msl_mem out_mem);
 
+/* ---- widening, SURVEY.md 8(f) rank 3: Hamming matching by projection, the next consumer of the ORB descriptors ----
+ * msl_match_by_projection_batch: n_pairs independent calls of
+ *     int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th)   (src/ORBmatcher.cc:547-678)
+ * with Frame::GetFeaturesInArea (src/Frame.cc:332-381), ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:835-849) and the rotation
+ * histogram / ComputeThreeMaxima (:799-830), for an ORBmatcher with mbCheckOrientation = check_orientation.
+ * All per-keypoint arrays hold `cap` entries per pair (pair f at index f * cap); the current-frame arrays are exactly the
+ * outputs of msl_orb_extract_frame_batch (mvKeys for octave / angle, mvKeysUn.pt, mvuRight, grid cell, descriptors), so in a
+ * batched pipeline they never leave HBM.  Last frame, per keypoint i < n_last[f]:
+ *   last_xyz[3 i..]  LastFrame.mvpMapPoints[i]->GetWorldPos()          last_desc[32 i..]  ->GetDescriptor()
+ *   last_flags[i]    bit 0: mvpMapPoints[i] != NULL && !mvbOutlier[i]; bit 1: ->Observations() > 0
+ *   last_octave[i]   LastFrame.mvKeys[i].octave                        last_angle[i]      LastFrame.mvKeysUn[i].angle
+ * Tcw_cur / Tcw_last: rows 0-2 of the CV_32F 4x4 mTcw of the two frames, row-major (12 floats per pair).
+ * CurrentFrame.mvpMapPoints is all NULL on entry (src/Tracking.cc:1252); on return match_out[f * cap + i2] is the index i of the
+ * last-frame keypoint whose MapPoint current keypoint i2 holds, or -1 (NULL); nmatches[f] is the function's return value.
+ * The greedy, order-dependent assignment of the reference (a candidate already held by a point with Observations() > 0 is
+ * skipped, later points overwrite earlier ones) is reproduced exactly.  Limits: cap <= 8192, nlevels <= MSL_MATCH_MAX_LEVELS.
+ * Synchronous; `mem` / `out_mem` say where the input / the two output arrays live. */
+#define MSL_MATCH_MAX_LEVELS 16
+typedef struct msl_match_params {
+    float fx, fy, cx, cy;             /* CurrentFrame.fx .. cy */
+    float bf;                         /* mbf; mb = mbf / fx (src/Frame.cc:150) */
+    float minX, maxX, minY, maxY;     /* mnMinX .. (msl_frame_image_bounds) */
+    float th;                         /* search window: radius = th * mvScaleFactors[octave] */
+    int32_t check_orientation;        /* ORBmatcher::mbCheckOrientation */
+    int32_t nlevels;
+    float scale_factors[MSL_MATCH_MAX_LEVELS];   /* CurrentFrame.mvScaleFactors (msl_orb_scale_tables) */
+} msl_match_params;
+MSL_API int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params,
+                                          const msl_keypoint *cur_kps, const float *cur_un_xy, const float *cur_uright,
+                                          const int32_t *cur_grid_cell, const uint8_t *cur_desc, const int32_t *n_cur,
+                                          const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
+                                          const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
+                                          const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out,
+                                          int32_t *nmatches, msl_mem out_mem);
+/* ORBmatcher::DescriptorDistance for n descriptor pairs (host arrays; parity hook for the popcount path). */
+MSL_API int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out);
+
 /* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
  * Keyframe f's images start at base + f * <frame_stride> bytes (member_frame_stride may be 0: one shared
  * membership image); refs[n_frames] and poses (16 * n_frames floats, column-major Twc each) are host arrays.

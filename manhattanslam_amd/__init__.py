@@ -10,3 +10,5 @@ from .orb import ORBextractor, frame_params  # noqa: F401
 from .surfel import SurfelFusion, SurfelMap  # noqa: F401
 from . import peac  # noqa: F401
 from ._lib import PEAC_STATS_DTYPE  # noqa: F401
+from . import match  # noqa: F401
+from ._lib import MATCH_PARAMS_DTYPE  # noqa: F401

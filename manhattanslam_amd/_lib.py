@@ -24,6 +24,8 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
                        ("_pad", "u1")])
 PEAC_STATS_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")])
 FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
+MATCH_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "bf", "minX", "maxX", "minY", "maxY", "th")] +
+                              [("check_orientation", "<i4"), ("nlevels", "<i4"), ("scale_factors", "<f4", (16,))])
 assert KEYPOINT_DTYPE.itemsize == 28 and SURFEL_DTYPE.itemsize == 56 and SEED_DTYPE.itemsize == 64
 
 MSL_MEM_HOST, MSL_MEM_DEVICE = 0, 1
@@ -63,6 +65,8 @@ SIGNATURES = {
     "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
+    "msl_match_by_projection_batch": (_i, [_i, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),
+    "msl_match_descriptor_distance": (_i, [_i, _vp, _vp, _i, _vp]),
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
     "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
     "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),

@@ -22,7 +22,7 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
 
 
 def build():
-    srcs = [os.path.join(ODIR, f) for f in ("orb_oracle.cpp", "surfel_oracle.cpp", "Makefile")]
+    srcs = [os.path.join(ODIR, f) for f in ("orb_oracle.cpp", "surfel_oracle.cpp", "peac_oracle.cpp", "match_oracle.cpp", "Makefile")]
     if not os.path.exists(OLIB) or any(os.path.getmtime(s) > os.path.getmtime(OLIB) for s in srcs if os.path.exists(s)):
         subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
     return OLIB
@@ -281,3 +281,34 @@ def peac_block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10
     f(_p(d), d.strides[0], W, H, fx, fy, cx, cy, depth_map_factor, window[0], window[1], depth_alpha, depth_change_tol, 1 if init_loose else 0,
       _p(cloud), _p(stats))
     return cloud, stats
+
+
+# ------------------------------------------------------------------------------------------------
+# Hamming matching by projection
+# ------------------------------------------------------------------------------------------------
+MATCH_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "bf", "minX", "maxX", "minY", "maxY", "th")] +
+                              [("check_orientation", "<i4"), ("nlevels", "<i4"), ("scale_factors", "<f4", (16,))])
+
+
+def search_by_projection(params, cur, last, Tcw_cur, Tcw_last):
+    """oracle/match_oracle.cpp for ONE pair: same dict layout as manhattanslam_amd.match.search_by_projection_batch."""
+    f = load().dll.mslo_search_by_projection
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] + [C.c_void_p] * 8
+    c = {k: np.ascontiguousarray(v) for k, v in cur.items()}
+    l = {k: np.ascontiguousarray(v) for k, v in last.items()}
+    tc = np.ascontiguousarray(np.asarray(Tcw_cur, np.float32)[:3, :4]); tl = np.ascontiguousarray(np.asarray(Tcw_last, np.float32)[:3, :4])
+    n = len(c["kps"])
+    out = np.zeros(max(n, 1), np.int32)
+    nm = f(_p(params), n, _p(c["kps"]), _p(c["un_xy"].astype(np.float32)), _p(c["uright"].astype(np.float32)), _p(c["grid_cell"].astype(np.int32)),
+           _p(c["desc"]), len(l["xyz"]), _p(l["xyz"].astype(np.float32)), _p(l["desc"]), _p(l["flags"].astype(np.uint8)),
+           _p(l["octave"].astype(np.int32)), _p(l["angle"].astype(np.float32)), _p(tc), _p(tl), _p(out))
+    return out[:n].copy(), nm
+
+
+def descriptor_distance(a, b):
+    f = load().dll.mslo_descriptor_distance
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p]
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+    return np.array([f(_p(a[i]), _p(b[i])) for i in range(len(a))], np.int32)

@@ -415,24 +415,28 @@ def test_resident_map_grows_without_reserve(oracle):
     any msl_sf_map_reserve call must keep every new surfel (the map silently stopped growing)."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
     g, o = _mk(synth.TUM1)
-    m = synth.surfel_map(60000, ref=0).astype(SURFEL_DTYPE)
-    g.map_upload(m)          # capacity = what upload chose; no reserve
+    # 60 000 stable surfels far outside the fusion range (never updated, never deleted): the map can only grow
+    m = synth.surfel_map(60000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
+    m["px"] += 100.0; m["py"] += 100.0; m["pz"] += 100.0
+    g.map_upload(m)          # capacity = what create/upload chose (65 536); no reserve
     o.map_set(m)
-    for k in range(6):       # ~4 k new surfels per keyframe on a sparse map: crosses 65 536 and the upload slack
-        gray, depth, member, pose = synth.surfel_frame(3 * k)
+    for k in range(4):       # views 60 degrees apart: each keyframe spawns a few thousand new surfels
+        gray, depth, member, pose = synth.surfel_frame(120 * k)
         g.fuse_resident(k, gray, depth, member, pose)
         o.fuse_map(k, gray, depth, member, pose)
     mo = o.map_get()
-    assert len(mo) > 65536 + 4800
+    assert len(mo) > 65536 + 2000, len(mo)
     assert_surfels_close(g.map_download(), mo, "map grown past its initial capacity")
     # batched form: several keyframes enqueued at once must reserve for all of them up front
     g.set_batch_capacity(4)
-    frames = [synth.surfel_frame(20 + 5 * k) for k in range(8)]
+    frames = [synth.surfel_frame(60 + 120 * k) for k in range(8)]
     for b in range(2):
         fr = frames[4 * b:4 * b + 4]
-        g.fuse_resident_batch([6 + 4 * b + j for j in range(4)], np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]),
+        g.fuse_resident_batch([4 + 4 * b + j for j in range(4)], np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]),
                               np.stack([f[2] for f in fr]), [f[3] for f in fr])
         for j, f in enumerate(fr):
-            o.fuse_map(6 + 4 * b + j, f[0], f[1], f[2], f[3])
-    assert_surfels_close(g.map_download(), o.map_get(), "map grown by batches")
+            o.fuse_map(4 + 4 * b + j, f[0], f[1], f[2], f[3])
+    mo = o.map_get()
+    assert len(mo) > 80000, len(mo)
+    assert_surfels_close(g.map_download(), mo, "map grown by batches")
     g.close()
