@@ -99,12 +99,14 @@ struct SfDev {
     int *changed;                // [slots][8]
     MapSoA map;
     unsigned long long cap;
-    // ctr[0]=n_live  [1]=K new (last)  [2]=D deleted (last)  [3]=updated (last)  [4]=n before (last)  [5]=err  [6]=n after (last)  [7]=tail fallback flag
+    // ctr[0]=n_live  [1]=K new (last)  [2]=D deleted (last)  [3]=updated (last)  [4]=n before (last)  [5]=err  [6]=n after (last)
+    // [7]=selection total (k_select_scan)  [8]=pending lazy tail moves
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
-    unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
-    unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
+    unsigned *delStage;          // [cap] per sub-block (256 slots) the slots k_fuse found deleted, ascending, from the sub-block's first entry
+    unsigned *tickets;           // [0] k_fuse's "last workgroup continues" ticket, [2] delUCount
+    unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of the continuation)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
     const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
 };
@@ -1014,15 +1016,192 @@ __device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_fla
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks).
-//   Phase A (streaming): each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records
-//   per lane.  The ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.
-//   Survivors are compacted into an LDS list (slot by LDS atomic; per-surfel work is order independent).
-//   Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed,
-//   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
-// Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
+// k_fuse (:167-283) -- the whole map stage of one keyframe in ONE launch.
+//   Streaming part: each wave owns sub-blocks of 256 consecutive surfels.
+//     Phase A: each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records per lane.  The
+//     ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.  Survivors are compacted into
+//     an LDS list (slot by LDS atomic; per-surfel work is order independent).
+//     Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed, cold
+//     record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
+//   Everything the compaction needs is handed over with write-through (agent-scope) stores: per-sub-block deleted counts and,
+//   for the sub-blocks that deleted something, their deleted slots in ascending order (a 256-bit LDS bitmap per wave, expanded
+//   by eight lanes); the updated count per workgroup; the `fused` flag of a seed (only the first store per XCD: the flag is
+//   read together with the seed record and stored only when it still reads 0).
+//   Continuation: the workgroup that draws the last ticket runs SurfelMapping::fuseMap's refill / compaction
+//   (src/SurfelMapping.cpp:366-391) and initializeSurfels (:285-331), see compact_tail() below.
+//   Lazy tail moves: when more slots were deleted than new surfels arrived, the reference moves tail elements into the
+//   leftover holes.  The moved records may still sit dirty in another XCD's L2, so the continuation only publishes the move
+//   list (hole -> source) and the new live count; the NEXT launch treats a hole as "the record at source" (phase A redirect,
+//   binary search in the list) and materialises it while streaming.  Host-visible accessors flush the list first.
+constexpr int CT_PEND = 8;   // ctr[8]: number of pending lazy tail moves (delList[a] <- srcOf[a], a < pend)
 
-__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
+__device__ __forceinline__ void st_agent_u8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// source of the pending move whose destination is slot i, or -1
+__device__ __forceinline__ long long pend_source(const SfDev &P, long long pend, long long i) {
+    long long lo = 0, hi = pend;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < i) lo = mid + 1; else hi = mid; }
+    return (lo < pend && (long long)P.delList[lo] == i) ? (long long)P.srcOf[lo] : -1;
+}
+
+__device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
+    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
+    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
+    M.hot[i] = h; M.cold[i] = c;
+}
+__device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
+    M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
+}
+
+// Continuation of k_fuse, one workgroup of NT threads.  mode 0: resident map.  mode 1 (host-vector drop-in): emission and
+// counters only; the caller compacts (SurfelMapping.cpp:366-391).
+//   D deleted slots d_0 < .. < d_{D-1}; new surfel k -> d_{D-1-k} while any remain, else appended (:372-384).  If D > K the
+//   literal `while` loop (:386-390) moves, at step i = 1..R (R = D - K), the element at position n - i into the i-th largest
+//   leftover hole; a hole inside the tail [nFinal, n) only relays what lands in it.  Net effect: the a-th smallest leftover
+//   hole below nFinal = n - R receives the a-th smallest LIVE element of the tail, i.e. position nFinal + a + j with j the
+//   number of tail holes below it (binary search over the hole list; checked against the literal loop by
+//   tests/test_surfel_gpu.py::test_compaction_matches_literal_loop).
+template <int NT>
+__device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned *s_raw /*>= LIST_D*/, unsigned *s_dl /*>= LIST_D*/, unsigned *s_wave /*>= 17*/,
+                             unsigned *s_misc /*>= 4*/) {
+    static_assert(LIST_D % NT == 0 || NT % LIST_D == 0, "strided loops below");
+    const int tid = threadIdx.x;
+    const long long n = P.ctr[0];
+    const bool bad = P.ctr[5] == 20;
+    const unsigned dHand = ld_agent(P.delUCount);
+    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS, nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;
+    if (tid == 0) { s_misc[0] = 0; }
+    // hand-over list of the fastest path: issue the loads before anything else
+    const bool fastest = mode == 0 && dHand <= LIST_D;
+    unsigned du[LIST_D / NT > 0 ? LIST_D / NT : 1];
+#pragma unroll
+    for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) {
+        const int j = tid + r * NT;
+        du[r] = (fastest && j < (int)dHand && j < LIST_D) ? ld_agent(&P.delU[j]) : 0xFFFFFFFFu;
+    }
+    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds;
+    const uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
+    const int s0 = tid * per, s1 = min(s0 + per, P.nseeds);
+    const bool wordsOk = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
+    auto spawns = [&](int i, unsigned cword, unsigned fword, int j) -> bool { return i + j < s1 && ((cword >> (8 * j)) & 0xFF) && !((fword >> (8 * j)) & 0xFF); };
+    auto flags_at = [&](int i, unsigned &c4, unsigned &f4) {   // four seeds' flags; `fused` was written in this launch: agent-scope loads
+        if (wordsOk && i + 4 <= P.nseeds) {
+            c4 = *reinterpret_cast<const unsigned *>(candOk + i);
+            f4 = ld_agent(reinterpret_cast<const unsigned *>(fused + i));
+        } else {
+            c4 = f4 = 0;
+            for (int j = 0; j < 4 && i + j < P.nseeds; j++) {
+                c4 |= (unsigned)candOk[i + j] << (8 * j);
+                f4 |= (unsigned)__hip_atomic_load(fused + i + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (8 * j);
+            }
+        }
+    };
+    unsigned cnt = 0;
+    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
+    for (int i = s0; i < s1; i += 4) {
+        unsigned c4, f4;
+        flags_at(i, c4, f4);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (spawns(i, c4, f4, j)) { cnt++; if (i + j - s0 < 64) emit |= 1ull << (i + j - s0); }
+    }
+    // updated count of this keyframe
+    {
+        unsigned u = 0;
+        for (long long c = tid; c < nWg; c += NT) u += ld_agent(&P.blockUpd[c]);
+        if (u) atomicAdd(&s_misc[0], u);
+    }
+    unsigned Ku, pos;
+    pos = block_excl_scan(cnt, s_wave, &Ku);
+    // ---- ascending list of the deleted slots ----
+    long long D = 0;
+    if (mode == 0 && !bad) {
+        if (fastest) {
+            D = dHand;
+#pragma unroll
+            for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) { const int j = tid + r * NT; if (j < LIST_D) s_raw[j] = du[r]; }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) {   // rank sort in LDS
+                const int j = tid + r * NT;
+                if (j < (int)D) {
+                    unsigned rk = 0;
+                    for (unsigned x = 0; x < (unsigned)D; x++) rk += s_raw[x] < du[r] ? 1u : 0u;
+                    s_dl[rk] = du[r];
+                }
+            }
+        } else {
+            // every k_fuse wave staged its sub-block's deleted slots in ascending order at delStage[sub * 256 ..]; an exclusive
+            // scan of the per-sub-block counts gives each staged run its place in the global ascending list
+            unsigned carry = 0;
+            constexpr int TILE = 4 * NT;
+            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+                const long long c = t0 + 4 * tid;
+                unsigned v[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v[j] = c + j < nblk ? ld_agent(&P.blockSums[c + j]) : 0u;
+                unsigned tot;
+                unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    for (unsigned r = 0; r < v[j]; r++) st_agent(&P.delList[ex + r], ld_agent(&P.delStage[(c + j) * SUB_ITEMS + r]));
+                    ex += v[j];
+                }
+                carry += tot;
+            }
+            D = carry;
+        }
+    }
+    if (mode != 0 || bad) D = dHand;   // counters only: k_fuse's running total of deleted slots
+    __syncthreads();
+    const long long K = Ku;
+    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
+    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
+    auto DL = [&](long long j) -> unsigned { return fastest ? s_dl[j] : ld_agent(&P.delList[j]); };
+    if (cnt) {
+        auto emit_one = [&](const msl_surfel &e) {
+            const long long k = pos++;
+            if (mode == 1) P.newSurfels[k] = e;     // host-vector mode returns this list
+            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
+                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
+        };
+        for (unsigned long long m = emit; m; m &= m - 1) emit_one(cand[s0 + __builtin_ctzll(m)]);
+        for (int i = s0 + 64; i < s1; i += 4) {
+            unsigned c4, f4;
+            flags_at(i, c4, f4);
+            for (int j = 0; j < 4; j++)
+                if (spawns(i, c4, f4, j)) emit_one(cand[i + j]);
+        }
+    }
+    long long nPublish = nAfter, pendOut = 0;
+    if (place && D > K) {
+        // lazy tail moves: leftover holes d_0 .. d_{R-1}; those below nFinal are the destinations
+        const long long R = D - K, nFinal = n - R;
+        long long lo = 0, hi = R;   // cntLow = first index in the hole list with value >= nFinal
+        while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < nFinal) lo = mid + 1; else hi = mid; }
+        const long long cntLow = lo, nTailHoles = R - cntLow;
+        for (long long a = tid; a < cntLow; a += NT) {
+            // a-th smallest live element of the tail: nFinal + a + j, j = number of tail holes below it
+            long long jl = 0, jh = nTailHoles;
+            while (jl < jh) { const long long mid = (jl + jh) >> 1; if ((long long)DL(cntLow + mid) - nFinal - mid > a) jh = mid; else jl = mid + 1; }
+            P.srcOf[a] = (unsigned)(nFinal + a + jl);
+            if (fastest) P.delList[a] = s_dl[a];   // the general path already holds the list in delList[]
+        }
+        nPublish = nFinal; pendOut = cntLow;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_misc[0]; P.ctr[4] = n; P.ctr[6] = nAfter;
+        if ((unsigned long long)nAfter > P.cap && mode == 0) P.ctr[5] = 20;  // capacity exceeded
+        if (place) { P.ctr[0] = nPublish; P.ctr[CT_PEND] = pendOut; }        // publish the new live count and the pending moves
+        st_agent(P.delUCount, 0u);                                           // re-arm the hand-over list
+    }
+}
+
+__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F, int mode) {   // F by value: kernarg -> SGPRs
     // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
@@ -1031,10 +1210,14 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
     // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
     __shared__ unsigned s_cnt[5], s_delSub[4];
     constexpr int LISTN = 4 * FUSE_NT;
+    static_assert(LISTN >= LIST_D, "the continuation reuses the survivor list as its hand-over buffer");
     __shared__ unsigned s_surv[LISTN];
-    __shared__ unsigned s_delBase;
+    __shared__ unsigned s_delBits[FUSE_WAVES][8];   // deleted slots of each wave's sub-block, one bit per surfel
+    __shared__ unsigned s_delBase, s_last;
+    __shared__ unsigned s_dl[LIST_D], s_wave[17], s_misc[4];
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
+    const long long pend = P.ctr[CT_PEND];
     const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + FUSE_WAVES - 1) / FUSE_WAVES;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
@@ -1047,15 +1230,18 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
         const long long b = nW - 1 - bq;   // the newest surfels (most phase-B work) are dispatched first
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
         if (threadIdx.x < FUSE_WAVES) s_delSub[threadIdx.x] = 0;
+        if (threadIdx.x < FUSE_WAVES * 8) (&s_delBits[0][0])[threadIdx.x] = 0;
         __syncthreads();
         unsigned nupd = 0;
-        // local index (10 bits) = wave << 8 | offset in the wave's sub-block
+        // local index (10 bits) = wave << 8 | offset in the wave's sub-block; bit 15 of a list entry = redirected record
         auto sub_base = [&](unsigned w) -> long long { return ((long long)w * nW + b) * SUB_ITEMS; };
-        auto global_of = [&](unsigned local) -> long long { return sub_base(local >> 8) + (local & 0xFFu); };
+        auto global_of = [&](unsigned local) -> long long { return sub_base((local >> 8) & 3u) + (local & 0xFFu); };
         const long long c0 = sub_base(wv);
         auto mark_deleted = [&](long long i) {
-            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
+            const unsigned off = (unsigned)(i - c0);
+            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | off;
             atomicAdd(&s_delSub[wv], 1u);
+            atomicOr(&s_delBits[wv][off >> 5], 1u << (off & 31u));
         };
         const bool hasSub = (long long)wv * nW + b < nSub;   // the last workgroups may own fewer than four sub-blocks
         // map capacity is a multiple of 4096: the 16-byte loads of an existing sub-block stay in bounds
@@ -1065,8 +1251,32 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
             uint4 q[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) q[j] = hp[j];
-            const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
-                                    q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+            unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
+                              q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+            unsigned redir = 0;
+            if (pend > 0) {   // (kernel-uniform) lazy tail moves of the previous keyframe: a hole below n stands for its source record
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const long long i = i0 + k;
+                    if (hasSub && i < n && (int)w[5 * k + 3] == 0) {
+                        const long long src = pend_source(P, pend, i);
+                        if (src >= 0) {
+                            const HotRec hs = M.hot[src];
+                            M.hot[i] = hs;                           // materialise the move now; phase B re-reads it past the L1
+                            {
+                                const unsigned *cs = reinterpret_cast<const unsigned *>(M.cold + src);
+                                unsigned *cd = reinterpret_cast<unsigned *>(M.cold + i);
+#pragma unroll
+                                for (int e = 0; e < 9; e++) cd[e] = cs[e];
+                            }
+                            w[5 * k] = __float_as_uint(hs.px); w[5 * k + 1] = __float_as_uint(hs.py); w[5 * k + 2] = __float_as_uint(hs.pz);
+                            w[5 * k + 3] = (unsigned)hs.updateTimes; w[5 * k + 4] = (unsigned)hs.lastUpdate;
+                            redir |= 1u << k;
+                        }
+                    }
+                }
+                if (redir) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the copies have reached the L2 before phase B looks for them
+            }
             // Branch-free up to the loads: the eight depth / superpixel lookups of the lane's (up to four) in-view surfels
             // leave together (lanes without an in-view surfel read some valid pixel), so the lane pays ONE dependent round trip.
             int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
@@ -1107,7 +1317,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
                 if (state[k] == 1) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
                 if (state[k] == 2) { mark_deleted(i); continue; }
                 if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (spi[k] << 16);
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (((redir >> k) & 1u) << 15) | (spi[k] << 16);
             }
         }
         __syncthreads();
@@ -1115,16 +1325,25 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
         unsigned ndelB = 0;
         for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
             const unsigned sv = s_surv[sidx];
-            const long long i = global_of(sv & 0xFFFFu);
+            const long long i = global_of(sv & 0x3FFu);
             const int spIndex = (int)(sv >> 16);
             // seed, hot record (just streamed by this workgroup: cache hit) and cold record in ONE round trip; the cold
             // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
             // fourth dependent round trip on this latency-bound chain
             const msl_seed S = seeds[spIndex];
-            const HotRec hr = M.hot[i];
+            const uint8_t fz = fused[spIndex];       // possibly stale (another XCD may have set it): only saves a redundant store
+            HotRec hr = M.hot[i];
             ColdRec C = M.cold[i];
             // common use of one field per load instruction (see phase A): all three records are in flight together
             asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
+            if (sv & 0x8000u) {   // redirected record, materialised by another thread of this workgroup a moment ago: read it past the L1
+                const unsigned *hp = reinterpret_cast<const unsigned *>(M.hot + i), *cp = reinterpret_cast<const unsigned *>(M.cold + i);
+                hr.px = __uint_as_float(ld_agent(hp)); hr.py = __uint_as_float(ld_agent(hp + 1)); hr.pz = __uint_as_float(ld_agent(hp + 2));
+                hr.updateTimes = (int)ld_agent(hp + 3); hr.lastUpdate = (int)ld_agent(hp + 4);
+                C.nx = __uint_as_float(ld_agent(cp)); C.ny = __uint_as_float(ld_agent(cp + 1)); C.nz = __uint_as_float(ld_agent(cp + 2));
+                C.size = __uint_as_float(ld_agent(cp + 3)); C.color = __uint_as_float(ld_agent(cp + 4));
+                C.r = (int)ld_agent(cp + 5); C.g = (int)ld_agent(cp + 6); C.b = (int)ld_agent(cp + 7); C.weight = __uint_as_float(ld_agent(cp + 8));
+            }
             const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
@@ -1135,7 +1354,11 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
             float nc[3];
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
+            if (normDiffCos < MAX_ANGLE_COS) {
+                M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u);
+                atomicOr(&s_delBits[(sv >> 8) & 3u][(sv & 0xFFu) >> 5], 1u << (sv & 31u));
+                ndelB++; continue;
+            }
             const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
@@ -1163,298 +1386,54 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F)
             if (newSize < C.size) C.size = newSize;
             M.hot[i] = Hn;
             M.cold[i] = C;
-            fused[spIndex] = 1;
+            if (!fz) st_agent_u8(&fused[spIndex], 1);   // write-through: the continuation reads the flags in this launch
             nupd++;
         }
         if (nupd) atomicAdd(&s_cnt[1], nupd);
         if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
         const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
-        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
+        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) st_agent(&P.blockSums[(long long)threadIdx.x * nW + b], s_delSub[threadIdx.x]);
         if (threadIdx.x == 0) {
-            P.blockUpd[b] = s_cnt[1];
+            st_agent(&P.blockUpd[b], s_cnt[1]);
             if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per workgroup that deleted something
         }
         __syncthreads();
         if (ndelBlk) {
             const unsigned base = s_delBase;
             for (unsigned j = threadIdx.x; j < ndelA; j += FUSE_NT)
-                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[LISTN - 1 - j]);
+                if (base + j < LIST_D) st_agent(&P.delU[base + j], (unsigned)global_of(s_surv[LISTN - 1 - j] & 0x3FFu));
             if (ndelBlk != ndelA)
                 for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
                     const unsigned sv = s_surv[sidx];
                     if ((sv >> 16) != 0xFFFFu) continue;
                     const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
-                    if (j < LIST_D) P.delU[j] = (unsigned)global_of(sv & 0xFFFFu);
+                    if (j < LIST_D) st_agent(&P.delU[j], (unsigned)global_of(sv & 0x3FFu));
                 }
+            // the wave's deleted slots in ascending order: lanes 0..7 expand one bitmap word each
+            const unsigned lane = threadIdx.x & 63u;
+            if (hasSub && s_delSub[wv]) {
+                const unsigned word = lane < 8 ? s_delBits[wv][lane] : 0u;
+                const unsigned pc = __popc(word);
+                unsigned o = wave_incl_scan(pc) - pc;
+                for (unsigned m = word; m; m &= m - 1) st_agent(&P.delStage[c0 + o++], (unsigned)(c0 + 32 * lane + __builtin_ctz(m)));
+            }
         }
         __syncthreads();
     }
+    // ---- the last workgroup to finish continues with the compaction ----
+    if (!last_workgroup(&P.tickets[0], &s_last)) return;
+    compact_tail<FUSE_NT>(P, slot, mode, s_surv, s_dl, s_wave, s_misc);
 }
 
-__device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
-    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
-    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
-    M.hot[i] = h; M.cold[i] = c;
+// Materialise pending lazy tail moves (host-visible accessors call this before they touch the map).
+__global__ __launch_bounds__(256) void k_flush_moves(SfDev P) {
+    const long long pend = P.ctr[CT_PEND];
+    for (long long a = (long long)blockIdx.x * 256 + threadIdx.x; a < pend; a += (long long)gridDim.x * 256)
+        move_surfel(P.map, (long long)P.delList[a], (long long)P.srcOf[a]);
 }
-__device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
-    M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
-}
-
-// Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
-// new surfel k -> d_{D-1-k} while any remain, else appended.  If D > K the literal `while` loop (:386-390) moves,
-// at step i = 1..R (R = D-K), the element at position n-i into the i-th largest leftover hole; a hole inside the
-// tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole (< nFinal) finally receives
-// resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): a short upward chain.
-constexpr int TAIL_MAX_HOPS = 64;
-
-// k_compact: everything after k_fuse in ONE launch.
-//   every workgroup : exclusive scan of the per-chunk deleted counts (each workgroup scans the <= cap/1024 partials itself,
-//                     so there is no inter-workgroup dependency), then lists the deleted slots of its own chunks in
-//                     ascending order (write-through stores);
-//   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
-//                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
-// mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
-constexpr int SMALL_D = 512, SMALL_CHUNKS = 48;   // single-workgroup path: few deletions in few chunks
-
-// LDS is kept to ~3.5 KB: on a GPU saturated by the LDS-heavy batched kernels a larger workgroup waits for a CU to drain.
-__global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
-    constexpr int NT = 256, TILE = 4 * NT;
-    __shared__ unsigned s_wave[33];
-    __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
-    __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
-    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk;
-    __shared__ unsigned s_nzIdx[SMALL_CHUNKS], s_nzCnt[SMALL_CHUNKS], s_nzSortIdx[SMALL_CHUNKS], s_nzSortCnt[SMALL_CHUNKS];   // sub-blocks with deletions
-    __shared__ int s_fallback;
-    __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
-    // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
-    // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
-    const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
-    uint4 bu[4];   // the first 4096 per-workgroup updated counts (arrays are padded by >= 4096 zeroed entries)
-#pragma unroll
-    for (int q = 0; q < 4; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
-    static_assert(LIST_D == NT, "one hand-over entry per thread");
-    const unsigned du = P.delU[threadIdx.x];
-    const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
-    const long long n = P.ctr[0];
-    const bool bad = P.ctr[5] == 20;
-    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
-    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
-    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
-    unsigned cnt = 0;
-    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
-    if (per <= 32 && (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0) {
-        // common geometry: all flag words of the thread in ONE round trip
-        unsigned cw[8], fw[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int i = s0 + 4 * q;
-            const bool in = 4 * q < per && i < s1;
-            cw[q] = in ? *reinterpret_cast<const unsigned *>(candOk + i) : 0u;
-            fw[q] = in ? *reinterpret_cast<const unsigned *>(fused + i) : 0u;
-        }
-        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]), "v"(cw[7]),
-                     "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3]), "v"(fw[4]), "v"(fw[5]), "v"(fw[6]), "v"(fw[7]));
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned e = (s0 + 4 * q + j < s1 && ((cw[q] >> (8 * j)) & 0xFF) && !((fw[q] >> (8 * j)) & 0xFF)) ? 1u : 0u;
-                cnt += e;
-                emit |= (unsigned long long)e << (4 * q + j);
-            }
-    } else {
-        for (int i = s0; i < s1; i += 4) {
-            unsigned c4, f4;
-            if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
-                c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
-            } else {
-                c4 = f4 = 0;
-                for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
-                cnt += e;
-                if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
-            }
-        }
-    }
-    // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
-    // that this round trip overlaps the scans below instead of following them.
-    msl_surfel e0, e1;
-    memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
-    if (pf && emit) {
-        e0 = cand[s0 + __builtin_ctzll(emit)];
-        const unsigned long long m1 = emit & (emit - 1);
-        if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
-    }
-    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
-    const long long nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;   // k_fuse workgroups (blockUpd entries)
-    s_raw[threadIdx.x] = du;
-    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
-    __syncthreads();
-    // k_fuse already counted the deleted slots; when they all fit its hand-over list (the steady state) the per-sub-block
-    // counts are not needed at all.  Otherwise one pass over them (4 consecutive per thread and tile) lists the sub-blocks
-    // that contain deletions.
-    const bool fastest = mode == 0 && dHand <= LIST_D;
-    unsigned vsum = 0;
-    if (!fastest)
-        for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-            const long long c = t0 + 4 * threadIdx.x;
-            const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
-            const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (x[j] > 0) {
-                    vsum += x[j];
-                    const unsigned q = atomicAdd(&s_nzChunks, 1u);
-                    if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
-                }
-        }
-    unsigned Dtot, Ku, exUnused, pos;
-    block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
-    const long long D = fastest ? (long long)dHand : (long long)Dtot;
-    // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
-    const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
-    const bool single = fastest || small;
-    if (single && blockIdx.x != 0) return;
-    if (mode == 0 && !bad) {
-        if (fastest) {
-            if (threadIdx.x < D) {   // rank-sort in LDS
-                unsigned r = 0;
-                for (unsigned j = 0; j < (unsigned)D; j++) r += s_raw[j] < du ? 1u : 0u;
-                s_dl[r] = du;
-            }
-        } else if (small) {
-            // few sub-blocks hold all deletions: order them by index (rank sort); a sub-block's offset in the ascending
-            // list is the sum of the counts before it -- no scan over the (thousands of) empty sub-blocks
-            const unsigned nz = s_nzChunks;
-            if (threadIdx.x < nz) {
-                const unsigned me = s_nzIdx[threadIdx.x];
-                unsigned r = 0;
-                for (unsigned j = 0; j < nz; j++) r += s_nzIdx[j] < me ? 1u : 0u;
-                s_nzSortIdx[r] = me; s_nzSortCnt[r] = s_nzCnt[threadIdx.x];
-            }
-            __syncthreads();
-            unsigned base = 0;
-            for (unsigned it = 0; it < nz; it++) {
-                const long long i0 = (long long)s_nzSortIdx[it] * SUB_ITEMS + threadIdx.x;   // one slot per thread: ascending
-                const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
-                unsigned tt;
-                const unsigned w = base + block_excl_scan(f, s_wave, &tt);
-                if (f) s_dl[w] = (unsigned)i0;
-                base += s_nzSortCnt[it];
-            }
-        } else {
-            // every workgroup lists the deleted slots of its own sub-blocks in ascending order; a sub-block's base offset
-            // lives in the registers of the thread that scanned it and is broadcast through one LDS word
-            unsigned carry = 0;
-            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-                const long long c = t0 + 4 * threadIdx.x;
-                const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
-                const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
-                unsigned tot;
-                const unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
-                const long long nIter = (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
-                for (long long it = 0; it < nIter; it++) {
-                    const long long b = t0 + blockIdx.x + it * gridDim.x;
-                    const int q = (int)(b - t0);
-                    if ((int)threadIdx.x == (q >> 2)) {
-                        const int comp = q & 3;
-                        s_base = ex + (comp > 0 ? v[0] : 0u) + (comp > 1 ? v[1] : 0u) + (comp > 2 ? v[2] : 0u);
-                        s_cntChunk = v[comp];
-                    }
-                    __syncthreads();
-                    const unsigned base = s_base, cntChunk = s_cntChunk;
-                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this sub-block
-                    const long long i0 = b * SUB_ITEMS + threadIdx.x;       // one slot per thread keeps the list ascending
-                    const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
-                    unsigned tt;
-                    const unsigned w = base + block_excl_scan(f, s_wave, &tt);   // (its barriers also protect s_base)
-                    if (f) st_agent(&P.delList[w], (unsigned)i0);
-                }
-                carry += tot;
-                __syncthreads();
-            }
-        }
-    }
-    __syncthreads();
-    if (mode == 0 && !single && !last_workgroup(&P.tickets[1], &s_last)) return;
-    // ================= continuation: one workgroup =================
-    // updated count
-    {
-        unsigned u = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const long long c = TILE * q + 4 * threadIdx.x;
-            u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
-        }
-        for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
-        if (u) atomicAdd(&s_upd, u);
-    }
-    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
-    const long long K = Ku;
-    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
-    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
-    auto DL = [&](long long j) -> unsigned { return single ? s_dl[j] : ld_agent(&P.delList[j]); };
-    if (cnt) {
-        auto emit_one = [&](const msl_surfel &e) {
-            const long long k = pos++;
-            P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
-            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
-                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
-        };
-        unsigned long long m = emit;
-        for (int j = 0; m; j++, m &= m - 1) {
-            const int i = s0 + __builtin_ctzll(m);
-            if (pf && j == 0) emit_one(e0);
-            else if (pf && j == 1) emit_one(e1);
-            else emit_one(cand[i]);
-        }
-        for (int i = s0 + 64; i < s1; i++)
-            if (candOk[i] && !fused[i]) emit_one(cand[i]);
-    }
-    __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
-    if (threadIdx.x == 0) {
-        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
-        if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
-    }
-    if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }
-    const long long t0 = threadIdx.x, stride = blockDim.x;
-    if (D > K) {
-        const long long R = D - K, nFinal = n - R;
-        auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
-            long long lo = 0, hi = R;
-            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
-            return lo;
-        };
-        const long long cntLow = lower(nFinal);
-        for (long long a = t0; a < cntLow; a += stride) {
-            long long p = nFinal + a;
-            int hop = 0;
-            for (; hop < TAIL_MAX_HOPS; hop++) {
-                const long long lb = lower(p);
-                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb);   // relay hole: follow to where its content came from
-                else break;
-            }
-            if (hop == TAIL_MAX_HOPS) s_fallback = 1;   // pathological chain: fall back to the literal loop
-            P.srcOf[a] = (unsigned)p;
-        }
-        __syncthreads();   // also orders the new-surfel stores above before the moves below (same workgroup)
-        if (s_fallback) {
-            if (threadIdx.x == 0)   // literal back-to-front loop (SurfelMapping.cpp:386-390), pathological delete patterns only
-                for (long long i = 1; i <= R; i++) {
-                    const long long hole = DL(R - i), src = n - i;
-                    if (src != hole) move_surfel(P.map, hole, src);
-                }
-        } else {
-            for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
-        }
-    }
-    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
+__global__ void k_clear_pend(long long *ctr) {
+    if (threadIdx.x == 0) ctr[CT_PEND] = 0;
 }
 
 // ---- map maintenance: ordered selection of surfels by a predicate -------------------------------
@@ -1544,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     dst[i] = e;
 }
 __global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
-    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
+    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; ctr[8] = 0; }
 }
 
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
@@ -1555,7 +1534,7 @@ __global__ void k_debug_div100(const float *x, double *out, long long n) {
 enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_COMMIT_SEEDS, SK_SEED_PLANE, SK_FUSE, SK_NEW, SK_COMPACT,
        SK_CONVERT, SK_COPY };
 const char *kSfNames[MSL_SF_NKERNELS] = {"kb_seed_init", "kb_assign", "kb_prop", "kb_commit_px", "kb_update_seeds", "kb_commit_seeds",
-                                         "kb_seed_plane", "k_fuse", "(unused)", "k_compact", "k_convert", "copy"};
+                                         "kb_seed_plane", "k_fuse", "(unused)", "k_flush_moves", "k_convert", "copy"};
 
 }  // namespace
 
@@ -1584,7 +1563,7 @@ struct msl_sf {
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     size_t liveBound = 0;        // host-side upper bound of the live count: last synced count + nseeds per keyframe enqueued since
-    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
+    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr, *d_delStage = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
 };
@@ -1598,6 +1577,7 @@ void set_map_ptrs(msl_sf *h) {
     M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
+    h->dev.delStage = h->d_delStage;
 }
 
 int sync_all(msl_sf *h) {
@@ -1609,7 +1589,7 @@ int sync_all(msl_sf *h) {
 // (Re)allocate the resident map for `cap` surfels, preserving the first `keep` entries.
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
-    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
+    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nst = nullptr;
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
@@ -1618,6 +1598,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
+        MSL_HIP_TRY(hipMalloc(&nst, sizeof(unsigned) * cap));
         if (keep && h->d_mapStore) {
             int rc = sync_all(h);
             if (rc != MSL_OK) return rc;
@@ -1633,12 +1614,14 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         if (nbu) (void)hipFree(nbu);
         if (ndl) (void)hipFree(ndl);
         if (nso) (void)hipFree(nso);
+        if (nst) (void)hipFree(nst);
         return arc;
     }
     if (h->d_mapStore) {
         (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
+        (void)hipFree(h->d_delStage);
     }
-    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->mapCap = cap;
+    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_delStage = nst; h->mapCap = cap;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -1688,6 +1671,9 @@ int alloc_slots(msl_sf *h, int maxBatch) {
 
 int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
+    // every host-visible accessor comes through here: materialise the lazy tail moves the last keyframe may have left pending
+    hipLaunchKernelGGL(k_flush_moves, dim3(128), dim3(256), 0, h->mapStream, h->dev);
+    hipLaunchKernelGGL(k_clear_pend, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr);
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 8, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
@@ -1826,10 +1812,12 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
-    for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(2048 * 4 / FUSE_WAVES), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f]);
-        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
-    }
+    // one launch per keyframe: fuse + new surfels + refill + (lazy) tail compaction.  The grid covers the host-side upper bound
+    // of the live count (the kernel loops if the map is larger, idle workgroups only take a ticket).
+    const size_t boundLive = compact ? h->liveBound : h->mapCap;
+    const unsigned fuseGrid = (unsigned)std::min<size_t>(65536, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
+    for (int f = 0; f < n; f++)
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f], compact ? 0 : 1);
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     MSL_HIP_TRY(hipGetLastError());
     h->lastSlot = slot0 + n - 1;
@@ -1863,8 +1851,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreateWithFlags(&h->evPre[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->evMap[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->evCopy[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 8) == hipSuccess;
-    ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 8) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
+    ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 8) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
@@ -1896,7 +1884,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_delStage); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
