@@ -296,6 +296,10 @@ MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
  * as left by the last fuse call. */
 MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
+/* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
+ * 5: deferred error code, 8: pending lazy tail moves -- always 0 here, the sync flushes them; 9-15: kernel time stamps in
+ * instrumented builds). */
+MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);

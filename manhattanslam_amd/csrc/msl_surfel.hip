@@ -54,6 +54,12 @@ constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the
 #endif
 constexpr int FUSE_WAVES = MSL_FUSE_WAVES;
 constexpr int FUSE_NT = 64 * FUSE_WAVES;
+// The seeds' fused bitmap is written by ~2000 workgroups (agent-scope ORs, ~30 words each) and read by one (the continuation).
+// Memory-side atomics on one 64-byte line serialise (~10-25 ns each: tools/micro/lat.hip), a single CU fetches about one line per
+// clock (tools/micro/coh.hip: 4096 scattered lines = 2 us).  16 replicas (a workgroup ORs into replica blockIdx % 16) x 4 words
+// per line = 600 lines: ~100 atomics per line for the writers, ~600 line fetches for the reader.
+constexpr int FBIT_STRIDE = 4;          // dwords between two words of the bitmap
+constexpr int FBIT_REPL = 16;           // replicas
 constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted-slot partials
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
@@ -88,7 +94,9 @@ struct SfDev {
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
     uint8_t *candOk;             // [slots][nseeds]
-    uint8_t *fused;              // [slots][nseeds] seed consumed by a fusion (written write-through, read at agent scope)
+    unsigned *fused;             // [slots][FBIT_REPL][fusedWords * FBIT_STRIDE] bit s of word s / 32 (OR over the replicas): seed s was consumed by
+                                 // a fusion
+    int fusedWords;              // ceil(nseeds / 32)
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
@@ -104,6 +112,8 @@ struct SfDev {
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
+    unsigned long long *blockDone;   // [cap / 512 + ..] per k_fuse work item: launch stamp << 44 | updated << 34 | wave 1 deleted << 17 | wave 0 deleted
+                                 //   (deleted = count | offset of the first deleted slot << 9), one 64-bit write-through store
     unsigned *delStage;          // [cap] per sub-block (256 slots) the slots k_fuse found deleted, ascending, from the sub-block's first entry
     unsigned *tickets;           // [0] k_fuse's "last workgroup continues" ticket, [2] delUCount
     unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of the continuation)
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     imageY = imageY < (P.H - 1) ? imageY : (P.H - 1);
     msl_seed s;
     memset(&s, 0, sizeof(s));
-    P.fused[(size_t)slot * P.nseeds + seedI] = 0;
+    for (int wd = seedI; wd < P.fusedWords * FBIT_REPL; wd += P.nseeds) P.fused[((size_t)slot * P.fusedWords * FBIT_REPL + wd) * FBIT_STRIDE] = 0;
     if (F.memberG()[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
         P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.invDepth[(size_t)slot * P.nseeds + seedI] = 0.0;
         return;
@@ -1057,110 +1067,161 @@ __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long
 // counters only; the caller compacts (SurfelMapping.cpp:366-391).
 //   D deleted slots d_0 < .. < d_{D-1}; new surfel k -> d_{D-1-k} while any remain, else appended (:372-384).  If D > K the
 //   literal `while` loop (:386-390) moves, at step i = 1..R (R = D - K), the element at position n - i into the i-th largest
-//   leftover hole; a hole inside the tail [nFinal, n) only relays what lands in it.  Net effect: the a-th smallest leftover
-//   hole below nFinal = n - R receives the a-th smallest LIVE element of the tail, i.e. position nFinal + a + j with j the
-//   number of tail holes below it (binary search over the hole list; checked against the literal loop by
-//   tests/test_surfel_gpu.py::test_compaction_matches_literal_loop).
+//   leftover hole; a hole inside the tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole
+//   (< nFinal = n - R) finally receives resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): an
+//   upward chain over the hole list (checked against the literal loop by test_compaction_matches_literal_loop).
+// Hand-over from the streaming workgroups (all write-through, read here at agent scope): blockSums[sub] = deleted count of the
+// sub-block | offset of its first deleted slot << 16; delStage[sub * 256 + r] = its r-th deleted slot (ascending); blockUpd[wg];
+// the seeds' fused flags.  Steady state (a handful of deletions, one per sub-block) needs ONE dependent round trip for all of it.
+#ifdef MSL_TAIL_STAMPS
+#define TSTAMP(k) do { if (threadIdx.x == 0) P.ctr[9 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TSTAMP(k) do { } while (0)
+#endif
 template <int NT>
-__device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned *s_raw /*>= LIST_D*/, unsigned *s_dl /*>= LIST_D*/, unsigned *s_wave /*>= 17*/,
-                             unsigned *s_misc /*>= 4*/) {
-    static_assert(LIST_D % NT == 0 || NT % LIST_D == 0, "strided loops below");
+__device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned seq, unsigned *s_dl /*>= LIST_D*/, unsigned *s_wave /*>= 33*/, unsigned *s_misc /*>= 4*/) {
     const int tid = threadIdx.x;
     const long long n = P.ctr[0];
     const bool bad = P.ctr[5] == 20;
-    const unsigned dHand = ld_agent(P.delUCount);
     const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS, nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;
-    if (tid == 0) { s_misc[0] = 0; }
-    // hand-over list of the fastest path: issue the loads before anything else
-    const bool fastest = mode == 0 && dHand <= LIST_D;
-    unsigned du[LIST_D / NT > 0 ? LIST_D / NT : 1];
-#pragma unroll
-    for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) {
-        const int j = tid + r * NT;
-        du[r] = (fastest && j < (int)dHand && j < LIST_D) ? ld_agent(&P.delU[j]) : 0xFFFFFFFFu;
-    }
-    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
+    static_assert(FUSE_WAVES == 2, "stamp layout: two sub-blocks per work item");
+    TSTAMP(1);
+    // ---- initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order.
+    // What does not depend on this launch (candOk, written by kb_seed_plane) is fetched before the wait below ----
     const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds;
-    const uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
+    const int per = (((P.nseeds + NT - 1) / NT) + 31) & ~31;      // seeds per thread, multiple of 32: whole bitmap words
     const int s0 = tid * per, s1 = min(s0 + per, P.nseeds);
-    const bool wordsOk = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
-    auto spawns = [&](int i, unsigned cword, unsigned fword, int j) -> bool { return i + j < s1 && ((cword >> (8 * j)) & 0xFF) && !((fword >> (8 * j)) & 0xFF); };
-    auto flags_at = [&](int i, unsigned &c4, unsigned &f4) {   // four seeds' flags; `fused` was written in this launch: agent-scope loads
-        if (wordsOk && i + 4 <= P.nseeds) {
-            c4 = *reinterpret_cast<const unsigned *>(candOk + i);
-            f4 = ld_agent(reinterpret_cast<const unsigned *>(fused + i));
-        } else {
-            c4 = f4 = 0;
-            for (int j = 0; j < 4 && i + j < P.nseeds; j++) {
-                c4 |= (unsigned)candOk[i + j] << (8 * j);
-                f4 |= (unsigned)__hip_atomic_load(fused + i + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << (8 * j);
+    unsigned long long cmask = 0;   // bit j: candOk of seed s0 + j
+    {   // candOk bytes (0 / 1) of the first 64 seeds as sixteen words (plain loads: written by an earlier kernel), packed to one bit each
+        const bool aligned = (reinterpret_cast<size_t>(candOk) & 3) == 0;
+        unsigned cw[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int i = s0 + 4 * q;
+            unsigned w4 = 0;
+            if (i + 4 <= s1 && aligned) w4 = *reinterpret_cast<const unsigned *>(candOk + i);
+            else
+                for (int j = 0; j < 4; j++)
+                    if (i + j < s1) w4 |= (unsigned)(candOk[i + j] != 0) << (8 * j);
+            cw[q] = w4;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const unsigned w4 = cw[q];
+            const unsigned nib = ((w4 & 0xFFu) ? 1u : 0u) | ((w4 & 0xFF00u) ? 2u : 0u) | ((w4 & 0xFF0000u) ? 4u : 0u) | ((w4 & 0xFF000000u) ? 8u : 0u);
+            cmask |= (unsigned long long)nib << (4 * q);
+        }
+    }
+    // ---- wait until every work item carries this launch's stamp; the stamps also bring the deleted / updated counts.  Thread t
+    // owns the contiguous work items [w0, w1): sub-block (wave w, item b) = w * nWg + b, so hole order = wave 0 items, then wave 1 ----
+    const long long perW = (nWg + NT - 1) / NT, w0 = min((long long)tid * perW, nWg), w1 = min(w0 + perW, nWg);
+    unsigned dsum0 = 0, dsum1 = 0, upd = 0, nne0 = 0, nne1 = 0;
+    unsigned neIdx[2][3], neW[2][3];      // per wave the thread's first non-empty sub-blocks (more: the second pass reloads)
+    for (int spin = 0;; spin++) {
+        int ok = 1;
+        dsum0 = dsum1 = upd = nne0 = nne1 = 0;
+        for (long long c = w0; c < w1; c += 16) {
+            unsigned long long st[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++)   // sixteen independent agent-scope loads in flight (all of a 1 M map's stamps in one round trip)
+                st[e] = c + e < w1 ? __hip_atomic_load(&P.blockDone[c + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)seq << 44);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                ok &= (unsigned)(st[e] >> 44) == seq ? 1 : 0;
+                upd += (unsigned)(st[e] >> 34) & 0x3FFu;
+                const unsigned a0 = (unsigned)st[e] & 0x1FFFFu, a1 = (unsigned)(st[e] >> 17) & 0x1FFFFu;
+                if (a0 & 0x1FFu) {
+                    dsum0 += a0 & 0x1FFu;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) if (nne0 == (unsigned)q) { neIdx[0][q] = (unsigned)(c + e); neW[0][q] = a0; }
+                    nne0++;
+                }
+                if (a1 & 0x1FFu) {
+                    dsum1 += a1 & 0x1FFu;
+#pragma unroll
+                    for (int q = 0; q < 3; q++) if (nne1 == (unsigned)q) { neIdx[1][q] = (unsigned)(nWg + c + e); neW[1][q] = a1; }
+                    nne1++;
+                }
             }
         }
+        if (__syncthreads_and(ok)) break;
+        if (spin >= (1 << 22)) { if (tid == 0) P.ctr[5] = 21; return; }   // bounded wait exceeded: reported at the next sync
+        __builtin_amdgcn_s_sleep(1);
+    }
+    TSTAMP(2);
+    if (tid == 0) s_misc[0] = 0;
+    const unsigned *fusedBits = P.fused + (size_t)slot * P.fusedWords * FBIT_REPL * FBIT_STRIDE;
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    // the thread's first two bitmap words (64 seeds) travel in one round trip; `fused` was written in this launch: agent-scope loads
+    auto fused_word = [&](int wd) -> unsigned {   // OR over the replicas: FBIT_REPL independent loads in flight
+        unsigned v[FBIT_REPL], r = 0;
+#pragma unroll
+        for (int e = 0; e < FBIT_REPL; e++) v[e] = ld_agent(&fusedBits[((size_t)e * P.fusedWords + wd) * FBIT_STRIDE]);
+#pragma unroll
+        for (int e = 0; e < FBIT_REPL; e++) r |= v[e];
+        return r;
     };
+    unsigned fb0 = 0, fb1 = 0;
+    {
+        unsigned v0[FBIT_REPL], v1[FBIT_REPL];
+        const bool h0 = s0 < s1, h1 = s0 + 32 < s1;
+#pragma unroll
+        for (int e = 0; e < FBIT_REPL; e++) {
+            v0[e] = h0 ? ld_agent(&fusedBits[((size_t)e * P.fusedWords + (s0 >> 5)) * FBIT_STRIDE]) : 0u;
+            v1[e] = h1 ? ld_agent(&fusedBits[((size_t)e * P.fusedWords + (s0 >> 5) + 1) * FBIT_STRIDE]) : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < FBIT_REPL; e++) { fb0 |= v0[e]; fb1 |= v1[e]; }
+    }
+    const unsigned long long fmask = (unsigned long long)fb0 | ((unsigned long long)fb1 << 32);   // fused flags of seeds s0 .. s0 + 63
+    auto is_fused_slow = [&](int i) -> bool { return (fused_word(i >> 5) >> (i & 31)) & 1u; };    // seeds beyond the first 64 (large images)
     unsigned cnt = 0;
     unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
-    for (int i = s0; i < s1; i += 4) {
-        unsigned c4, f4;
-        flags_at(i, c4, f4);
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (spawns(i, c4, f4, j)) { cnt++; if (i + j - s0 < 64) emit |= 1ull << (i + j - s0); }
-    }
-    // updated count of this keyframe
     {
-        unsigned u = 0;
-        for (long long c = tid; c < nWg; c += NT) u += ld_agent(&P.blockUpd[c]);
-        if (u) atomicAdd(&s_misc[0], u);
+        emit = cmask & ~fmask;
+        cnt = (unsigned)__popcll(emit);
+        for (int i = s0 + 64; i < s1; i++)
+            if (candOk[i] && !is_fused_slow(i)) cnt++;
     }
-    unsigned Ku, pos;
+    if (upd) atomicAdd(&s_misc[0], upd);
+    const unsigned dsum = dsum0 + dsum1;
+    TSTAMP(3);
+    unsigned D0, D1, ex0, ex1, Ku, pos;
+    block_excl_scan_pair(dsum0, dsum1, s_wave, &D0, &D1, ex0, ex1);
     pos = block_excl_scan(cnt, s_wave, &Ku);
-    // ---- ascending list of the deleted slots ----
-    long long D = 0;
-    if (mode == 0 && !bad) {
-        if (fastest) {
-            D = dHand;
+    // ---- ascending list of the deleted slots: LDS when it is short, delList[] otherwise ----
+    const long long D = (long long)D0 + D1, K = Ku;
+    const bool useLds = D <= LIST_D;
+    const bool build = mode == 0 && !bad;
+    auto put = [&](unsigned j, unsigned slotIdx) { if (useLds) s_dl[j] = slotIdx; else st_agent(&P.delList[j], slotIdx); };
+    auto put_sub = [&](unsigned &off, unsigned sub, unsigned word) {   // word = count | offset of the first deleted slot << 9
+        const unsigned c = word & 0x1FFu, base = sub * (unsigned)SUB_ITEMS;
+        put(off, base + (word >> 9));
+        for (unsigned r = 1; r < c; r++) put(off + r, ld_agent(&P.delStage[base + r]));
+        off += c;
+    };
+    if (build && dsum) {
 #pragma unroll
-            for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) { const int j = tid + r * NT; if (j < LIST_D) s_raw[j] = du[r]; }
-            __syncthreads();
+        for (int w = 0; w < 2; w++) {
+            unsigned off = w == 0 ? ex0 : D0 + ex1;
+            const unsigned nne = w == 0 ? nne0 : nne1;
+            if (nne <= 3) {
 #pragma unroll
-            for (int r = 0; r < (LIST_D / NT > 0 ? LIST_D / NT : 1); r++) {   // rank sort in LDS
-                const int j = tid + r * NT;
-                if (j < (int)D) {
-                    unsigned rk = 0;
-                    for (unsigned x = 0; x < (unsigned)D; x++) rk += s_raw[x] < du[r] ? 1u : 0u;
-                    s_dl[rk] = du[r];
+                for (int q = 0; q < 3; q++)
+                    if ((unsigned)q < nne) put_sub(off, neIdx[w][q], neW[w][q]);
+            } else {
+                for (long long c = w0; c < w1; c++) {
+                    const unsigned long long st = __hip_atomic_load(&P.blockDone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned word = (unsigned)(st >> (17 * w)) & 0x1FFFFu;
+                    if (word & 0x1FFu) put_sub(off, (unsigned)(w * nWg + c), word);
                 }
             }
-        } else {
-            // every k_fuse wave staged its sub-block's deleted slots in ascending order at delStage[sub * 256 ..]; an exclusive
-            // scan of the per-sub-block counts gives each staged run its place in the global ascending list
-            unsigned carry = 0;
-            constexpr int TILE = 4 * NT;
-            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
-                const long long c = t0 + 4 * tid;
-                unsigned v[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v[j] = c + j < nblk ? ld_agent(&P.blockSums[c + j]) : 0u;
-                unsigned tot;
-                unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    for (unsigned r = 0; r < v[j]; r++) st_agent(&P.delList[ex + r], ld_agent(&P.delStage[(c + j) * SUB_ITEMS + r]));
-                    ex += v[j];
-                }
-                carry += tot;
-            }
-            D = carry;
         }
     }
-    if (mode != 0 || bad) D = dHand;   // counters only: k_fuse's running total of deleted slots
     __syncthreads();
-    const long long K = Ku;
     const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
-    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
-    auto DL = [&](long long j) -> unsigned { return fastest ? s_dl[j] : ld_agent(&P.delList[j]); };
+    const bool place = build && (unsigned long long)nAfter <= P.cap;
+    auto DL = [&](long long j) -> unsigned { return useLds ? s_dl[j] : ld_agent(&P.delList[j]); };
     if (cnt) {
         auto emit_one = [&](const msl_surfel &e) {
             const long long k = pos++;
@@ -1169,26 +1230,28 @@ __device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned *s_raw
                 store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
         };
         for (unsigned long long m = emit; m; m &= m - 1) emit_one(cand[s0 + __builtin_ctzll(m)]);
-        for (int i = s0 + 64; i < s1; i += 4) {
-            unsigned c4, f4;
-            flags_at(i, c4, f4);
-            for (int j = 0; j < 4; j++)
-                if (spawns(i, c4, f4, j)) emit_one(cand[i + j]);
-        }
+        for (int i = s0 + 64; i < s1; i++)
+            if (candOk[i] && !is_fused_slow(i)) emit_one(cand[i]);
     }
+    TSTAMP(4);
     long long nPublish = nAfter, pendOut = 0;
     if (place && D > K) {
         // lazy tail moves: leftover holes d_0 .. d_{R-1}; those below nFinal are the destinations
         const long long R = D - K, nFinal = n - R;
-        long long lo = 0, hi = R;   // cntLow = first index in the hole list with value >= nFinal
-        while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < nFinal) lo = mid + 1; else hi = mid; }
-        const long long cntLow = lo, nTailHoles = R - cntLow;
+        auto lower = [&](long long x) -> long long {   // first index in the leftover holes with value >= x
+            long long lo = 0, hi = R;
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const long long cntLow = lower(nFinal);
         for (long long a = tid; a < cntLow; a += NT) {
-            // a-th smallest live element of the tail: nFinal + a + j, j = number of tail holes below it
-            long long jl = 0, jh = nTailHoles;
-            while (jl < jh) { const long long mid = (jl + jh) >> 1; if ((long long)DL(cntLow + mid) - nFinal - mid > a) jh = mid; else jl = mid + 1; }
-            P.srcOf[a] = (unsigned)(nFinal + a + jl);
-            if (fastest) P.delList[a] = s_dl[a];   // the general path already holds the list in delList[]
+            long long p = nFinal + a;
+            for (long long hop = 0; hop <= R; hop++) {   // a relay hole forwards to where its content came from: strictly upward, ends at a live element
+                const long long lb = lower(p);
+                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb); else break;
+            }
+            P.srcOf[a] = (unsigned)p;
+            if (useLds) P.delList[a] = s_dl[a];   // the long-list path already holds the destinations in delList[]
         }
         nPublish = nFinal; pendOut = cntLow;
     }
@@ -1197,32 +1260,33 @@ __device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned *s_raw
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_misc[0]; P.ctr[4] = n; P.ctr[6] = nAfter;
         if ((unsigned long long)nAfter > P.cap && mode == 0) P.ctr[5] = 20;  // capacity exceeded
         if (place) { P.ctr[0] = nPublish; P.ctr[CT_PEND] = pendOut; }        // publish the new live count and the pending moves
-        st_agent(P.delUCount, 0u);                                           // re-arm the hand-over list
     }
+    TSTAMP(5);
 }
 
-__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F, int mode) {   // F by value: kernarg -> SGPRs
-    // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
-    // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
-    // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
+__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F, int mode, unsigned seq) {   // F by value: kernarg -> SGPRs
+    // One small survivor list per workgroup (4 entries per thread: local index | superpixel << 16) keeps the kernel co-resident
+    // with the LDS-heavy batched kernels; deleted slots are recorded in a 256-bit map per wave.
     // Each wave owns one sub-block of 256 consecutive surfels, and the FUSE_WAVES waves of a workgroup take theirs from
     // different parts of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
     // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
     __shared__ unsigned s_cnt[5], s_delSub[4];
     constexpr int LISTN = 4 * FUSE_NT;
-    static_assert(LISTN >= LIST_D, "the continuation reuses the survivor list as its hand-over buffer");
     __shared__ unsigned s_surv[LISTN];
     __shared__ unsigned s_delBits[FUSE_WAVES][8];   // deleted slots of each wave's sub-block, one bit per surfel
-    __shared__ unsigned s_delBase, s_last;
-    __shared__ unsigned s_dl[LIST_D], s_wave[17], s_misc[4];
+    __shared__ unsigned s_dl[LIST_D], s_wave[33], s_misc[4], s_subWord[FUSE_WAVES];
+    extern __shared__ unsigned s_fbits[];           // [fusedWords] seeds this workgroup fused surfels into
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
     const long long pend = P.ctr[CT_PEND];
+#ifdef MSL_TAIL_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr[9] = (long long)__builtin_readcyclecounter();
+#endif
     const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + FUSE_WAVES - 1) / FUSE_WAVES;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
-    uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
+    unsigned *fusedBits = P.fused + ((size_t)slot * FBIT_REPL + (blockIdx.x % FBIT_REPL)) * P.fusedWords * FBIT_STRIDE;   // this workgroup's replica
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     const int wv = threadIdx.x >> 6;
@@ -1231,6 +1295,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
         if (threadIdx.x < FUSE_WAVES) s_delSub[threadIdx.x] = 0;
         if (threadIdx.x < FUSE_WAVES * 8) (&s_delBits[0][0])[threadIdx.x] = 0;
+        for (int wd = threadIdx.x; wd < P.fusedWords; wd += FUSE_NT) s_fbits[wd] = 0;
         __syncthreads();
         unsigned nupd = 0;
         // local index (10 bits) = wave << 8 | offset in the wave's sub-block; bit 15 of a list entry = redirected record
@@ -1239,7 +1304,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
         const long long c0 = sub_base(wv);
         auto mark_deleted = [&](long long i) {
             const unsigned off = (unsigned)(i - c0);
-            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | off;
+            atomicAdd(&s_cnt[0], 1u);
             atomicAdd(&s_delSub[wv], 1u);
             atomicOr(&s_delBits[wv][off >> 5], 1u << (off & 31u));
         };
@@ -1331,7 +1396,6 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
             // fourth dependent round trip on this latency-bound chain
             const msl_seed S = seeds[spIndex];
-            const uint8_t fz = fused[spIndex];       // possibly stale (another XCD may have set it): only saves a redundant store
             HotRec hr = M.hot[i];
             ColdRec C = M.cold[i];
             // common use of one field per load instruction (see phase A): all three records are in flight together
@@ -1355,7 +1419,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
             if (normDiffCos < MAX_ANGLE_COS) {
-                M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u);
+                M.hot[i].updateTimes = 0; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u);
                 atomicOr(&s_delBits[(sv >> 8) & 3u][(sv & 0xFFu) >> 5], 1u << (sv & 31u));
                 ndelB++; continue;
             }
@@ -1386,44 +1450,55 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             if (newSize < C.size) C.size = newSize;
             M.hot[i] = Hn;
             M.cold[i] = C;
-            if (!fz) st_agent_u8(&fused[spIndex], 1);   // write-through: the continuation reads the flags in this launch
+            atomicOr(&s_fbits[spIndex >> 5], 1u << (spIndex & 31));   // seed.fused = true (:279), handed over below
             nupd++;
         }
         if (nupd) atomicAdd(&s_cnt[1], nupd);
         if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
-        const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
-        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) st_agent(&P.blockSums[(long long)threadIdx.x * nW + b], s_delSub[threadIdx.x]);
-        if (threadIdx.x == 0) {
-            st_agent(&P.blockUpd[b], s_cnt[1]);
-            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per workgroup that deleted something
-        }
-        __syncthreads();
-        if (ndelBlk) {
-            const unsigned base = s_delBase;
-            for (unsigned j = threadIdx.x; j < ndelA; j += FUSE_NT)
-                if (base + j < LIST_D) st_agent(&P.delU[base + j], (unsigned)global_of(s_surv[LISTN - 1 - j] & 0x3FFu));
-            if (ndelBlk != ndelA)
-                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
-                    const unsigned sv = s_surv[sidx];
-                    if ((sv >> 16) != 0xFFFFu) continue;
-                    const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
-                    if (j < LIST_D) st_agent(&P.delU[j], (unsigned)global_of(sv & 0x3FFu));
-                }
-            // the wave's deleted slots in ascending order: lanes 0..7 expand one bitmap word each
+        const unsigned ndelBlk = s_cnt[0] + s_cnt[3];
+        {   // hand the wave's deleted slots over: count | offset of the first one << 9, and (if any) all of them in ascending order
             const unsigned lane = threadIdx.x & 63u;
-            if (hasSub && s_delSub[wv]) {
+            const unsigned myDel = hasSub ? s_delSub[wv] : 0u;
+            unsigned first = 0;
+            if (ndelBlk && myDel) {   // (workgroup-uniform && wave-uniform) lanes 0..7 expand one bitmap word each
                 const unsigned word = lane < 8 ? s_delBits[wv][lane] : 0u;
                 const unsigned pc = __popc(word);
                 unsigned o = wave_incl_scan(pc) - pc;
+                const unsigned long long nz = __ballot(word != 0);
+                first = 32u * (unsigned)__builtin_ctzll(nz) + (unsigned)__builtin_ctz(__shfl(word, __builtin_ctzll(nz), 64));
                 for (unsigned m = word; m; m &= m - 1) st_agent(&P.delStage[c0 + o++], (unsigned)(c0 + 32 * lane + __builtin_ctz(m)));
             }
+            if (lane == 0) s_subWord[wv] = myDel | (first << 9);
         }
+        // seeds this workgroup fused into: OR its bits into the keyframe's bitmap (<= one atomic per bitmap word and workgroup).
+        // Measured at 1 M surfels / 60 k updates per keyframe: result-less ORs +2 us per launch; a coherent pre-read that would
+        // skip already-set words +20 us (2000 workgroups reading the same 150 lines at agent scope serialise at the memory side);
+        // write-through byte flags +33 us.
+        for (int wd = threadIdx.x; wd < P.fusedWords; wd += FUSE_NT) {
+            const unsigned mine = s_fbits[wd];
+            if (mine) {
+                unsigned *g = &fusedBits[(size_t)wd * FBIT_STRIDE];
+                __hip_atomic_fetch_or(g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: a fire-and-forget OR
+            }
+        }
+        // publish: every hand-over store of this workgroup has been performed before its stamp becomes visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&P.blockDone[b], ((unsigned long long)seq << 44) | ((unsigned long long)(s_cnt[1] & 0x3FFu) << 34) |
+                                                    ((unsigned long long)s_subWord[1] << 17) | (unsigned long long)s_subWord[0],
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();   // s_subWord / s_cnt are rewritten by the next iteration
     }
-    // ---- the last workgroup to finish continues with the compaction ----
-    if (!last_workgroup(&P.tickets[0], &s_last)) return;
-    compact_tail<FUSE_NT>(P, slot, mode, s_surv, s_dl, s_wave, s_misc);
+    // ---- workgroup 0 continues with the compaction once every other workgroup has published its stamp.  No atomics: 2000
+    // same-address tickets serialise at the memory side (measured: 90 us per launch); per-workgroup stamps are plain write-through
+    // stores, polled with a few parallel agent-scope loads.  Nobody waits for workgroup 0, so this cannot deadlock. ----
+    if (blockIdx.x != 0) return;
+#if defined(MSL_EXP) && MSL_EXP == 4
+    return;
+#endif
+    compact_tail<FUSE_NT>(P, slot, mode, seq, s_dl, s_wave, s_misc);
 }
 
 // Materialise pending lazy tail moves (host-visible accessors call this before they touch the map).
@@ -1549,7 +1624,7 @@ struct msl_sf {
     int lastSlot = 0;
     // per-slot device buffers
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
-    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
+    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr; unsigned *d_fused = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
     double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
     float *d_pxInv = nullptr;
@@ -1563,7 +1638,8 @@ struct msl_sf {
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     size_t liveBound = 0;        // host-side upper bound of the live count: last synced count + nseeds per keyframe enqueued since
-    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr, *d_delStage = nullptr;
+    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr, *d_delStage = nullptr; unsigned long long *d_blockDone = nullptr;
+    unsigned fuseSeq = 0;        // launch stamp of k_fuse (the continuation waits until every work item carries it)
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
 };
@@ -1577,7 +1653,7 @@ void set_map_ptrs(msl_sf *h) {
     M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
-    h->dev.delStage = h->d_delStage;
+    h->dev.delStage = h->d_delStage; h->dev.blockDone = h->d_blockDone;
 }
 
 int sync_all(msl_sf *h) {
@@ -1589,7 +1665,7 @@ int sync_all(msl_sf *h) {
 // (Re)allocate the resident map for `cap` surfels, preserving the first `keep` entries.
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
-    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nst = nullptr;
+    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nst = nullptr; unsigned long long *nbd = nullptr;
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
@@ -1599,6 +1675,8 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nst, sizeof(unsigned) * cap));
+        MSL_HIP_TRY(hipMalloc(&nbd, sizeof(unsigned long long) * (cap / SUB_ITEMS + 4100)));
+        MSL_HIP_TRY(hipMemset(nbd, 0, sizeof(unsigned long long) * (cap / SUB_ITEMS + 4100)));
         if (keep && h->d_mapStore) {
             int rc = sync_all(h);
             if (rc != MSL_OK) return rc;
@@ -1615,13 +1693,14 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         if (ndl) (void)hipFree(ndl);
         if (nso) (void)hipFree(nso);
         if (nst) (void)hipFree(nst);
+        if (nbd) (void)hipFree(nbd);
         return arc;
     }
     if (h->d_mapStore) {
         (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
-        (void)hipFree(h->d_delStage);
+        (void)hipFree(h->d_delStage); (void)hipFree(h->d_blockDone);
     }
-    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_delStage = nst; h->mapCap = cap;
+    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_delStage = nst; h->d_blockDone = nbd; h->mapCap = cap;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -1644,7 +1723,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_seedsTmp, sizeof(msl_seed) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_cand, sizeof(msl_surfel) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_candOk, ns * slots));
-    MSL_HIP_TRY(hipMalloc(&h->d_fused, ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_fused, sizeof(unsigned) * (size_t)D.fusedWords * FBIT_REPL * FBIT_STRIDE * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_index, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
@@ -1657,7 +1736,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
     MSL_HIP_TRY(hipMemset(h->d_index, 0, sizeof(unsigned short) * npx * slots));
-    MSL_HIP_TRY(hipMemset(h->d_fused, 0, ns * slots));
+    MSL_HIP_TRY(hipMemset(h->d_fused, 0, sizeof(unsigned) * (size_t)D.fusedWords * FBIT_REPL * FBIT_STRIDE * slots));
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
@@ -1674,7 +1753,7 @@ int read_ctr(msl_sf *h) {
     // every host-visible accessor comes through here: materialise the lazy tail moves the last keyframe may have left pending
     hipLaunchKernelGGL(k_flush_moves, dim3(128), dim3(256), 0, h->mapStream, h->dev);
     hipLaunchKernelGGL(k_clear_pend, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr);
-    MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 8, hipMemcpyDeviceToHost, h->mapStream));
+    MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 16, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
     h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
@@ -1686,6 +1765,7 @@ int check_err(msl_sf *h) {
         const long long e = h->h_ctr[5];
         (void)hipMemsetAsync(h->d_ctr + 5, 0, sizeof(long long), h->mapStream);
         if (e == 20) set_error("resident surfel map capacity exceeded (reserve more with msl_sf_map_reserve)");
+        else if (e == 21) set_error("surfel map stage: bounded wait for the streaming workgroups exceeded (code 21)");
         else set_error("surfel pipeline device-side bound exceeded (code %lld)", e);
         return MSL_ERR_OVERFLOW;
     }
@@ -1780,7 +1860,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     SfDev P = D;
     // shift every per-slot base so that blockIdx.y/z == 0 addresses slot0
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
-    P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
+    P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.fusedWords * FBIT_REPL * FBIT_STRIDE;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
     P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.npx; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
@@ -1816,8 +1896,16 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // of the live count (the kernel loops if the map is larger, idle workgroups only take a ticket).
     const size_t boundLive = compact ? h->liveBound : h->mapCap;
     const unsigned fuseGrid = (unsigned)std::min<size_t>(65536, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
-    for (int f = 0; f < n; f++)
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f], compact ? 0 : 1);
+    for (int f = 0; f < n; f++) {
+        // 20-bit launch stamp, never 0; when it wraps the stamps of all work items are cleared so that no stale value can match
+        h->fuseSeq = (h->fuseSeq + 1) & 0xFFFFFu;
+        if (h->fuseSeq == 0) {
+            MSL_HIP_TRY(hipMemsetAsync(h->d_blockDone, 0, sizeof(unsigned long long) * (h->mapCap / SUB_ITEMS + 4100), sm));
+            h->fuseSeq = 1;
+        }
+        LAUNCH_LDS(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), sizeof(unsigned) * D.fusedWords, P, f, h->h_frames[slot0 + f], compact ? 0 : 1,
+                   h->fuseSeq);
+    }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     MSL_HIP_TRY(hipGetLastError());
     h->lastSlot = slot0 + n - 1;
@@ -1840,6 +1928,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     SfDev &D = h->dev;
     D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;
     D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.fuseFar = fuseFar; D.fuseNear = fuseNear;
+    D.fusedWords = (D.nseeds + 31) / 32;
     bool ok = true;
     {   // the per-keyframe map stage is the latency-critical chain: highest priority for its stream, lowest for the
         // throughput-oriented frame-batched superpixel stage
@@ -1853,7 +1942,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
              hipEventCreateWithFlags(&h->evCopy[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
-    ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 8) == hipSuccess;
+    ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
     ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D) == hipSuccess;
@@ -1869,7 +1958,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     if (ok && D.nseeds <= PROP_LDS_MAX_SEEDS)   // the attribute belongs to the function, not to this handle: always ask for the largest size any handle may use
         h->propLds = hipFuncSetAttribute((const void *)kb_prop_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * PROP_LDS_MAX_SEEDS)) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
-    memset(h->h_ctr, 0, sizeof(long long) * 8);
+    memset(h->h_ctr, 0, sizeof(long long) * 16);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
@@ -1884,7 +1973,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_delStage); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_delStage); F(h->d_blockDone); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
@@ -2105,9 +2194,22 @@ int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {
     if (rc != MSL_OK) return rc;
     const size_t ns = h->dev.nseeds;
     MSL_HIP_TRY(hipMemcpy(out, h->d_seeds + ns * h->lastSlot, sizeof(msl_seed) * ns, hipMemcpyDeviceToHost));
-    std::vector<uint8_t> fused(ns);
-    MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + ns * h->lastSlot, ns, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < ns; i++) out[i].fused = fused[i];
+    const size_t fwords = (size_t)h->dev.fusedWords, fw = fwords * FBIT_REPL * FBIT_STRIDE;
+    std::vector<unsigned> fused(fw);
+    MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + fw * h->lastSlot, sizeof(unsigned) * fw, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ns; i++) {
+        unsigned v = 0;
+        for (int e = 0; e < FBIT_REPL; e++) v |= fused[(e * fwords + (i >> 5)) * FBIT_STRIDE];
+        out[i].fused = (v >> (i & 31)) & 1u;
+    }
+    return MSL_OK;
+}
+int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {
+    if (!h || !out) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctr(h);
+    if (rc != MSL_OK) return rc;
+    for (int i = 0; i < 16; i++) out[i] = h->h_ctr[i];
     return MSL_OK;
 }
 int msl_sf_debug_index(msl_sf *h, int32_t *out) {

@@ -137,6 +137,11 @@ class SurfelFusion:
         check(lib.msl_sf_debug_seeds(self._h, ptr(out)))
         return out
 
+    def debug_ctr(self):
+        out = np.zeros(16, np.int64)
+        check(lib.msl_sf_debug_ctr(self._h, ptr(out)))
+        return out
+
     def debug_index(self):
         out = np.zeros((self.height, self.width), np.int32)
         check(lib.msl_sf_debug_index(self._h, ptr(out)))
