@@ -297,8 +297,7 @@ MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
 MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
 /* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
- * 5: deferred error code, 8: pending lazy tail moves -- always 0 here, the sync flushes them; 9-15: kernel time stamps in
- * instrumented builds). */
+ * 5: deferred error code; 8-15: spare, used by instrumented experiment builds for in-kernel time stamps). */
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */

@@ -54,12 +54,6 @@ constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the
 #endif
 constexpr int FUSE_WAVES = MSL_FUSE_WAVES;
 constexpr int FUSE_NT = 64 * FUSE_WAVES;
-// The seeds' fused bitmap is written by ~2000 workgroups (agent-scope ORs, ~30 words each) and read by one (the continuation).
-// Memory-side atomics on one 64-byte line serialise (~10-25 ns each: tools/micro/lat.hip), a single CU fetches about one line per
-// clock (tools/micro/coh.hip: 4096 scattered lines = 2 us).  16 replicas (a workgroup ORs into replica blockIdx % 16) x 4 words
-// per line = 600 lines: ~100 atomics per line for the writers, ~600 line fetches for the reader.
-constexpr int FBIT_STRIDE = 4;          // dwords between two words of the bitmap
-constexpr int FBIT_REPL = 16;           // replicas
 constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted-slot partials
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
@@ -94,9 +88,7 @@ struct SfDev {
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
     uint8_t *candOk;             // [slots][nseeds]
-    unsigned *fused;             // [slots][FBIT_REPL][fusedWords * FBIT_STRIDE] bit s of word s / 32 (OR over the replicas): seed s was consumed by
-                                 // a fusion
-    int fusedWords;              // ceil(nseeds / 32)
+    uint8_t *fused;              // [slots][nseeds] seed consumed by a fusion (written write-through, read at agent scope)
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
@@ -107,16 +99,12 @@ struct SfDev {
     int *changed;                // [slots][8]
     MapSoA map;
     unsigned long long cap;
-    // ctr[0]=n_live  [1]=K new (last)  [2]=D deleted (last)  [3]=updated (last)  [4]=n before (last)  [5]=err  [6]=n after (last)
-    // [7]=selection total (k_select_scan)  [8]=pending lazy tail moves
+    // ctr[0]=n_live  [1]=K new (last)  [2]=D deleted (last)  [3]=updated (last)  [4]=n before (last)  [5]=err  [6]=n after (last)  [7]=tail fallback flag
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
-    unsigned long long *blockDone;   // [cap / 512 + ..] per k_fuse work item: launch stamp << 44 | updated << 34 | wave 1 deleted << 17 | wave 0 deleted
-                                 //   (deleted = count | offset of the first deleted slot << 9), one 64-bit write-through store
-    unsigned *delStage;          // [cap] per sub-block (256 slots) the slots k_fuse found deleted, ascending, from the sub-block's first entry
-    unsigned *tickets;           // [0] k_fuse's "last workgroup continues" ticket, [2] delUCount
-    unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of the continuation)
+    unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
+    unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
     const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
 };
@@ -242,7 +230,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     imageY = imageY < (P.H - 1) ? imageY : (P.H - 1);
     msl_seed s;
     memset(&s, 0, sizeof(s));
-    for (int wd = seedI; wd < P.fusedWords * FBIT_REPL; wd += P.nseeds) P.fused[((size_t)slot * P.fusedWords * FBIT_REPL + wd) * FBIT_STRIDE] = 0;
+    P.fused[(size_t)slot * P.nseeds + seedI] = 0;
     if (F.memberG()[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
         P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.invDepth[(size_t)slot * P.nseeds + seedI] = 0.0;
         return;
@@ -1026,267 +1014,32 @@ __device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_fla
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// k_fuse (:167-283) -- the whole map stage of one keyframe in ONE launch.
-//   Streaming part: each wave owns sub-blocks of 256 consecutive surfels.
-//     Phase A: each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records per lane.  The
-//     ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.  Survivors are compacted into
-//     an LDS list (slot by LDS atomic; per-surfel work is order independent).
-//     Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed, cold
-//     record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
-//   Everything the compaction needs is handed over with write-through (agent-scope) stores: per-sub-block deleted counts and,
-//   for the sub-blocks that deleted something, their deleted slots in ascending order (a 256-bit LDS bitmap per wave, expanded
-//   by eight lanes); the updated count per workgroup; the `fused` flag of a seed (only the first store per XCD: the flag is
-//   read together with the seed record and stored only when it still reads 0).
-//   Continuation: the workgroup that draws the last ticket runs SurfelMapping::fuseMap's refill / compaction
-//   (src/SurfelMapping.cpp:366-391) and initializeSurfels (:285-331), see compact_tail() below.
-//   Lazy tail moves: when more slots were deleted than new surfels arrived, the reference moves tail elements into the
-//   leftover holes.  The moved records may still sit dirty in another XCD's L2, so the continuation only publishes the move
-//   list (hole -> source) and the new live count; the NEXT launch treats a hole as "the record at source" (phase A redirect,
-//   binary search in the list) and materialises it while streaming.  Host-visible accessors flush the list first.
-constexpr int CT_PEND = 8;   // ctr[8]: number of pending lazy tail moves (delList[a] <- srcOf[a], a < pend)
+// k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks).
+//   Phase A (streaming): each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records
+//   per lane.  The ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.
+//   Survivors are compacted into an LDS list (slot by LDS atomic; per-surfel work is order independent).
+//   Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed,
+//   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
+// Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
-__device__ __forceinline__ void st_agent_u8(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// source of the pending move whose destination is slot i, or -1
-__device__ __forceinline__ long long pend_source(const SfDev &P, long long pend, long long i) {
-    long long lo = 0, hi = pend;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)P.delList[mid] < i) lo = mid + 1; else hi = mid; }
-    return (lo < pend && (long long)P.delList[lo] == i) ? (long long)P.srcOf[lo] : -1;
-}
-
-__device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
-    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
-    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
-    M.hot[i] = h; M.cold[i] = c;
-}
-__device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
-    M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
-}
-
-// Continuation of k_fuse, one workgroup of NT threads.  mode 0: resident map.  mode 1 (host-vector drop-in): emission and
-// counters only; the caller compacts (SurfelMapping.cpp:366-391).
-//   D deleted slots d_0 < .. < d_{D-1}; new surfel k -> d_{D-1-k} while any remain, else appended (:372-384).  If D > K the
-//   literal `while` loop (:386-390) moves, at step i = 1..R (R = D - K), the element at position n - i into the i-th largest
-//   leftover hole; a hole inside the tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole
-//   (< nFinal = n - R) finally receives resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): an
-//   upward chain over the hole list (checked against the literal loop by test_compaction_matches_literal_loop).
-// Hand-over from the streaming workgroups (all write-through, read here at agent scope): blockSums[sub] = deleted count of the
-// sub-block | offset of its first deleted slot << 16; delStage[sub * 256 + r] = its r-th deleted slot (ascending); blockUpd[wg];
-// the seeds' fused flags.  Steady state (a handful of deletions, one per sub-block) needs ONE dependent round trip for all of it.
-#ifdef MSL_TAIL_STAMPS
-#define TSTAMP(k) do { if (threadIdx.x == 0) P.ctr[9 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
-#else
-#define TSTAMP(k) do { } while (0)
-#endif
-template <int NT>
-__device__ void compact_tail(const SfDev &P, int slot, int mode, unsigned seq, unsigned *s_dl /*>= LIST_D*/, unsigned *s_wave /*>= 33*/, unsigned *s_misc /*>= 4*/) {
-    const int tid = threadIdx.x;
-    const long long n = P.ctr[0];
-    const bool bad = P.ctr[5] == 20;
-    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS, nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;
-    static_assert(FUSE_WAVES == 2, "stamp layout: two sub-blocks per work item");
-    TSTAMP(1);
-    // ---- initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order.
-    // What does not depend on this launch (candOk, written by kb_seed_plane) is fetched before the wait below ----
-    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds;
-    const int per = (((P.nseeds + NT - 1) / NT) + 31) & ~31;      // seeds per thread, multiple of 32: whole bitmap words
-    const int s0 = tid * per, s1 = min(s0 + per, P.nseeds);
-    unsigned long long cmask = 0;   // bit j: candOk of seed s0 + j
-    {   // candOk bytes (0 / 1) of the first 64 seeds as sixteen words (plain loads: written by an earlier kernel), packed to one bit each
-        const bool aligned = (reinterpret_cast<size_t>(candOk) & 3) == 0;
-        unsigned cw[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int i = s0 + 4 * q;
-            unsigned w4 = 0;
-            if (i + 4 <= s1 && aligned) w4 = *reinterpret_cast<const unsigned *>(candOk + i);
-            else
-                for (int j = 0; j < 4; j++)
-                    if (i + j < s1) w4 |= (unsigned)(candOk[i + j] != 0) << (8 * j);
-            cw[q] = w4;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const unsigned w4 = cw[q];
-            const unsigned nib = ((w4 & 0xFFu) ? 1u : 0u) | ((w4 & 0xFF00u) ? 2u : 0u) | ((w4 & 0xFF0000u) ? 4u : 0u) | ((w4 & 0xFF000000u) ? 8u : 0u);
-            cmask |= (unsigned long long)nib << (4 * q);
-        }
-    }
-    // ---- wait until every work item carries this launch's stamp; the stamps also bring the deleted / updated counts.  Thread t
-    // owns the contiguous work items [w0, w1): sub-block (wave w, item b) = w * nWg + b, so hole order = wave 0 items, then wave 1 ----
-    const long long perW = (nWg + NT - 1) / NT, w0 = min((long long)tid * perW, nWg), w1 = min(w0 + perW, nWg);
-    unsigned dsum0 = 0, dsum1 = 0, upd = 0, nne0 = 0, nne1 = 0;
-    unsigned neIdx[2][3], neW[2][3];      // per wave the thread's first non-empty sub-blocks (more: the second pass reloads)
-    for (int spin = 0;; spin++) {
-        int ok = 1;
-        dsum0 = dsum1 = upd = nne0 = nne1 = 0;
-        for (long long c = w0; c < w1; c += 16) {
-            unsigned long long st[16];
-#pragma unroll
-            for (int e = 0; e < 16; e++)   // sixteen independent agent-scope loads in flight (all of a 1 M map's stamps in one round trip)
-                st[e] = c + e < w1 ? __hip_atomic_load(&P.blockDone[c + e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)seq << 44);
-#pragma unroll
-            for (int e = 0; e < 16; e++) {
-                ok &= (unsigned)(st[e] >> 44) == seq ? 1 : 0;
-                upd += (unsigned)(st[e] >> 34) & 0x3FFu;
-                const unsigned a0 = (unsigned)st[e] & 0x1FFFFu, a1 = (unsigned)(st[e] >> 17) & 0x1FFFFu;
-                if (a0 & 0x1FFu) {
-                    dsum0 += a0 & 0x1FFu;
-#pragma unroll
-                    for (int q = 0; q < 3; q++) if (nne0 == (unsigned)q) { neIdx[0][q] = (unsigned)(c + e); neW[0][q] = a0; }
-                    nne0++;
-                }
-                if (a1 & 0x1FFu) {
-                    dsum1 += a1 & 0x1FFu;
-#pragma unroll
-                    for (int q = 0; q < 3; q++) if (nne1 == (unsigned)q) { neIdx[1][q] = (unsigned)(nWg + c + e); neW[1][q] = a1; }
-                    nne1++;
-                }
-            }
-        }
-        if (__syncthreads_and(ok)) break;
-        if (spin >= (1 << 22)) { if (tid == 0) P.ctr[5] = 21; return; }   // bounded wait exceeded: reported at the next sync
-        __builtin_amdgcn_s_sleep(1);
-    }
-    TSTAMP(2);
-    if (tid == 0) s_misc[0] = 0;
-    const unsigned *fusedBits = P.fused + (size_t)slot * P.fusedWords * FBIT_REPL * FBIT_STRIDE;
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
-    // the thread's first two bitmap words (64 seeds) travel in one round trip; `fused` was written in this launch: agent-scope loads
-    auto fused_word = [&](int wd) -> unsigned {   // OR over the replicas: FBIT_REPL independent loads in flight
-        unsigned v[FBIT_REPL], r = 0;
-#pragma unroll
-        for (int e = 0; e < FBIT_REPL; e++) v[e] = ld_agent(&fusedBits[((size_t)e * P.fusedWords + wd) * FBIT_STRIDE]);
-#pragma unroll
-        for (int e = 0; e < FBIT_REPL; e++) r |= v[e];
-        return r;
-    };
-    unsigned fb0 = 0, fb1 = 0;
-    {
-        unsigned v0[FBIT_REPL], v1[FBIT_REPL];
-        const bool h0 = s0 < s1, h1 = s0 + 32 < s1;
-#pragma unroll
-        for (int e = 0; e < FBIT_REPL; e++) {
-            v0[e] = h0 ? ld_agent(&fusedBits[((size_t)e * P.fusedWords + (s0 >> 5)) * FBIT_STRIDE]) : 0u;
-            v1[e] = h1 ? ld_agent(&fusedBits[((size_t)e * P.fusedWords + (s0 >> 5) + 1) * FBIT_STRIDE]) : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < FBIT_REPL; e++) { fb0 |= v0[e]; fb1 |= v1[e]; }
-    }
-    const unsigned long long fmask = (unsigned long long)fb0 | ((unsigned long long)fb1 << 32);   // fused flags of seeds s0 .. s0 + 63
-    auto is_fused_slow = [&](int i) -> bool { return (fused_word(i >> 5) >> (i & 31)) & 1u; };    // seeds beyond the first 64 (large images)
-    unsigned cnt = 0;
-    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
-    {
-        emit = cmask & ~fmask;
-        cnt = (unsigned)__popcll(emit);
-        for (int i = s0 + 64; i < s1; i++)
-            if (candOk[i] && !is_fused_slow(i)) cnt++;
-    }
-    if (upd) atomicAdd(&s_misc[0], upd);
-    const unsigned dsum = dsum0 + dsum1;
-    TSTAMP(3);
-    unsigned D0, D1, ex0, ex1, Ku, pos;
-    block_excl_scan_pair(dsum0, dsum1, s_wave, &D0, &D1, ex0, ex1);
-    pos = block_excl_scan(cnt, s_wave, &Ku);
-    // ---- ascending list of the deleted slots: LDS when it is short, delList[] otherwise ----
-    const long long D = (long long)D0 + D1, K = Ku;
-    const bool useLds = D <= LIST_D;
-    const bool build = mode == 0 && !bad;
-    auto put = [&](unsigned j, unsigned slotIdx) { if (useLds) s_dl[j] = slotIdx; else st_agent(&P.delList[j], slotIdx); };
-    auto put_sub = [&](unsigned &off, unsigned sub, unsigned word) {   // word = count | offset of the first deleted slot << 9
-        const unsigned c = word & 0x1FFu, base = sub * (unsigned)SUB_ITEMS;
-        put(off, base + (word >> 9));
-        for (unsigned r = 1; r < c; r++) put(off + r, ld_agent(&P.delStage[base + r]));
-        off += c;
-    };
-    if (build && dsum) {
-#pragma unroll
-        for (int w = 0; w < 2; w++) {
-            unsigned off = w == 0 ? ex0 : D0 + ex1;
-            const unsigned nne = w == 0 ? nne0 : nne1;
-            if (nne <= 3) {
-#pragma unroll
-                for (int q = 0; q < 3; q++)
-                    if ((unsigned)q < nne) put_sub(off, neIdx[w][q], neW[w][q]);
-            } else {
-                for (long long c = w0; c < w1; c++) {
-                    const unsigned long long st = __hip_atomic_load(&P.blockDone[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned word = (unsigned)(st >> (17 * w)) & 0x1FFFFu;
-                    if (word & 0x1FFu) put_sub(off, (unsigned)(w * nWg + c), word);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
-    const bool place = build && (unsigned long long)nAfter <= P.cap;
-    auto DL = [&](long long j) -> unsigned { return useLds ? s_dl[j] : ld_agent(&P.delList[j]); };
-    if (cnt) {
-        auto emit_one = [&](const msl_surfel &e) {
-            const long long k = pos++;
-            if (mode == 1) P.newSurfels[k] = e;     // host-vector mode returns this list
-            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
-                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
-        };
-        for (unsigned long long m = emit; m; m &= m - 1) emit_one(cand[s0 + __builtin_ctzll(m)]);
-        for (int i = s0 + 64; i < s1; i++)
-            if (candOk[i] && !is_fused_slow(i)) emit_one(cand[i]);
-    }
-    TSTAMP(4);
-    long long nPublish = nAfter, pendOut = 0;
-    if (place && D > K) {
-        // lazy tail moves: leftover holes d_0 .. d_{R-1}; those below nFinal are the destinations
-        const long long R = D - K, nFinal = n - R;
-        auto lower = [&](long long x) -> long long {   // first index in the leftover holes with value >= x
-            long long lo = 0, hi = R;
-            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
-            return lo;
-        };
-        const long long cntLow = lower(nFinal);
-        for (long long a = tid; a < cntLow; a += NT) {
-            long long p = nFinal + a;
-            for (long long hop = 0; hop <= R; hop++) {   // a relay hole forwards to where its content came from: strictly upward, ends at a live element
-                const long long lb = lower(p);
-                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb); else break;
-            }
-            P.srcOf[a] = (unsigned)p;
-            if (useLds) P.delList[a] = s_dl[a];   // the long-list path already holds the destinations in delList[]
-        }
-        nPublish = nFinal; pendOut = cntLow;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_misc[0]; P.ctr[4] = n; P.ctr[6] = nAfter;
-        if ((unsigned long long)nAfter > P.cap && mode == 0) P.ctr[5] = 20;  // capacity exceeded
-        if (place) { P.ctr[0] = nPublish; P.ctr[CT_PEND] = pendOut; }        // publish the new live count and the pending moves
-    }
-    TSTAMP(5);
-}
-
-__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F, int mode, unsigned seq) {   // F by value: kernarg -> SGPRs
-    // One small survivor list per workgroup (4 entries per thread: local index | superpixel << 16) keeps the kernel co-resident
-    // with the LDS-heavy batched kernels; deleted slots are recorded in a 256-bit map per wave.
+__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
+    // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
+    // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
+    // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
     // Each wave owns one sub-block of 256 consecutive surfels, and the FUSE_WAVES waves of a workgroup take theirs from
     // different parts of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
     // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
     __shared__ unsigned s_cnt[5], s_delSub[4];
     constexpr int LISTN = 4 * FUSE_NT;
     __shared__ unsigned s_surv[LISTN];
-    __shared__ unsigned s_delBits[FUSE_WAVES][8];   // deleted slots of each wave's sub-block, one bit per surfel
-    __shared__ unsigned s_dl[LIST_D], s_wave[33], s_misc[4], s_subWord[FUSE_WAVES];
-    extern __shared__ unsigned s_fbits[];           // [fusedWords] seeds this workgroup fused surfels into
+    __shared__ unsigned s_delBase;
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const long long n = P.ctr[0];
-    const long long pend = P.ctr[CT_PEND];
-#ifdef MSL_TAIL_STAMPS
-    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctr[9] = (long long)__builtin_readcyclecounter();
-#endif
     const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + FUSE_WAVES - 1) / FUSE_WAVES;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
-    unsigned *fusedBits = P.fused + ((size_t)slot * FBIT_REPL + (blockIdx.x % FBIT_REPL)) * P.fusedWords * FBIT_STRIDE;   // this workgroup's replica
+    uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     const int wv = threadIdx.x >> 6;
@@ -1294,19 +1047,15 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
         const long long b = nW - 1 - bq;   // the newest surfels (most phase-B work) are dispatched first
         if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
         if (threadIdx.x < FUSE_WAVES) s_delSub[threadIdx.x] = 0;
-        if (threadIdx.x < FUSE_WAVES * 8) (&s_delBits[0][0])[threadIdx.x] = 0;
-        for (int wd = threadIdx.x; wd < P.fusedWords; wd += FUSE_NT) s_fbits[wd] = 0;
         __syncthreads();
         unsigned nupd = 0;
-        // local index (10 bits) = wave << 8 | offset in the wave's sub-block; bit 15 of a list entry = redirected record
+        // local index (10 bits) = wave << 8 | offset in the wave's sub-block
         auto sub_base = [&](unsigned w) -> long long { return ((long long)w * nW + b) * SUB_ITEMS; };
-        auto global_of = [&](unsigned local) -> long long { return sub_base((local >> 8) & 3u) + (local & 0xFFu); };
+        auto global_of = [&](unsigned local) -> long long { return sub_base(local >> 8) + (local & 0xFFu); };
         const long long c0 = sub_base(wv);
         auto mark_deleted = [&](long long i) {
-            const unsigned off = (unsigned)(i - c0);
-            atomicAdd(&s_cnt[0], 1u);
+            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
             atomicAdd(&s_delSub[wv], 1u);
-            atomicOr(&s_delBits[wv][off >> 5], 1u << (off & 31u));
         };
         const bool hasSub = (long long)wv * nW + b < nSub;   // the last workgroups may own fewer than four sub-blocks
         // map capacity is a multiple of 4096: the 16-byte loads of an existing sub-block stay in bounds
@@ -1316,32 +1065,8 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             uint4 q[5];
 #pragma unroll
             for (int j = 0; j < 5; j++) q[j] = hp[j];
-            unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
-                              q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
-            unsigned redir = 0;
-            if (pend > 0) {   // (kernel-uniform) lazy tail moves of the previous keyframe: a hole below n stands for its source record
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const long long i = i0 + k;
-                    if (hasSub && i < n && (int)w[5 * k + 3] == 0) {
-                        const long long src = pend_source(P, pend, i);
-                        if (src >= 0) {
-                            const HotRec hs = M.hot[src];
-                            M.hot[i] = hs;                           // materialise the move now; phase B re-reads it past the L1
-                            {
-                                const unsigned *cs = reinterpret_cast<const unsigned *>(M.cold + src);
-                                unsigned *cd = reinterpret_cast<unsigned *>(M.cold + i);
-#pragma unroll
-                                for (int e = 0; e < 9; e++) cd[e] = cs[e];
-                            }
-                            w[5 * k] = __float_as_uint(hs.px); w[5 * k + 1] = __float_as_uint(hs.py); w[5 * k + 2] = __float_as_uint(hs.pz);
-                            w[5 * k + 3] = (unsigned)hs.updateTimes; w[5 * k + 4] = (unsigned)hs.lastUpdate;
-                            redir |= 1u << k;
-                        }
-                    }
-                }
-                if (redir) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the copies have reached the L2 before phase B looks for them
-            }
+            const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
+                                    q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
             // Branch-free up to the loads: the eight depth / superpixel lookups of the lane's (up to four) in-view surfels
             // leave together (lanes without an in-view surfel read some valid pixel), so the lane pays ONE dependent round trip.
             int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
@@ -1382,7 +1107,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
                 if (state[k] == 1) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
                 if (state[k] == 2) { mark_deleted(i); continue; }
                 if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (((redir >> k) & 1u) << 15) | (spi[k] << 16);
+                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (spi[k] << 16);
             }
         }
         __syncthreads();
@@ -1390,24 +1115,16 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
         unsigned ndelB = 0;
         for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
             const unsigned sv = s_surv[sidx];
-            const long long i = global_of(sv & 0x3FFu);
+            const long long i = global_of(sv & 0xFFFFu);
             const int spIndex = (int)(sv >> 16);
             // seed, hot record (just streamed by this workgroup: cache hit) and cold record in ONE round trip; the cold
             // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
             // fourth dependent round trip on this latency-bound chain
             const msl_seed S = seeds[spIndex];
-            HotRec hr = M.hot[i];
+            const HotRec hr = M.hot[i];
             ColdRec C = M.cold[i];
             // common use of one field per load instruction (see phase A): all three records are in flight together
             asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
-            if (sv & 0x8000u) {   // redirected record, materialised by another thread of this workgroup a moment ago: read it past the L1
-                const unsigned *hp = reinterpret_cast<const unsigned *>(M.hot + i), *cp = reinterpret_cast<const unsigned *>(M.cold + i);
-                hr.px = __uint_as_float(ld_agent(hp)); hr.py = __uint_as_float(ld_agent(hp + 1)); hr.pz = __uint_as_float(ld_agent(hp + 2));
-                hr.updateTimes = (int)ld_agent(hp + 3); hr.lastUpdate = (int)ld_agent(hp + 4);
-                C.nx = __uint_as_float(ld_agent(cp)); C.ny = __uint_as_float(ld_agent(cp + 1)); C.nz = __uint_as_float(ld_agent(cp + 2));
-                C.size = __uint_as_float(ld_agent(cp + 3)); C.color = __uint_as_float(ld_agent(cp + 4));
-                C.r = (int)ld_agent(cp + 5); C.g = (int)ld_agent(cp + 6); C.b = (int)ld_agent(cp + 7); C.weight = __uint_as_float(ld_agent(cp + 8));
-            }
             const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
             if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
             if (S.viewCos < MAX_ANGLE_COS) continue;
@@ -1418,11 +1135,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             float nc[3];
             mul3(F.invPose, C.nx, C.ny, C.nz, nc);
             const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) {
-                M.hot[i].updateTimes = 0; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u);
-                atomicOr(&s_delBits[(sv >> 8) & 3u][(sv & 0xFFu) >> 5], 1u << (sv & 31u));
-                ndelB++; continue;
-            }
+            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
             const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
             const float oldWeight = C.weight;
             const float newWeight = get_weight(S.meanDepth);
@@ -1450,65 +1163,298 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F,
             if (newSize < C.size) C.size = newSize;
             M.hot[i] = Hn;
             M.cold[i] = C;
-            atomicOr(&s_fbits[spIndex >> 5], 1u << (spIndex & 31));   // seed.fused = true (:279), handed over below
+            fused[spIndex] = 1;
             nupd++;
         }
         if (nupd) atomicAdd(&s_cnt[1], nupd);
         if (ndelB) atomicAdd(&s_cnt[3], ndelB);
         __syncthreads();
-        const unsigned ndelBlk = s_cnt[0] + s_cnt[3];
-        {   // hand the wave's deleted slots over: count | offset of the first one << 9, and (if any) all of them in ascending order
-            const unsigned lane = threadIdx.x & 63u;
-            const unsigned myDel = hasSub ? s_delSub[wv] : 0u;
-            unsigned first = 0;
-            if (ndelBlk && myDel) {   // (workgroup-uniform && wave-uniform) lanes 0..7 expand one bitmap word each
-                const unsigned word = lane < 8 ? s_delBits[wv][lane] : 0u;
-                const unsigned pc = __popc(word);
-                unsigned o = wave_incl_scan(pc) - pc;
-                const unsigned long long nz = __ballot(word != 0);
-                first = 32u * (unsigned)__builtin_ctzll(nz) + (unsigned)__builtin_ctz(__shfl(word, __builtin_ctzll(nz), 64));
-                for (unsigned m = word; m; m &= m - 1) st_agent(&P.delStage[c0 + o++], (unsigned)(c0 + 32 * lane + __builtin_ctz(m)));
-            }
-            if (lane == 0) s_subWord[wv] = myDel | (first << 9);
+        const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
+        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
+        if (threadIdx.x == 0) {
+            P.blockUpd[b] = s_cnt[1];
+            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per workgroup that deleted something
         }
-        // seeds this workgroup fused into: OR its bits into the keyframe's bitmap (<= one atomic per bitmap word and workgroup).
-        // Measured at 1 M surfels / 60 k updates per keyframe: result-less ORs +2 us per launch; a coherent pre-read that would
-        // skip already-set words +20 us (2000 workgroups reading the same 150 lines at agent scope serialise at the memory side);
-        // write-through byte flags +33 us.
-        for (int wd = threadIdx.x; wd < P.fusedWords; wd += FUSE_NT) {
-            const unsigned mine = s_fbits[wd];
-            if (mine) {
-                unsigned *g = &fusedBits[(size_t)wd * FBIT_STRIDE];
-                __hip_atomic_fetch_or(g, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // result unused: a fire-and-forget OR
-            }
-        }
-        // publish: every hand-over store of this workgroup has been performed before its stamp becomes visible
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&P.blockDone[b], ((unsigned long long)seq << 44) | ((unsigned long long)(s_cnt[1] & 0x3FFu) << 34) |
-                                                    ((unsigned long long)s_subWord[1] << 17) | (unsigned long long)s_subWord[0],
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();   // s_subWord / s_cnt are rewritten by the next iteration
+        if (ndelBlk) {
+            const unsigned base = s_delBase;
+            for (unsigned j = threadIdx.x; j < ndelA; j += FUSE_NT)
+                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[LISTN - 1 - j]);
+            if (ndelBlk != ndelA)
+                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
+                    const unsigned sv = s_surv[sidx];
+                    if ((sv >> 16) != 0xFFFFu) continue;
+                    const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
+                    if (j < LIST_D) P.delU[j] = (unsigned)global_of(sv & 0xFFFFu);
+                }
+        }
+        __syncthreads();
     }
-    // ---- workgroup 0 continues with the compaction once every other workgroup has published its stamp.  No atomics: 2000
-    // same-address tickets serialise at the memory side (measured: 90 us per launch); per-workgroup stamps are plain write-through
-    // stores, polled with a few parallel agent-scope loads.  Nobody waits for workgroup 0, so this cannot deadlock. ----
-    if (blockIdx.x != 0) return;
-#if defined(MSL_EXP) && MSL_EXP == 4
-    return;
-#endif
-    compact_tail<FUSE_NT>(P, slot, mode, seq, s_dl, s_wave, s_misc);
 }
 
-// Materialise pending lazy tail moves (host-visible accessors call this before they touch the map).
-__global__ __launch_bounds__(256) void k_flush_moves(SfDev P) {
-    const long long pend = P.ctr[CT_PEND];
-    for (long long a = (long long)blockIdx.x * 256 + threadIdx.x; a < pend; a += (long long)gridDim.x * 256)
-        move_surfel(P.map, (long long)P.delList[a], (long long)P.srcOf[a]);
+__device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
+    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
+    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
+    M.hot[i] = h; M.cold[i] = c;
 }
-__global__ void k_clear_pend(long long *ctr) {
-    if (threadIdx.x == 0) ctr[CT_PEND] = 0;
+__device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
+    M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
+}
+
+// Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
+// new surfel k -> d_{D-1-k} while any remain, else appended.  If D > K the literal `while` loop (:386-390) moves,
+// at step i = 1..R (R = D-K), the element at position n-i into the i-th largest leftover hole; a hole inside the
+// tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole (< nFinal) finally receives
+// resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): a short upward chain.
+constexpr int TAIL_MAX_HOPS = 64;
+
+// k_compact: everything after k_fuse in ONE launch.
+//   every workgroup : exclusive scan of the per-chunk deleted counts (each workgroup scans the <= cap/1024 partials itself,
+//                     so there is no inter-workgroup dependency), then lists the deleted slots of its own chunks in
+//                     ascending order (write-through stores);
+//   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
+//                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
+// mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
+constexpr int SMALL_D = 512, SMALL_CHUNKS = 48;   // single-workgroup path: few deletions in few chunks
+
+// LDS is kept to ~3.5 KB: on a GPU saturated by the LDS-heavy batched kernels a larger workgroup waits for a CU to drain.
+__global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
+    constexpr int NT = 256, TILE = 4 * NT;
+    __shared__ unsigned s_wave[33];
+    __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
+    __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
+    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk;
+    __shared__ unsigned s_nzIdx[SMALL_CHUNKS], s_nzCnt[SMALL_CHUNKS], s_nzSortIdx[SMALL_CHUNKS], s_nzSortCnt[SMALL_CHUNKS];   // sub-blocks with deletions
+    __shared__ int s_fallback;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
+    // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
+    // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
+    const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
+    uint4 bu[4];   // the first 4096 per-workgroup updated counts (arrays are padded by >= 4096 zeroed entries)
+#pragma unroll
+    for (int q = 0; q < 4; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
+    static_assert(LIST_D == NT, "one hand-over entry per thread");
+    const unsigned du = P.delU[threadIdx.x];
+    const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
+    const long long n = P.ctr[0];
+    const bool bad = P.ctr[5] == 20;
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
+    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
+    unsigned cnt = 0;
+    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
+    if (per <= 32 && (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0) {
+        // common geometry: all flag words of the thread in ONE round trip
+        unsigned cw[8], fw[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = s0 + 4 * q;
+            const bool in = 4 * q < per && i < s1;
+            cw[q] = in ? *reinterpret_cast<const unsigned *>(candOk + i) : 0u;
+            fw[q] = in ? *reinterpret_cast<const unsigned *>(fused + i) : 0u;
+        }
+        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]), "v"(cw[7]),
+                     "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3]), "v"(fw[4]), "v"(fw[5]), "v"(fw[6]), "v"(fw[7]));
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (s0 + 4 * q + j < s1 && ((cw[q] >> (8 * j)) & 0xFF) && !((fw[q] >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                emit |= (unsigned long long)e << (4 * q + j);
+            }
+    } else {
+        for (int i = s0; i < s1; i += 4) {
+            unsigned c4, f4;
+            if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
+                c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
+            } else {
+                c4 = f4 = 0;
+                for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+            }
+        }
+    }
+    // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
+    // that this round trip overlaps the scans below instead of following them.
+    msl_surfel e0, e1;
+    memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
+    if (pf && emit) {
+        e0 = cand[s0 + __builtin_ctzll(emit)];
+        const unsigned long long m1 = emit & (emit - 1);
+        if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
+    }
+    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
+    const long long nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;   // k_fuse workgroups (blockUpd entries)
+    s_raw[threadIdx.x] = du;
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
+    __syncthreads();
+    // k_fuse already counted the deleted slots; when they all fit its hand-over list (the steady state) the per-sub-block
+    // counts are not needed at all.  Otherwise one pass over them (4 consecutive per thread and tile) lists the sub-blocks
+    // that contain deletions.
+    const bool fastest = mode == 0 && dHand <= LIST_D;
+    unsigned vsum = 0;
+    if (!fastest)
+        for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+            const long long c = t0 + 4 * threadIdx.x;
+            const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+            const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x[j] > 0) {
+                    vsum += x[j];
+                    const unsigned q = atomicAdd(&s_nzChunks, 1u);
+                    if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
+                }
+        }
+    unsigned Dtot, Ku, exUnused, pos;
+    block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
+    const long long D = fastest ? (long long)dHand : (long long)Dtot;
+    // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
+    const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
+    const bool single = fastest || small;
+    if (single && blockIdx.x != 0) return;
+    if (mode == 0 && !bad) {
+        if (fastest) {
+            if (threadIdx.x < D) {   // rank-sort in LDS
+                unsigned r = 0;
+                for (unsigned j = 0; j < (unsigned)D; j++) r += s_raw[j] < du ? 1u : 0u;
+                s_dl[r] = du;
+            }
+        } else if (small) {
+            // few sub-blocks hold all deletions: order them by index (rank sort); a sub-block's offset in the ascending
+            // list is the sum of the counts before it -- no scan over the (thousands of) empty sub-blocks
+            const unsigned nz = s_nzChunks;
+            if (threadIdx.x < nz) {
+                const unsigned me = s_nzIdx[threadIdx.x];
+                unsigned r = 0;
+                for (unsigned j = 0; j < nz; j++) r += s_nzIdx[j] < me ? 1u : 0u;
+                s_nzSortIdx[r] = me; s_nzSortCnt[r] = s_nzCnt[threadIdx.x];
+            }
+            __syncthreads();
+            unsigned base = 0;
+            for (unsigned it = 0; it < nz; it++) {
+                const long long i0 = (long long)s_nzSortIdx[it] * SUB_ITEMS + threadIdx.x;   // one slot per thread: ascending
+                const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
+                unsigned tt;
+                const unsigned w = base + block_excl_scan(f, s_wave, &tt);
+                if (f) s_dl[w] = (unsigned)i0;
+                base += s_nzSortCnt[it];
+            }
+        } else {
+            // every workgroup lists the deleted slots of its own sub-blocks in ascending order; a sub-block's base offset
+            // lives in the registers of the thread that scanned it and is broadcast through one LDS word
+            unsigned carry = 0;
+            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+                const long long c = t0 + 4 * threadIdx.x;
+                const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+                const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+                unsigned tot;
+                const unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+                const long long nIter = (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
+                for (long long it = 0; it < nIter; it++) {
+                    const long long b = t0 + blockIdx.x + it * gridDim.x;
+                    const int q = (int)(b - t0);
+                    if ((int)threadIdx.x == (q >> 2)) {
+                        const int comp = q & 3;
+                        s_base = ex + (comp > 0 ? v[0] : 0u) + (comp > 1 ? v[1] : 0u) + (comp > 2 ? v[2] : 0u);
+                        s_cntChunk = v[comp];
+                    }
+                    __syncthreads();
+                    const unsigned base = s_base, cntChunk = s_cntChunk;
+                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this sub-block
+                    const long long i0 = b * SUB_ITEMS + threadIdx.x;       // one slot per thread keeps the list ascending
+                    const unsigned f = (i0 < n && P.map.hot[i0].updateTimes == 0) ? 1u : 0u;
+                    unsigned tt;
+                    const unsigned w = base + block_excl_scan(f, s_wave, &tt);   // (its barriers also protect s_base)
+                    if (f) st_agent(&P.delList[w], (unsigned)i0);
+                }
+                carry += tot;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (mode == 0 && !single && !last_workgroup(&P.tickets[1], &s_last)) return;
+    // ================= continuation: one workgroup =================
+    // updated count
+    {
+        unsigned u = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long c = TILE * q + 4 * threadIdx.x;
+            u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
+        }
+        for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
+        if (u) atomicAdd(&s_upd, u);
+    }
+    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
+    const long long K = Ku;
+    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
+    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
+    auto DL = [&](long long j) -> unsigned { return single ? s_dl[j] : ld_agent(&P.delList[j]); };
+    if (cnt) {
+        auto emit_one = [&](const msl_surfel &e) {
+            const long long k = pos++;
+            P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
+            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
+                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
+        };
+        unsigned long long m = emit;
+        for (int j = 0; m; j++, m &= m - 1) {
+            const int i = s0 + __builtin_ctzll(m);
+            if (pf && j == 0) emit_one(e0);
+            else if (pf && j == 1) emit_one(e1);
+            else emit_one(cand[i]);
+        }
+        for (int i = s0 + 64; i < s1; i++)
+            if (candOk[i] && !fused[i]) emit_one(cand[i]);
+    }
+    __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
+    if (threadIdx.x == 0) {
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
+        if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
+    }
+    if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }
+    const long long t0 = threadIdx.x, stride = blockDim.x;
+    if (D > K) {
+        const long long R = D - K, nFinal = n - R;
+        auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
+            long long lo = 0, hi = R;
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const long long cntLow = lower(nFinal);
+        for (long long a = t0; a < cntLow; a += stride) {
+            long long p = nFinal + a;
+            int hop = 0;
+            for (; hop < TAIL_MAX_HOPS; hop++) {
+                const long long lb = lower(p);
+                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb);   // relay hole: follow to where its content came from
+                else break;
+            }
+            if (hop == TAIL_MAX_HOPS) s_fallback = 1;   // pathological chain: fall back to the literal loop
+            P.srcOf[a] = (unsigned)p;
+        }
+        __syncthreads();   // also orders the new-surfel stores above before the moves below (same workgroup)
+        if (s_fallback) {
+            if (threadIdx.x == 0)   // literal back-to-front loop (SurfelMapping.cpp:386-390), pathological delete patterns only
+                for (long long i = 1; i <= R; i++) {
+                    const long long hole = DL(R - i), src = n - i;
+                    if (src != hole) move_surfel(P.map, hole, src);
+                }
+        } else {
+            for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
+        }
+    }
+    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
 }
 
 // ---- map maintenance: ordered selection of surfels by a predicate -------------------------------
@@ -1598,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     dst[i] = e;
 }
 __global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
-    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; ctr[8] = 0; }
+    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
 }
 
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
@@ -1609,7 +1555,7 @@ __global__ void k_debug_div100(const float *x, double *out, long long n) {
 enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_COMMIT_SEEDS, SK_SEED_PLANE, SK_FUSE, SK_NEW, SK_COMPACT,
        SK_CONVERT, SK_COPY };
 const char *kSfNames[MSL_SF_NKERNELS] = {"kb_seed_init", "kb_assign", "kb_prop", "kb_commit_px", "kb_update_seeds", "kb_commit_seeds",
-                                         "kb_seed_plane", "k_fuse", "(unused)", "k_flush_moves", "k_convert", "copy"};
+                                         "kb_seed_plane", "k_fuse", "(unused)", "k_compact", "k_convert", "copy"};
 
 }  // namespace
 
@@ -1624,7 +1570,7 @@ struct msl_sf {
     int lastSlot = 0;
     // per-slot device buffers
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
-    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr; unsigned *d_fused = nullptr;
+    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
     double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
     float *d_pxInv = nullptr;
@@ -1638,8 +1584,7 @@ struct msl_sf {
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     size_t liveBound = 0;        // host-side upper bound of the live count: last synced count + nseeds per keyframe enqueued since
-    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr, *d_delStage = nullptr; unsigned long long *d_blockDone = nullptr;
-    unsigned fuseSeq = 0;        // launch stamp of k_fuse (the continuation waits until every work item carries it)
+    unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
 };
@@ -1653,7 +1598,6 @@ void set_map_ptrs(msl_sf *h) {
     M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
-    h->dev.delStage = h->d_delStage; h->dev.blockDone = h->d_blockDone;
 }
 
 int sync_all(msl_sf *h) {
@@ -1665,7 +1609,7 @@ int sync_all(msl_sf *h) {
 // (Re)allocate the resident map for `cap` surfels, preserving the first `keep` entries.
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
-    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nst = nullptr; unsigned long long *nbd = nullptr;
+    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
@@ -1674,9 +1618,6 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
-        MSL_HIP_TRY(hipMalloc(&nst, sizeof(unsigned) * cap));
-        MSL_HIP_TRY(hipMalloc(&nbd, sizeof(unsigned long long) * (cap / SUB_ITEMS + 4100)));
-        MSL_HIP_TRY(hipMemset(nbd, 0, sizeof(unsigned long long) * (cap / SUB_ITEMS + 4100)));
         if (keep && h->d_mapStore) {
             int rc = sync_all(h);
             if (rc != MSL_OK) return rc;
@@ -1692,15 +1633,12 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         if (nbu) (void)hipFree(nbu);
         if (ndl) (void)hipFree(ndl);
         if (nso) (void)hipFree(nso);
-        if (nst) (void)hipFree(nst);
-        if (nbd) (void)hipFree(nbd);
         return arc;
     }
     if (h->d_mapStore) {
         (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
-        (void)hipFree(h->d_delStage); (void)hipFree(h->d_blockDone);
     }
-    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_delStage = nst; h->d_blockDone = nbd; h->mapCap = cap;
+    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->mapCap = cap;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -1723,7 +1661,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_seedsTmp, sizeof(msl_seed) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_cand, sizeof(msl_surfel) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_candOk, ns * slots));
-    MSL_HIP_TRY(hipMalloc(&h->d_fused, sizeof(unsigned) * (size_t)D.fusedWords * FBIT_REPL * FBIT_STRIDE * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_fused, ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_index, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
@@ -1736,7 +1674,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
     MSL_HIP_TRY(hipMemset(h->d_index, 0, sizeof(unsigned short) * npx * slots));
-    MSL_HIP_TRY(hipMemset(h->d_fused, 0, sizeof(unsigned) * (size_t)D.fusedWords * FBIT_REPL * FBIT_STRIDE * slots));
+    MSL_HIP_TRY(hipMemset(h->d_fused, 0, ns * slots));
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
@@ -1750,9 +1688,6 @@ int alloc_slots(msl_sf *h, int maxBatch) {
 
 int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
-    // every host-visible accessor comes through here: materialise the lazy tail moves the last keyframe may have left pending
-    hipLaunchKernelGGL(k_flush_moves, dim3(128), dim3(256), 0, h->mapStream, h->dev);
-    hipLaunchKernelGGL(k_clear_pend, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr);
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 16, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
@@ -1765,7 +1700,6 @@ int check_err(msl_sf *h) {
         const long long e = h->h_ctr[5];
         (void)hipMemsetAsync(h->d_ctr + 5, 0, sizeof(long long), h->mapStream);
         if (e == 20) set_error("resident surfel map capacity exceeded (reserve more with msl_sf_map_reserve)");
-        else if (e == 21) set_error("surfel map stage: bounded wait for the streaming workgroups exceeded (code 21)");
         else set_error("surfel pipeline device-side bound exceeded (code %lld)", e);
         return MSL_ERR_OVERFLOW;
     }
@@ -1860,7 +1794,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     SfDev P = D;
     // shift every per-slot base so that blockIdx.y/z == 0 addresses slot0
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
-    P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.fusedWords * FBIT_REPL * FBIT_STRIDE;
+    P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
     P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.npx; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
@@ -1892,19 +1826,13 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
-    // one launch per keyframe: fuse + new surfels + refill + (lazy) tail compaction.  The grid covers the host-side upper bound
-    // of the live count (the kernel loops if the map is larger, idle workgroups only take a ticket).
+    // k_fuse's grid covers the host-side upper bound of the live count (the kernel loops if the map is larger): at 1 M surfels half
+    // of the former fixed 4096 workgroups had nothing to do
     const size_t boundLive = compact ? h->liveBound : h->mapCap;
     const unsigned fuseGrid = (unsigned)std::min<size_t>(65536, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
     for (int f = 0; f < n; f++) {
-        // 20-bit launch stamp, never 0; when it wraps the stamps of all work items are cleared so that no stale value can match
-        h->fuseSeq = (h->fuseSeq + 1) & 0xFFFFFu;
-        if (h->fuseSeq == 0) {
-            MSL_HIP_TRY(hipMemsetAsync(h->d_blockDone, 0, sizeof(unsigned long long) * (h->mapCap / SUB_ITEMS + 4100), sm));
-            h->fuseSeq = 1;
-        }
-        LAUNCH_LDS(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), sizeof(unsigned) * D.fusedWords, P, f, h->h_frames[slot0 + f], compact ? 0 : 1,
-                   h->fuseSeq);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f]);
+        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     MSL_HIP_TRY(hipGetLastError());
@@ -1928,7 +1856,6 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     SfDev &D = h->dev;
     D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;
     D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.fuseFar = fuseFar; D.fuseNear = fuseNear;
-    D.fusedWords = (D.nseeds + 31) / 32;
     bool ok = true;
     {   // the per-keyframe map stage is the latency-critical chain: highest priority for its stream, lowest for the
         // throughput-oriented frame-batched superpixel stage
@@ -1973,7 +1900,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_delStage); F(h->d_blockDone); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
@@ -2194,14 +2121,9 @@ int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {
     if (rc != MSL_OK) return rc;
     const size_t ns = h->dev.nseeds;
     MSL_HIP_TRY(hipMemcpy(out, h->d_seeds + ns * h->lastSlot, sizeof(msl_seed) * ns, hipMemcpyDeviceToHost));
-    const size_t fwords = (size_t)h->dev.fusedWords, fw = fwords * FBIT_REPL * FBIT_STRIDE;
-    std::vector<unsigned> fused(fw);
-    MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + fw * h->lastSlot, sizeof(unsigned) * fw, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < ns; i++) {
-        unsigned v = 0;
-        for (int e = 0; e < FBIT_REPL; e++) v |= fused[(e * fwords + (i >> 5)) * FBIT_STRIDE];
-        out[i].fused = (v >> (i & 31)) & 1u;
-    }
+    std::vector<uint8_t> fused(ns);
+    MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + ns * h->lastSlot, ns, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ns; i++) out[i].fused = fused[i];
     return MSL_OK;
 }
 int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {
