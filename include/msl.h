@@ -240,6 +240,45 @@ MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth
                                  int window_h, double depth_alpha, double depth_change_tol, int init_loose, double *cloud_out,
                                  msl_peac_stats *stats_out, msl_mem out_mem);
 
+/* The rest of the plane extractor: the producer of SurfelFusion's inputPlaneMembershipImg (BASELINE config 4).
+ * msl_peac_params = the members of ahc::PlaneFitter (include/peac/AHCPlaneFitter.hpp:122-131, 157-161) and ahc::ParamSet
+ * (include/peac/AHCParamSet.hpp:36-76); msl_peac_default_params fills the reference's defaults (PlaneDetection overrides none).
+ * msl_peac_block = the initial graph node of one window: its Stats plus the PCA plane fit of ahc::PlaneSeg::Stats::compute
+ * (AHCPlaneSeg.hpp:148-183: centre of mass, unit normal towards the camera, MSE, curvature; NaN MSE / curvature for N < 4), the
+ * 3x3 symmetric eigen-solve being LA::eig33sym = Eigen::SelfAdjointEigenSolver<Matrix3d> (include/peac/eig33sym.hpp:71-75).
+ * msl_peac_block_fit: cloud + block statistics + PCA on the GPU (one wave per window, FP64, the reference's summation order).
+ * msl_peac_membership_batch: PlaneDetection::readDepthImage + runPlaneDetection (src/PlaneExtractor.cpp:44-81) for n_frames
+ *   depth images: block fit on the GPU; graph initialisation (AHCPlaneFitter.hpp:756-928), agglomerative clustering (:939-1143),
+ *   block erosion (:490-596), region growing (:422-471) and the final merge / relabelling (:296-372) on the host (inherently
+ *   sequential: a priority queue of merges, a FIFO flood fill), one host thread per frame.
+ *   membership_out (HOST, [n_frames][ceil(h/2)][ceil(w/2)]) = plane_filter.membershipImg as SurfelMapping receives it
+ *   (src/Tracking.cc:228): plane id >= 0, -1 = no plane, and -- exactly like the reference -- the region-growing visit counters
+ *   -2..-6 on pixels that were tried and rejected.  n_planes_out (HOST, may be NULL) = extractedPlanes.size() per frame. */
+typedef struct msl_peac_block {
+    msl_peac_stats stats;
+    double center[3], normal[3], mse, curvature;
+} msl_peac_block;
+typedef struct msl_peac_params {
+    int32_t window_w, window_h;       /* windowWidth, windowHeight (10, 10) */
+    int32_t min_support;              /* minSupport (3000) */
+    int32_t max_step;                 /* maxStep (100000) */
+    int32_t do_refine;                /* doRefine (true) */
+    int32_t erode_type;               /* ErodeType: 0 none, 1 segment borders, 2 all borders (ERODE_ALL_BORDER) */
+    int32_t init_loose;               /* initType == INIT_LOOSE (INIT_STRICT) */
+    int32_t _pad;
+    double depth_sigma, std_tol_init, std_tol_merge;              /* depthSigma, stdTol_init, stdTol_merge */
+    double z_near, z_far, angle_near, angle_far;                  /* T_ang(P_INIT) */
+    double similarity_th_merge, similarity_th_refine;             /* cos 60 deg, cos 30 deg */
+    double depth_alpha, depth_change_tol;                         /* T_dz */
+} msl_peac_params;
+MSL_API void msl_peac_default_params(msl_peac_params *p);
+MSL_API int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
+                               int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
+                               const msl_peac_params *params, msl_peac_block *blocks_out, msl_mem out_mem);
+MSL_API int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
+                                      int height, int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                      const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
+
 /* ---- widening, SURVEY.md 8(f) rank 3: Hamming matching by projection, the next consumer of the ORB descriptors ----
  * msl_match_by_projection_batch: n_pairs independent calls of
  *     int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th)   (src/ORBmatcher.cc:547-678)

@@ -23,6 +23,11 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
                        ("g", "<i4"), ("b", "<i4"), ("fused", "u1"), ("stable", "u1"), ("use", "u1"),
                        ("_pad", "u1")])
 PEAC_STATS_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")])
+PEAC_PARAMS_DTYPE = np.dtype([(n, "<i4") for n in ("window_w", "window_h", "min_support", "max_step", "do_refine", "erode_type", "init_loose", "_pad")] +
+                             [(n, "<f8") for n in ("depth_sigma", "std_tol_init", "std_tol_merge", "z_near", "z_far", "angle_near", "angle_far",
+                                                   "similarity_th_merge", "similarity_th_refine", "depth_alpha", "depth_change_tol")])
+PEAC_BLOCK_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")] +
+                            [("center", "<f8", (3,)), ("normal", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8")])
 FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
 MATCH_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "bf", "minX", "maxX", "minY", "maxY", "th")] +
                               [("check_orientation", "<i4"), ("nlevels", "<i4"), ("scale_factors", "<f4", (16,))])
@@ -64,6 +69,9 @@ SIGNATURES = {
     "msl_sf_map_detach": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "msl_peac_default_params": (None, [_vp]),
+    "msl_peac_block_fit": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _i]),
+    "msl_peac_membership_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
     "msl_match_by_projection_batch": (_i, [_i, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),
     "msl_match_descriptor_distance": (_i, [_i, _vp, _vp, _i, _vp]),

@@ -1,10 +1,33 @@
-// organised point cloud + initial block statistics of the PEAC plane extractor on the GPU.
-// Everything is FP64 and reproduces the reference's evaluation order, so the outputs are bit-identical to the host code:
-//   cloud  : PlaneDetection::readDepthImage           (/root/reference/src/PlaneExtractor.cpp:44-76)
-//   blocks : ahc::PlaneSeg::PlaneSeg(points, ...)     (/root/reference/include/peac/AHCPlaneSeg.hpp:237-285), one block per thread
+// msl_peac.hip -- the PEAC plane extractor, producer of SurfelFusion's plane-membership image.
+//
+// Replaces PlaneDetection::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:44-81), i.e.
+// ahc::PlaneFitter<ImagePointCloud>::run (include/peac/AHCPlaneFitter.hpp:218-262) with the reference's default parameters.
+//
+//   GPU (frame-batched, FP64, bit-identical to the host arithmetic of the reference):
+//     k_peac_cloud  organised half-resolution cloud (src/PlaneExtractor.cpp:60-74), only when the caller asks for it
+//     k_peac_fit    ONE WAVE PER WINDOW: the lanes evaluate the window's points in parallel -- missing data, depth discontinuity
+//                   towards the right / lower neighbour (include/peac/AHCPlaneSeg.hpp:237-285, :41-43), the nine products of
+//                   Stats::push (:81-92) -- and stage the products in LDS; nine lanes then add one statistic each in window
+//                   raster order (the reference's summation order, so the FP64 sums are the reference's bit for bit); one lane
+//                   runs the PCA plane fit (Stats::compute, :148-183) with the 3x3 symmetric eigen-solve of
+//                   include/peac/eig33sym.hpp:71-75 (Eigen::SelfAdjointEigenSolver, restated below).
+//   Host (sequential by nature: a min-MSE priority queue of merges, a FIFO region growing), one thread per frame, index based
+//   (node pool + sorted adjacency vectors instead of shared_ptr / std::set<PlaneSeg*>):
+//     graph initialisation (AHCPlaneFitter.hpp:756-928), agglomerative clustering (:939-1143), block erosion + seeds (:490-596),
+//     region growing (:422-471), final merge and relabelling (:296-372).
+//
+// The membership image keeps every quirk a consumer can observe: rid2plid[] default-inserts plane 0 for an
+// unknown set id, pixels whose plane was eroded keep their old id, rejected pixels keep their visit counters -2..-6.
 #include "msl_common.h"
 
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <map>
 #include <mutex>
+#include <queue>
+#include <thread>
+#include <vector>
 
 namespace {
 using namespace msl;
@@ -17,17 +40,117 @@ struct PeacDev {
     int winW, winH, Nw, Nh, loose;
     double alpha, tol;
     double *cloud;                         // [frames][ch * cw][3] or nullptr
-    msl_peac_stats *stats;                 // [frames][Nh * Nw]
+    msl_peac_block *blocks;                // [frames][Nh * Nw]
 };
 
-// z of cloud vertex (row, col): (double)depth(2 row, 2 col) * depthMapFactor (src/PlaneExtractor.cpp:64)
-__device__ __forceinline__ double vertex_z(const PeacDev &P, const uint16_t *img, int row, int col) {
-    const uint16_t d = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(img) + (size_t)(2 * row) * P.strideBytes + 2 * (2 * col));
-    return (double)d * P.factor;
+// ---- arithmetic shared by the device kernel and the host clustering (same expressions, IEEE double, no FMA contraction) ----
+__host__ __device__ inline double hypot_pos(double x, double y) {   // Eigen::numext::hypot
+    const double ax = fabs(x), ay = fabs(y);
+    double p, qp;
+    if (ax > ay) { p = ax; qp = ay / p; } else { p = ay; qp = ax / p; }
+    if (p == 0) return 0;
+    return p * sqrt(1.0 + qp * qp);
 }
-__device__ __forceinline__ void vertex_xy(const PeacDev &P, int row, int col, double z, double &x, double &y) {
-    x = ((double)(2 * col) - P.cx) * z / P.fx;   // :69
-    y = ((double)(2 * row) - P.cy) * z / P.fy;   // :70
+
+// Eigen::SelfAdjointEigenSolver<Matrix3d>::compute as LA::eig33sym uses it: s[0] <= s[1] <= s[2], V[:][i] the eigenvector of s[i].
+// (lower triangle scaled by its largest coefficient, closed-form 3x3 Householder tridiagonalisation, implicit symmetric QR with
+// Wilkinson shift and the 2-epsilon deflation test, eigenvalues sorted increasingly with their vectors)
+__host__ __device__ inline void eig33sym(const double K[3][3], double s[3], double V[3][3]) {
+    double a00 = K[0][0], a10 = K[1][0], a11 = K[1][1], a20 = K[2][0], a21 = K[2][1], a22 = K[2][2];
+    double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
+    if (scale == 0) scale = 1;
+    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
+    double d0 = a00, d1, d2, e0, e1;
+    double q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    const double tiny = 2.2250738585072014e-308;   // std::numeric_limits<double>::min()
+    const double v1norm2 = a20 * a20;
+    if (v1norm2 <= tiny) {
+        d1 = a11; d2 = a22; e0 = a10; e1 = a21;
+    } else {
+        const double beta = sqrt(a10 * a10 + v1norm2);
+        const double invBeta = 1.0 / beta;
+        const double m01 = a10 * invBeta, m02 = a20 * invBeta;
+        const double qq = 2.0 * m01 * a21 + m02 * (a22 - a11);
+        d1 = a11 + m02 * qq; d2 = a22 - m02 * qq;
+        e0 = beta; e1 = a21 - m01 * qq;
+        q[1][1] = m01; q[1][2] = m02; q[2][1] = m02; q[2][2] = -m01;
+    }
+    double dg[3] = {d0, d1, d2}, sb[2] = {e0, e1};
+    int end = 2, start = 0, iter = 0;
+    const double precision = 2.0 * 2.220446049250313e-16;
+    while (end > 0) {
+        for (int i = start; i < end; ++i)
+            if (fabs(sb[i]) <= (fabs(dg[i]) + fabs(dg[i + 1])) * precision || fabs(sb[i]) <= tiny) sb[i] = 0;
+        while (end > 0 && sb[end - 1] == 0.0) end--;
+        if (end <= 0) break;
+        if (++iter > 30 * 3) break;
+        start = end - 1;
+        while (start > 0 && sb[start - 1] != 0) start--;
+        const double td = (dg[end - 1] - dg[end]) * 0.5, e = sb[end - 1];
+        double mu = dg[end];
+        if (td == 0.0) mu -= fabs(e);
+        else if (e != 0.0) {
+            const double e2 = e * e, h = hypot_pos(td, e);
+            if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? h : -h)) / e);
+            else mu -= e2 / (td + (td > 0.0 ? h : -h));
+        }
+        double x = dg[start] - mu, z = sb[start];
+        for (int k = start; k < end && z != 0.0; ++k) {
+            double c, sn;   // Givens rotation that annihilates z against x
+            if (x == 0.0) { c = 0.0; sn = z < 0.0 ? 1.0 : -1.0; }
+            else if (fabs(x) > fabs(z)) { const double t = z / x; double u = sqrt(1.0 + t * t); if (x < 0.0) u = -u; c = 1.0 / u; sn = -t * c; }
+            else { const double t = x / z; double u = sqrt(1.0 + t * t); if (z < 0.0) u = -u; sn = -1.0 / u; c = -t * sn; }
+            const double sdk = sn * dg[k] + c * sb[k];
+            const double dkp1 = sn * sb[k] + c * dg[k + 1];
+            dg[k] = c * (c * dg[k] - sn * sb[k]) - sn * (c * sb[k] - sn * dg[k + 1]);
+            dg[k + 1] = sn * sdk + c * dkp1;
+            sb[k] = c * sdk - sn * dkp1;
+            if (k > start) sb[k - 1] = c * sb[k - 1] - sn * z;
+            x = sb[k];
+            if (k < end - 1) { z = -sn * sb[k + 1]; sb[k + 1] = c * sb[k + 1]; }
+            for (int r = 0; r < 3; r++) {
+                const double xi = q[r][k], yi = q[r][k + 1];
+                q[r][k] = c * xi - sn * yi;
+                q[r][k + 1] = sn * xi + c * yi;
+            }
+        }
+    }
+    for (int i = 0; i < 2; ++i) {   // selection sort, columns follow
+        int k = 0;
+        for (int j = 1; j < 3 - i; j++) if (dg[i + j] < dg[i + k]) k = j;
+        if (k > 0) {
+            const double t = dg[i]; dg[i] = dg[k + i]; dg[k + i] = t;
+            for (int r = 0; r < 3; r++) { const double u = q[r][i]; q[r][i] = q[r][k + i]; q[r][k + i] = u; }
+        }
+    }
+    for (int i = 0; i < 3; i++) s[i] = dg[i] * scale;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) V[r][c] = q[r][c];
+}
+
+// ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183)
+__host__ __device__ inline void plane_fit(const msl_peac_stats &st, double center[3], double normal[3], double &mse, double &curvature) {
+    const double sc = ((double)1.0) / st.N;
+    center[0] = st.sx * sc; center[1] = st.sy * sc; center[2] = st.sz * sc;
+    double K[3][3] = {{st.sxx - st.sx * st.sx * sc, st.sxy - st.sx * st.sy * sc, st.sxz - st.sx * st.sz * sc},
+                      {0, st.syy - st.sy * st.sy * sc, st.syz - st.sy * st.sz * sc},
+                      {0, 0, st.szz - st.sz * st.sz * sc}};
+    K[1][0] = K[0][1]; K[2][0] = K[0][2]; K[2][1] = K[1][2];
+    double sv[3], V[3][3];
+    eig33sym(K, sv, V);
+    const double sgn = (V[0][0] * center[0] + V[1][0] * center[1] + V[2][0] * center[2] <= 0) ? 1.0 : -1.0;   // normal towards the camera
+    normal[0] = sgn > 0 ? V[0][0] : -V[0][0]; normal[1] = sgn > 0 ? V[1][0] : -V[1][0]; normal[2] = sgn > 0 ? V[2][0] : -V[2][0];
+    mse = sv[0] * sc;
+    curvature = sv[0] / (sv[0] + sv[1] + sv[2]);
+}
+
+// z of cloud vertex (row, col): (double)depth(2 row, 2 col) * depthMapFactor (src/PlaneExtractor.cpp:64)
+__host__ __device__ inline double vertex_z(const uint16_t *img, size_t strideBytes, float factor, int row, int col) {
+    const uint16_t d = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(img) + (size_t)(2 * row) * strideBytes + 2 * (size_t)(2 * col));
+    return (double)d * factor;
+}
+__host__ __device__ inline void vertex_xy(float fx, float fy, float cx, float cy, int row, int col, double z, double &x, double &y) {
+    x = ((double)(2 * col) - cx) * z / fx;   // :69
+    y = ((double)(2 * row) - cy) * z / fy;   // :70
 }
 
 __global__ __launch_bounds__(256) void k_peac_cloud(PeacDev P) {
@@ -36,128 +159,501 @@ __global__ __launch_bounds__(256) void k_peac_cloud(PeacDev P) {
     if (i >= P.cw * P.ch) return;
     const int row = i / P.cw, col = i - row * P.cw;
     const uint16_t *img = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P.depth) + (size_t)frame * P.frameStrideBytes);
-    const double z = vertex_z(P, img, row, col);
+    const double z = vertex_z(img, P.strideBytes, P.factor, row, col);
     double x, y;
-    vertex_xy(P, row, col, z, x, y);
+    vertex_xy(P.fx, P.fy, P.cx, P.cy, row, col, z, x, y);
     double *o = P.cloud + ((size_t)frame * P.cw * P.ch + i) * 3;
     o[0] = x; o[1] = y; o[2] = z;
 }
 
-// ImagePointCloud::get (include/PlaneExtractor.h:47-55): z == 0 is missing data (a 16-bit depth times a float is never NaN)
-__device__ __forceinline__ bool cloud_get(const PeacDev &P, const uint16_t *img, int row, int col, double &x, double &y, double &z) {
-    z = vertex_z(P, img, row, col);
-    if (z == 0) return false;
-    vertex_xy(P, row, col, z, x, y);
-    return true;
-}
-__device__ __forceinline__ bool depth_discontinuous(const PeacDev &P, double d0, double d1) {   // AHCPlaneSeg.hpp:41-43
-    return fabs(d0 - d1) > P.alpha * fabs(d0) + P.tol;
-}
-
-__global__ __launch_bounds__(64) void k_peac_blocks(PeacDev P) {
-    const int frame = blockIdx.y;
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= P.Nw * P.Nh) return;
+// One wave per window.  LDS: nine arrays of winW * winH products (a missing point contributes +0.0, which leaves every partial
+// sum unchanged, so the additions that matter happen in the reference's raster order).
+__global__ __launch_bounds__(64) void k_peac_fit(PeacDev P) {
+    extern __shared__ double s_term[];   // [9][win]
+    const int frame = blockIdx.y, b = blockIdx.x, lane = threadIdx.x;
     const uint16_t *img = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P.depth) + (size_t)frame * P.frameStrideBytes);
-    const int seedRow = (b / P.Nw) * P.winH, seedCol = (b % P.Nw) * P.winW;
-    msl_peac_stats S;
-    S.sx = S.sy = S.sz = S.sxx = S.syy = S.szz = S.sxy = S.syz = S.sxz = 0; S.N = 0; S.nouse = 0;
-    bool windowValid = true;
-    int nanCnt = 0;
-    const int nanCntTh = P.winH * P.winW / 2;
-    for (int i = seedRow, icnt = 0; icnt < P.winH && i < P.ch; ++i, ++icnt) {
-        for (int j = seedCol, jcnt = 0; jcnt < P.winW && j < P.cw; ++j, ++jcnt) {
-            double x = 0, y = 0, z = 10000;
-            if (!cloud_get(P, img, i, j, x, y, z)) {
-                if (P.loose) {
-                    ++nanCnt;
-                    if (nanCnt < nanCntTh) continue;
-                }
-                windowValid = false;
-                break;
-            }
-            double xn = 0, yn = 0, zn = 10000;
-            if (j + 1 < P.cw && (cloud_get(P, img, i, j + 1, xn, yn, zn) && depth_discontinuous(P, z, zn))) { windowValid = false; break; }
-            if (i + 1 < P.ch && (cloud_get(P, img, i + 1, j, xn, yn, zn) && depth_discontinuous(P, z, zn))) { windowValid = false; break; }
-            S.sx += x; S.sy += y; S.sz += z;                       // Stats::push (:81-92)
-            S.sxx += x * x; S.syy += y * y; S.szz += z * z;
-            S.sxy += x * y; S.syz += y * z; S.sxz += x * z;
-            ++S.N;
+    const int seedRow = (b / P.Nw) * P.winH, seedCol = (b % P.Nw) * P.winW, win = P.winW * P.winH;
+    int nMissing = 0, nPushed = 0;
+    bool broken = false;   // a valid point with a depth discontinuity towards its right / lower neighbour
+    for (int p = lane; p < win; p += 64) {
+        const int i = seedRow + p / P.winW, j = seedCol + p % P.winW;
+        const double z = vertex_z(img, P.strideBytes, P.factor, i, j);
+        double x = 0, y = 0;
+        const bool has = z != 0;   // ImagePointCloud::get (include/PlaneExtractor.h:47-55): a 16-bit depth times a float is never NaN
+        if (has) {
+            vertex_xy(P.fx, P.fy, P.cx, P.cy, i, j, z, x, y);
+            if (j + 1 < P.cw) { const double zn = vertex_z(img, P.strideBytes, P.factor, i, j + 1); if (zn != 0 && fabs(z - zn) > P.alpha * fabs(z) + P.tol) broken = true; }
+            if (i + 1 < P.ch) { const double zn = vertex_z(img, P.strideBytes, P.factor, i + 1, j); if (zn != 0 && fabs(z - zn) > P.alpha * fabs(z) + P.tol) broken = true; }
+            nPushed++;
+        } else {
+            nMissing++;
         }
-        if (!windowValid) break;
+        const double zz = has ? z : 0.0;
+        s_term[0 * win + p] = x; s_term[1 * win + p] = y; s_term[2 * win + p] = zz;
+        s_term[3 * win + p] = x * x; s_term[4 * win + p] = y * y; s_term[5 * win + p] = zz * zz;
+        s_term[6 * win + p] = x * y; s_term[7 * win + p] = y * zz; s_term[8 * win + p] = x * zz;
     }
-    if (!windowValid) { S.sx = S.sy = S.sz = S.sxx = S.syy = S.szz = S.sxy = S.syz = S.sxz = 0; S.N = 0; S.nouse = 1; }
-    P.stats[(size_t)frame * P.Nw * P.Nh + b] = S;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { nMissing += __shfl_xor(nMissing, d, 64); nPushed += __shfl_xor(nPushed, d, 64); }
+    // INIT_STRICT: any missing point rejects the window; INIT_LOOSE: the nanCntTh-th missing point does (AHCPlaneSeg.hpp:245-257)
+    const bool valid = !__any(broken) && (P.loose ? nMissing < win / 2 : nMissing == 0);
+    __builtin_amdgcn_wave_barrier();
+    double sum = 0.0;
+    if (valid && lane < 9) {
+        const double *t = s_term + lane * win;
+        for (int p = 0; p < win; p++) sum += t[p];   // Stats::push order (:81-92)
+    }
+    msl_peac_stats S;
+    S.sx = __shfl(sum, 0, 64); S.sy = __shfl(sum, 1, 64); S.sz = __shfl(sum, 2, 64);
+    S.sxx = __shfl(sum, 3, 64); S.syy = __shfl(sum, 4, 64); S.szz = __shfl(sum, 5, 64);
+    S.sxy = __shfl(sum, 6, 64); S.syz = __shfl(sum, 7, 64); S.sxz = __shfl(sum, 8, 64);
+    S.N = valid ? nPushed : 0; S.nouse = valid ? 0 : 1;
+    if (lane != 0) return;
+    msl_peac_block B;
+    B.stats = S;
+    B.center[0] = B.center[1] = B.center[2] = B.normal[0] = B.normal[1] = B.normal[2] = 0;
+    if (S.N < 4) B.mse = B.curvature = __longlong_as_double(0x7FF8000000000000ll);   // quiet NaN (:279-280)
+    else plane_fit(S, B.center, B.normal, B.mse, B.curvature);
+    P.blocks[(size_t)frame * P.Nw * P.Nh + b] = B;
 }
 
-struct Scratch { void *depth = nullptr, *stats = nullptr, *cloud = nullptr; size_t depthCap = 0, statsCap = 0, cloudCap = 0; };
+// ---- host side: agglomerative clustering over the block graph -----------------------------------------------------------------
+struct Thresholds {
+    msl_peac_params p;
+    double t_mse_init(double z) const { return std::pow(p.depth_sigma * z * z + p.std_tol_init, 2); }     // ParamSet::T_mse (AHCParamSet.hpp:87-99)
+    double t_mse_merge(double z) const { return std::pow(p.depth_sigma * z * z + p.std_tol_merge, 2); }
+    double t_ang_init(double z) const {                                                                   // ParamSet::T_ang (:111-131)
+        double clipped_z = z;
+        clipped_z = std::max(clipped_z, p.z_near);
+        clipped_z = std::min(clipped_z, p.z_far);
+        const double factor = (p.angle_far - p.angle_near) / (p.z_far - p.z_near);
+        return std::cos(factor * clipped_z + p.angle_near - factor * p.z_near);
+    }
+};
+
+struct Node {
+    msl_peac_stats st;
+    double center[3], normal[3], mse, curvature;
+    int N, rid;
+    bool nouse;
+    std::vector<int> nbs;   // adjacent node ids, ascending (= the reference's std::set<PlaneSeg*> with addresses pinned to creation order)
+};
+
+class FrameSegmenter {
+public:
+    FrameSegmenter(const msl_peac_params &prm, const uint16_t *img, size_t strideBytes, int cw, int ch, float fx, float fy, float cx, float cy, float factor)
+        : T{prm}, img_(img), stride_(strideBytes), W(cw), H(ch), fx_(fx), fy_(fy), cx_(cx), cy_(cy), factor_(factor), winW(prm.window_w),
+          winH(prm.window_h), Nw(cw / prm.window_w), Nh(ch / prm.window_h) {}
+
+    // returns the number of extracted planes; member[H * W] receives PlaneFitter::membershipImg
+    int run(const msl_peac_block *blocks, int32_t *member) {
+        parent_.resize((size_t)Nw * Nh); setSize_.assign((size_t)Nw * Nh, 1);
+        for (size_t i = 0; i < parent_.size(); i++) parent_[i] = (int)i;
+        nodes_.clear(); nodes_.reserve((size_t)Nw * Nh * 2);
+        Heap heap{MseGreater{this}};
+        build_graph(blocks, heap);
+        cluster(heap);
+        member_ = member;
+        std::fill(member, member + (size_t)W * H, -1);
+        if (T.p.do_refine) refine();
+        return (int)planes_.size();
+    }
+
+private:
+    struct MseGreater {   // PlaneSegMinMSECmp: the queue's top is the node with the smallest MSE
+        const FrameSegmenter *f;
+        bool operator()(int a, int b) const { return f->nodes_[b].mse < f->nodes_[a].mse; }
+    };
+    typedef std::priority_queue<int, std::vector<int>, MseGreater> Heap;
+
+    Thresholds T;
+    const uint16_t *img_; size_t stride_;
+    int W, H; float fx_, fy_, cx_, cy_, factor_;
+    int winW, winH, Nw, Nh;
+    std::vector<Node> nodes_;
+    std::vector<int> parent_, setSize_;       // disjoint set over the windows (DisjointSet.hpp)
+    std::vector<int> planes_;                 // extractedPlanes, node ids
+    std::vector<int> blkMap_;
+    std::vector<std::pair<int, int>> growQ_;  // rfQueue: (pixel, plane)
+    int32_t *member_ = nullptr;
+
+    int find(int x) { while (parent_[x] != x) { parent_[x] = parent_[parent_[x]]; x = parent_[x]; } return x; }   // (path halving: same roots as Find())
+    void unite(int x, int y) {
+        const int xr = find(x), yr = find(y);
+        if (xr == yr) return;
+        if (setSize_[xr] < setSize_[yr]) { parent_[xr] = yr; setSize_[yr] += setSize_[xr]; }
+        else { parent_[yr] = xr; setSize_[xr] += setSize_[yr]; }
+    }
+    static double similarity(const Node &a, const Node &b) { return std::abs(a.normal[0] * b.normal[0] + a.normal[1] * b.normal[1] + a.normal[2] * b.normal[2]); }
+    static void link_one(std::vector<int> &v, int id) { auto it = std::lower_bound(v.begin(), v.end(), id); if (it == v.end() || *it != id) v.insert(it, id); }
+    static void unlink_one(std::vector<int> &v, int id) { auto it = std::lower_bound(v.begin(), v.end(), id); if (it != v.end() && *it == id) v.erase(it); }
+    void connect(int a, int b) { link_one(nodes_[a].nbs, b); link_one(nodes_[b].nbs, a); }
+    void isolate(int a) { for (int nb : nodes_[a].nbs) unlink_one(nodes_[nb].nbs, a); nodes_[a].nbs.clear(); }
+
+    void build_graph(const msl_peac_block *blocks, Heap &heap) {
+        std::vector<int> G((size_t)Nw * Nh, -1);   // node id of an accepted window
+        for (int b = 0; b < Nw * Nh; b++) {
+            const msl_peac_block &B = blocks[b];
+            Node nd;
+            nd.st = B.stats; nd.mse = B.mse; nd.curvature = B.curvature; nd.rid = b; nd.nouse = B.stats.nouse != 0; nd.N = nd.nouse ? 0 : B.stats.N;
+            for (int k = 0; k < 3; k++) { nd.center[k] = B.center[k]; nd.normal[k] = B.normal[k]; }
+            nodes_.push_back(nd);
+            if (nd.mse < T.t_mse_init(nd.center[2]) && !nd.nouse) { G[b] = b; heap.push(b); }
+        }
+        // edges between horizontally / vertically adjacent accepted windows whose two outer neighbours agree in normal (:849-927)
+        auto sweep = [&](int outerN, int innerN, int outerStride, int innerStride) {
+            for (int o = 0; o < outerN; ++o)
+                for (int k = 1; k < innerN; k += 2) {
+                    const int c = o * outerStride + k * innerStride, prev = c - innerStride, next = c + innerStride;
+                    if (G[prev] < 0) { --k; continue; }
+                    if (G[c] < 0) continue;
+                    if (k < innerN - 1 && G[next] < 0) { ++k; continue; }
+                    const double th = T.t_ang_init(nodes_[G[c]].center[2]);
+                    const bool ok = k < innerN - 1 ? similarity(nodes_[G[prev]], nodes_[G[next]]) >= th : similarity(nodes_[G[c]], nodes_[G[prev]]) >= th;
+                    if (ok) { connect(G[c], G[prev]); if (k < innerN - 1) connect(G[c], G[next]); }
+                    else --k;
+                }
+        };
+        sweep(Nh, Nw, Nw, 1);
+        sweep(Nw, Nh, 1, Nw);
+    }
+
+    Node merged_node(int a, int b) const {   // PlaneSeg(pa, pb) (AHCPlaneSeg.hpp:299-322)
+        Node nd;
+        const msl_peac_stats &x = nodes_[a].st, &y = nodes_[b].st;
+        nd.st.sx = x.sx + y.sx; nd.st.sy = x.sy + y.sy; nd.st.sz = x.sz + y.sz; nd.st.sxx = x.sxx + y.sxx; nd.st.syy = x.syy + y.syy; nd.st.szz = x.szz + y.szz;
+        nd.st.sxy = x.sxy + y.sxy; nd.st.syz = x.syz + y.syz; nd.st.sxz = x.sxz + y.sxz; nd.st.N = x.N + y.N; nd.st.nouse = 0;
+        nd.nouse = false;
+        nd.rid = nodes_[a].N >= nodes_[b].N ? nodes_[a].rid : nodes_[b].rid;
+        nd.N = nd.st.N;
+        plane_fit(nd.st, nd.center, nd.normal, nd.mse, nd.curvature);
+        return nd;
+    }
+
+    void cluster(Heap &heap) {   // ahCluster (:939-1143)
+        int step = 0;
+        while (!heap.empty() && step <= T.p.max_step) {
+            const int p = heap.top();
+            heap.pop();
+            if (nodes_[p].nouse) continue;
+            // try to merge with every neighbour (ascending id), keep the merge with the smallest MSE
+            bool have = false;
+            Node best;
+            int bestNb = -1;
+            for (int nb : nodes_[p].nbs) {
+                if (similarity(nodes_[p], nodes_[nb]) < T.p.similarity_th_merge) continue;
+                const Node m = merged_node(p, nb);
+                if (!have || best.mse > m.mse || (best.mse == m.mse && best.N < m.mse)) { best = m; bestNb = nb; have = true; }   // (sic: N against mse, :1005)
+            }
+            if (have && best.mse < T.t_mse_merge(best.center[2])) {
+                nodes_.push_back(best);
+                const int id = (int)nodes_.size() - 1;   // accepted merges get ascending ids: the newest node sorts last among neighbours
+                heap.push(id);
+                // mergeNbsFrom (AHCPlaneSeg.hpp:398-436)
+                unite(nodes_[p].rid, nodes_[bestNb].rid);
+                std::vector<int> u;
+                std::set_union(nodes_[p].nbs.begin(), nodes_[p].nbs.end(), nodes_[bestNb].nbs.begin(), nodes_[bestNb].nbs.end(), std::back_inserter(u));
+                unlink_one(u, p); unlink_one(u, bestNb);
+                isolate(p); isolate(bestNb);
+                for (int nb : u) link_one(nodes_[nb].nbs, id);
+                nodes_[id].nbs.swap(u);
+                nodes_[p].nouse = nodes_[bestNb].nouse = true;
+            } else {
+                if (nodes_[p].N >= T.p.min_support) planes_.push_back(p);
+                isolate(p);
+            }
+            ++step;
+        }
+        while (!heap.empty()) {
+            const int p = heap.top();
+            heap.pop();
+            if (nodes_[p].N >= T.p.min_support) planes_.push_back(p);
+            isolate(p);
+        }
+        std::sort(planes_.begin(), planes_.end(), [this](int a, int b) { return nodes_[b].N < nodes_[a].N; });   // PlaneSegSizeCmp
+    }
+
+    bool point(int row, int col, double pt[3]) const {   // ImagePointCloud::get on the fly
+        const double z = vertex_z(img_, stride_, factor_, row, col);
+        pt[2] = z;
+        if (z == 0) return false;
+        vertex_xy(fx_, fy_, cx_, cy_, row, col, z, pt[0], pt[1]);
+        return true;
+    }
+    static int neighbours4(int i, int j, int Hh, int Ww, int nbs[4]) {
+        const int id = i * Ww + j;
+        int cnt = 0;
+        if (j > 0) nbs[cnt++] = id - 1;
+        if (j < Ww - 1) nbs[cnt++] = id + 1;
+        if (i > 0) nbs[cnt++] = id - Ww;
+        if (i < Hh - 1) nbs[cnt++] = id + Ww;
+        return cnt;
+    }
+
+    void erode_blocks(std::vector<char> &validPlane) {   // findBlockMembership(isValidExtractedPlane) (:490-596)
+        std::map<int, int> rid2plid;
+        for (int plid = 0; plid < (int)planes_.size(); ++plid) rid2plid.insert(std::make_pair(nodes_[planes_[plid]].rid, plid));
+        const int perBlk = winW * winH;
+        blkMap_.assign((size_t)Nw * Nh, -1);
+        validPlane.assign(planes_.size(), 0);
+        for (int i = 0, blk = 0; i < Nh; ++i)
+            for (int j = 0; j < Nw; ++j, ++blk) {
+                const int setid = find(blk);
+                if (setSize_[setid] * perBlk >= T.p.min_support) {
+                    int nb4[4] = {-1, -1, -1, -1};
+                    const int nNb = neighbours4(i, j, Nh, Nw, nb4);
+                    bool interior = true;
+                    for (int k = 0; k < nNb && T.p.erode_type != 0; ++k)
+                        if (find(nb4[k]) != setid && (T.p.erode_type == 2 || setSize_[find(nb4[k])] * perBlk >= T.p.min_support)) { interior = false; break; }
+                    const int plid = rid2plid[setid];   // default-inserts plane 0 for a set whose root is no extracted plane's rid, as the reference does
+                    if (interior) {
+                        blkMap_[blk] = plid;
+                        for (int y = i * winH; y < (i + 1) * winH; y++) std::fill(member_ + (size_t)y * W + j * winW, member_ + (size_t)y * W + (j + 1) * winW, plid);
+                        validPlane[plid] = 1;
+                    }
+                }
+                // seeds of the region growing: the pixels of a plane window that face a window of another (or no) plane
+                if (blkMap_[blk] < 0) {
+                    if (i > 0 && blkMap_[blk - Nw] >= 0)
+                        for (int k = 1; k < winW; ++k) growQ_.push_back(std::make_pair((i * winH - 1) * W + j * winW + k, blkMap_[blk - Nw]));
+                    if (j > 0 && blkMap_[blk - 1] >= 0)
+                        for (int k = 0; k < winH - 1; ++k) growQ_.push_back(std::make_pair((i * winH) * W + j * winW - 1 + k * W, blkMap_[blk - 1]));
+                } else {
+                    const int plid = blkMap_[blk];
+                    if (i > 0 && blkMap_[blk - Nw] != plid)
+                        for (int k = 0; k < winW - 1; ++k) growQ_.push_back(std::make_pair((i * winH) * W + j * winW + k, plid));
+                    if (j > 0 && blkMap_[blk - 1] != plid)
+                        for (int k = 1; k < winH; ++k) growQ_.push_back(std::make_pair((i * winH) * W + j * winW + k * W, plid));
+                }
+            }
+    }
+
+    void grow_regions() {   // floodFill (:422-471)
+        std::vector<float> distMap((size_t)H * W, std::numeric_limits<float>::max());
+        for (size_t k = 0; k < growQ_.size(); ++k) {
+            const int seed = growQ_[k].first, plid = growQ_[k].second;
+            const int sy = seed / W, sx = seed - sy * W;
+            const Node &pl = nodes_[planes_[plid]];
+            int nb4[4] = {-1, -1, -1, -1};
+            const int nNb = neighbours4(sy, sx, H, W, nb4);
+            for (int t = 0; t < nNb; ++t) {
+                const int c = nb4[t];
+                int32_t &trail = member_[c];
+                if (trail <= -6) continue;
+                if (trail >= 0 && trail == plid) continue;
+                const int cy = c / W, cx = c - cy * W;
+                const int by = cy / winH, bx = cx / winW;
+                if (by < Nh && bx < Nw && blkMap_[by * Nw + bx] >= 0) continue;   // only pixels outside the plane windows
+                double pt[3] = {0, 0, 0};
+                float cdist = -1;
+                bool close = false;
+                if (point(cy, cx, pt)) {
+                    cdist = (float)std::abs(pl.normal[0] * (pt[0] - pl.center[0]) + pl.normal[1] * (pt[1] - pl.center[1]) + pl.normal[2] * (pt[2] - pl.center[2]));
+                    close = std::pow(cdist, 2) < 9 * pl.mse + 1e-5;   // point-plane distance within 3 sigma
+                }
+                if (close) {
+                    if (trail >= 0 && similarity(pl, nodes_[planes_[trail]]) >= T.p.similarity_th_refine) connect(planes_[trail], planes_[plid]);
+                    float &old = distMap[c];
+                    if (cdist < old) { trail = plid; old = cdist; growQ_.push_back(std::make_pair(c, plid)); }
+                    else if (trail < 0) trail -= 1;
+                } else if (trail < 0) {
+                    trail -= 1;
+                }
+            }
+        }
+    }
+
+    void refine() {   // refineDetails (:296-372)
+        std::vector<char> validPlane;
+        erode_blocks(validPlane);
+        grow_regions();
+        const std::vector<int> old = planes_;
+        planes_.clear();
+        Heap heap{MseGreater{this}};
+        for (size_t i = 0; i < old.size(); ++i)
+            if (validPlane[i]) heap.push(old[i]);
+        cluster(heap);
+        std::vector<int> relabel(old.size(), -1);
+        for (size_t i = 0; i < old.size(); ++i) {
+            if (!validPlane[i]) continue;
+            const int root = find(nodes_[old[i]].rid);
+            for (size_t j = 0; j < planes_.size(); ++j)
+                if (root == nodes_[planes_[j]].rid) { relabel[i] = (int)j; break; }
+        }
+        for (size_t i = 0, nPx = (size_t)W * H; i < nPx; ++i) {
+            int32_t &plid = member_[i];
+            if (plid >= 0 && relabel[plid] >= 0) plid = relabel[plid];   // anything else keeps its value (old id or visit counter), as in the reference
+        }
+    }
+};
+
+struct Scratch { void *depth = nullptr, *blocks = nullptr, *cloud = nullptr; size_t depthCap = 0, blocksCap = 0, cloudCap = 0; };
 Scratch g_scratch[16];
 std::mutex g_scratchMutex;
 
-}  // namespace
+hipError_t grow(void *&p, size_t &cap, size_t need) {
+    if (need <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    const hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess) cap = need;
+    return e;
+}
 
-extern "C" {
+#define PEAC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_peac: %s", hipGetErrorString(e_)); return MSL_ERR_HIP; } } while (0)
 
-int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
-                         int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, int window_w,
-                         int window_h, double depth_alpha, double depth_change_tol, int init_loose, double *cloud_out,
-                         msl_peac_stats *stats_out, msl_mem out_mem) {
-    if (!depth || !stats_out || width < 2 || height < 2 || n_frames < 1 || window_w < 1 || window_h < 1 || depth_stride_bytes < (size_t)width * 2 ||
-        (n_frames > 1 && frame_stride_bytes < depth_stride_bytes * (size_t)height) || fx == 0 || fy == 0) {
-        set_error("msl_peac_block_stats: invalid argument");
+// cloud (optional) + block fit for n_frames images; dBlocksOut receives the device pointer of the [frames][Nh * Nw] blocks.
+// The caller holds g_scratchMutex.
+int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t frameStrideBytes, int width, int height, int n_frames, msl_mem mem, float fx,
+               float fy, float cx, float cy, float factor, const msl_peac_params &prm, double *cloudDev, msl_peac_block **dBlocksOut, const uint16_t **dDepthOut,
+               size_t *dFrameStride, msl_peac_block *blocksUser /* device output buffer or nullptr */) {
+    if (!depth || width < 2 || height < 2 || n_frames < 1 || prm.window_w < 1 || prm.window_h < 1 || prm.window_w * prm.window_h > 4096 ||
+        strideBytes < (size_t)width * 2 || (n_frames > 1 && frameStrideBytes < strideBytes * (size_t)(height - 1) + (size_t)width * 2) || fx == 0 || fy == 0) {
+        set_error("msl_peac: invalid argument");
         return MSL_ERR_INVALID;
     }
     int rc = bind_device(device);
     if (rc != MSL_OK) return rc;
     PeacDev P;
     P.width = width; P.height = height; P.cw = (width + 1) / 2; P.ch = (height + 1) / 2;   // ceil(cols / 2.0), ceil(rows / 2.0) (:51-52)
-    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.factor = depth_map_factor;
-    P.winW = window_w; P.winH = window_h; P.Nw = P.cw / window_w; P.Nh = P.ch / window_h; P.loose = init_loose ? 1 : 0;
-    P.alpha = depth_alpha; P.tol = depth_change_tol;
-    P.strideBytes = depth_stride_bytes; P.frameStrideBytes = frame_stride_bytes;
+    P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.factor = factor;
+    P.winW = prm.window_w; P.winH = prm.window_h; P.Nw = P.cw / prm.window_w; P.Nh = P.ch / prm.window_h; P.loose = prm.init_loose ? 1 : 0;
+    P.alpha = prm.depth_alpha; P.tol = prm.depth_change_tol;
+    P.strideBytes = strideBytes; P.frameStrideBytes = frameStrideBytes;
     const size_t nBlocks = (size_t)P.Nw * P.Nh, nVert = (size_t)P.cw * P.ch;
-    if (nBlocks == 0) { set_error("msl_peac_block_stats: image smaller than one block"); return MSL_ERR_INVALID; }
-    // staging buffers for host-memory calls: cached per device (grow-only), so a per-frame caller pays no hipMalloc
-    uint16_t *dDepth = nullptr; double *dCloud = nullptr; msl_peac_stats *dStats = nullptr;
-#define PEAC_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_peac_block_stats: %s", hipGetErrorString(e_)); return MSL_ERR_HIP; } } while (0)
-    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (nBlocks == 0) { set_error("msl_peac: image smaller than one window"); return MSL_ERR_INVALID; }
     Scratch &sc = g_scratch[device & 15];
-    auto grow = [&](void *&p, size_t &cap, size_t need) -> hipError_t {
-        if (need <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        const hipError_t e = hipMalloc(&p, need);
-        if (e == hipSuccess) cap = need;
-        return e;
-    };
     if (mem == MSL_MEM_HOST) {
-        const size_t frameBytes = depth_stride_bytes * (size_t)height;
-        PEAC_TRY(grow(sc.depth, sc.depthCap, frameBytes * n_frames));
-        dDepth = (uint16_t *)sc.depth;
+        // bytes actually present in the caller's buffer: the last row carries no stride padding
+        const size_t frameBytes = strideBytes * (size_t)(height - 1) + (size_t)width * 2, slot = (frameBytes + 255) & ~(size_t)255;
+        PEAC_TRY(grow(sc.depth, sc.depthCap, slot * n_frames));
         for (int f = 0; f < n_frames; f++)
-            PEAC_TRY(hipMemcpy((uint8_t *)dDepth + f * frameBytes, (const uint8_t *)depth + f * frame_stride_bytes, frameBytes, hipMemcpyHostToDevice));
-        P.depth = dDepth; P.frameStrideBytes = frameBytes;
+            PEAC_TRY(hipMemcpyAsync((uint8_t *)sc.depth + f * slot, (const uint8_t *)depth + f * frameStrideBytes, frameBytes, hipMemcpyHostToDevice, 0));
+        P.depth = (const uint16_t *)sc.depth; P.frameStrideBytes = slot;
     } else {
         P.depth = depth;
     }
-    if (out_mem == MSL_MEM_HOST) {
-        PEAC_TRY(grow(sc.stats, sc.statsCap, sizeof(msl_peac_stats) * nBlocks * n_frames));
-        dStats = (msl_peac_stats *)sc.stats;
-        if (cloud_out) { PEAC_TRY(grow(sc.cloud, sc.cloudCap, sizeof(double) * 3 * nVert * n_frames)); dCloud = (double *)sc.cloud; }
-    } else {
-        dStats = stats_out; dCloud = cloud_out;
-    }
-    P.stats = dStats; P.cloud = dCloud;
-    if (dCloud) hipLaunchKernelGGL(k_peac_cloud, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P);
-    hipLaunchKernelGGL(k_peac_blocks, dim3((unsigned)((nBlocks + 63) / 64), (unsigned)n_frames), dim3(64), 0, 0, P);
+    if (blocksUser) P.blocks = blocksUser;
+    else { PEAC_TRY(grow(sc.blocks, sc.blocksCap, sizeof(msl_peac_block) * nBlocks * n_frames)); P.blocks = (msl_peac_block *)sc.blocks; }
+    P.cloud = cloudDev;
+    if (cloudDev) hipLaunchKernelGGL(k_peac_cloud, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P);
+    hipLaunchKernelGGL(k_peac_fit, dim3((unsigned)nBlocks, (unsigned)n_frames), dim3(64), sizeof(double) * 9 * prm.window_w * prm.window_h, 0, P);
     PEAC_TRY(hipGetLastError());
+    *dBlocksOut = P.blocks;
+    if (dDepthOut) { *dDepthOut = P.depth; *dFrameStride = P.frameStrideBytes; }
+    return MSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void msl_peac_default_params(msl_peac_params *p) {   // ahc::ParamSet / ahc::PlaneFitter defaults (AHCParamSet.hpp:68-76, AHCPlaneFitter.hpp:157-161)
+    if (!p) return;
+    p->window_w = 10; p->window_h = 10; p->min_support = 3000; p->max_step = 100000; p->do_refine = 1; p->erode_type = 2; p->init_loose = 0; p->_pad = 0;
+    p->depth_sigma = 1.6e-6; p->std_tol_init = 5; p->std_tol_merge = 8; p->z_near = 500; p->z_far = 4000;
+    p->angle_near = ((15.0) * M_PI / 180.0); p->angle_far = ((90.0) * M_PI / 180.0);
+    p->similarity_th_merge = std::cos(((60.0) * M_PI / 180.0)); p->similarity_th_refine = std::cos(((30.0) * M_PI / 180.0));
+    p->depth_alpha = 0.04; p->depth_change_tol = 0.02;
+}
+
+int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                       msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                       msl_peac_block *blocks_out, msl_mem out_mem) {
+    if (!params || !blocks_out) { set_error("msl_peac_block_fit: invalid argument"); return MSL_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    msl_peac_block *dBlocks = nullptr;
+    int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, nullptr,
+                        &dBlocks, nullptr, nullptr, out_mem == MSL_MEM_DEVICE ? blocks_out : nullptr);
+    if (rc != MSL_OK) return rc;
+    const size_t nBlocks = (size_t)(((width + 1) / 2) / params->window_w) * (((height + 1) / 2) / params->window_h);
+    if (out_mem == MSL_MEM_HOST) PEAC_TRY(hipMemcpy(blocks_out, dBlocks, sizeof(msl_peac_block) * nBlocks * n_frames, hipMemcpyDeviceToHost));
+    else PEAC_TRY(hipDeviceSynchronize());
+    return MSL_OK;
+}
+
+int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                         msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, int window_w, int window_h, double depth_alpha,
+                         double depth_change_tol, int init_loose, double *cloud_out, msl_peac_stats *stats_out, msl_mem out_mem) {
+    if (!stats_out) { set_error("msl_peac_block_stats: invalid argument"); return MSL_ERR_INVALID; }
+    msl_peac_params prm;
+    msl_peac_default_params(&prm);
+    prm.window_w = window_w; prm.window_h = window_h; prm.depth_alpha = depth_alpha; prm.depth_change_tol = depth_change_tol; prm.init_loose = init_loose;
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    const size_t cw = (width + 1) / 2, ch = (height + 1) / 2, nVert = cw * ch;
+    if (window_w < 1 || window_h < 1) { set_error("msl_peac_block_stats: invalid argument"); return MSL_ERR_INVALID; }
+    const size_t nBlocks = (cw / window_w) * (ch / window_h);
+    double *dCloud = nullptr;
+    if (cloud_out) {
+        if (out_mem == MSL_MEM_HOST) {
+            if (bind_device(device) != MSL_OK) return MSL_ERR_NO_DEVICE;
+            Scratch &sc = g_scratch[device & 15];
+            PEAC_TRY(grow(sc.cloud, sc.cloudCap, sizeof(double) * 3 * nVert * n_frames));
+            dCloud = (double *)sc.cloud;
+        } else {
+            dCloud = cloud_out;
+        }
+    }
+    msl_peac_block *dBlocks = nullptr;
+    int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, prm, dCloud, &dBlocks,
+                        nullptr, nullptr, nullptr);
+    if (rc != MSL_OK) return rc;
+    // this entry point returns the Stats part only
+    std::vector<msl_peac_block> hb(nBlocks * n_frames);
+    PEAC_TRY(hipMemcpy(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost));
+    std::vector<msl_peac_stats> hs(hb.size());
+    for (size_t i = 0; i < hb.size(); i++) hs[i] = hb[i].stats;
     if (out_mem == MSL_MEM_HOST) {
-        PEAC_TRY(hipMemcpy(stats_out, dStats, sizeof(msl_peac_stats) * nBlocks * n_frames, hipMemcpyDeviceToHost));
+        memcpy(stats_out, hs.data(), sizeof(msl_peac_stats) * hs.size());
         if (cloud_out) PEAC_TRY(hipMemcpy(cloud_out, dCloud, sizeof(double) * 3 * nVert * n_frames, hipMemcpyDeviceToHost));
     } else {
-        PEAC_TRY(hipDeviceSynchronize());
+        PEAC_TRY(hipMemcpy(stats_out, hs.data(), sizeof(msl_peac_stats) * hs.size(), hipMemcpyHostToDevice));
     }
-#undef PEAC_TRY
+    return MSL_OK;
+}
+
+int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                              msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                              int32_t *membership_out, int32_t *n_planes_out) {
+    if (!params || !membership_out || params->min_support < 1) { set_error("msl_peac_membership_batch: invalid argument"); return MSL_ERR_INVALID; }
+    std::vector<msl_peac_block> hb;
+    std::vector<uint8_t> hostDepth;   // host copy of device-resident depth (the region growing reads single pixels)
+    const int cw = (width + 1) / 2, ch = (height + 1) / 2;
+    size_t nBlocks = 0, hostFrameStride = frame_stride_bytes;
+    const uint16_t *hostBase = depth;
+    {
+        std::lock_guard<std::mutex> lock(g_scratchMutex);
+        msl_peac_block *dBlocks = nullptr;
+        const uint16_t *dDepth = nullptr; size_t dStride = 0;
+        int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, nullptr,
+                            &dBlocks, &dDepth, &dStride, nullptr);
+        if (rc != MSL_OK) return rc;
+        nBlocks = (size_t)(cw / params->window_w) * (ch / params->window_h);
+        hb.resize(nBlocks * n_frames);
+        PEAC_TRY(hipMemcpy(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost));
+        if (mem == MSL_MEM_DEVICE) {
+            const size_t frameBytes = depth_stride_bytes * (size_t)(height - 1) + (size_t)width * 2;
+            hostDepth.resize(frameBytes * n_frames);
+            for (int f = 0; f < n_frames; f++)
+                PEAC_TRY(hipMemcpy(hostDepth.data() + f * frameBytes, (const uint8_t *)depth + f * frame_stride_bytes, frameBytes, hipMemcpyDeviceToHost));
+            hostBase = (const uint16_t *)hostDepth.data(); hostFrameStride = frameBytes;
+        }
+    }
+    auto one = [&](int f) {
+        FrameSegmenter seg(*params, (const uint16_t *)((const uint8_t *)hostBase + (size_t)f * hostFrameStride), depth_stride_bytes, cw, ch, fx, fy, cx, cy,
+                           depth_map_factor);
+        const int n = seg.run(hb.data() + (size_t)f * nBlocks, membership_out + (size_t)f * cw * ch);
+        if (n_planes_out) n_planes_out[f] = n;
+    };
+    const int nThreads = std::min(n_frames, std::max(1, std::min(16, (int)std::thread::hardware_concurrency())));
+    if (nThreads <= 1) {
+        for (int f = 0; f < n_frames; f++) one(f);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nThreads; t++)
+            pool.emplace_back([&, t]() { for (int f = t; f < n_frames; f += nThreads) one(f); });
+        for (auto &th : pool) th.join();
+    }
     return MSL_OK;
 }
 

@@ -5,7 +5,7 @@ ahc::PlaneFitter::initGraph (include/peac/AHCPlaneFitter.hpp:756-776, include/pe
 """
 import numpy as np
 
-from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, MSL_MEM_HOST
+from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, PEAC_PARAMS_DTYPE, PEAC_BLOCK_DTYPE, MSL_MEM_HOST
 
 
 def block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), depth_alpha=0.04, depth_change_tol=0.02,
@@ -24,3 +24,42 @@ def block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), de
                                    window[0], window[1], depth_alpha, depth_change_tol, 1 if init_loose else 0,
                                    ptr(cloud) if want_cloud else None, ptr(stats), MSL_MEM_HOST), "msl_peac_block_stats")
     return cloud, stats
+
+
+def default_params():
+    """ahc::PlaneFitter / ahc::ParamSet defaults (PlaneDetection overrides none of them)."""
+    p = np.zeros(1, PEAC_PARAMS_DTYPE)
+    lib.msl_peac_default_params(ptr(p))
+    return p
+
+
+def _frames(depth_u16):
+    d = np.asarray(depth_u16)
+    if d.ndim == 2:
+        d = d[None]
+    return np.ascontiguousarray(d, np.uint16)
+
+
+def block_fit(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, device=0):
+    """Initial graph node of every window (Stats + PCA plane fit) on the GPU: [F, Nh * Nw] PEAC_BLOCK_DTYPE."""
+    d = _frames(depth_u16)
+    F, H, W = d.shape
+    prm = default_params() if params is None else params
+    nb = (((W + 1) // 2) // int(prm["window_w"][0])) * (((H + 1) // 2) // int(prm["window_h"][0]))
+    out = np.zeros((F, nb), PEAC_BLOCK_DTYPE)
+    check(lib.msl_peac_block_fit(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(out),
+                                 MSL_MEM_HOST), "msl_peac_block_fit")
+    return out
+
+
+def plane_membership(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, device=0):
+    """PlaneDetection::readDepthImage + runPlaneDetection for [H, W] or [F, H, W] uint16 depth: (membership [F, ceil(H/2), ceil(W/2)] int32 =
+    plane_filter.membershipImg, number of extracted planes [F])."""
+    d = _frames(depth_u16)
+    F, H, W = d.shape
+    prm = default_params() if params is None else params
+    member = np.zeros((F, (H + 1) // 2, (W + 1) // 2), np.int32)
+    n = np.zeros(F, np.int32)
+    check(lib.msl_peac_membership_batch(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor, ptr(prm),
+                                        ptr(member), ptr(n)), "msl_peac_membership_batch")
+    return member, n

@@ -99,7 +99,7 @@ def _ray_box(cw, dw):
     return np.min(t, axis=2), axis
 
 
-def surfel_frame(k, w=640, h=480, intr=TUM1, variant="A", seed=7):
+def surfel_frame(k, w=640, h=480, intr=TUM1, variant="A", seed=7, dropout=0.02):
     """(gray u8 [h,w], depth f32 [h,w] metres, membership i32 [h/2,w/2], pose f32[16]) for keyframe k."""
     rng = np.random.Generator(np.random.PCG64(seed * 100003 + k))
     pose = camera_pose(k)
@@ -111,7 +111,7 @@ def surfel_frame(k, w=640, h=480, intr=TUM1, variant="A", seed=7):
     t, axis = _ray_box(cw, dw)
     hit = cw + dw * t[:, :, None]
     depth = t + rng.uniform(-0.002, 0.002, size=t.shape)
-    depth[rng.random(t.shape) < 0.02] = 0.0
+    depth[rng.random(t.shape) < dropout] = 0.0   # invalid pixels (dropout = 0.02 unless a test wants cleaner depth)
     # wall checker: the two tangent coordinates of the hit wall
     a = np.where(axis == 0, hit[:, :, 1], hit[:, :, 0])
     b = np.where(axis == 2, hit[:, :, 1], hit[:, :, 2])
@@ -153,3 +153,8 @@ def surfel_map(n, ref=0, seed=11, min_update_times=1):
     m["updateTimes"] = rng.integers(min_update_times, 21, n)
     m["lastUpdate"] = ref - rng.integers(0, 9, n)
     return m
+
+
+def depth_u16(depth_m, factor=5000.0):
+    """Metres -> the raw 16-bit depth image the plane extractor reads (TUM / ICL convention: 5000 units per metre)."""
+    return np.clip(np.rint(depth_m * factor), 0, 65535).astype(np.uint16)

@@ -46,3 +46,10 @@ cloud, stats = oracle_lib.peac_block_stats(d16, I["fx"], I["fy"], I["cx"], I["cy
 np.savez_compressed(os.path.join(OUT, "peac_640x480.npz"), frame=2, depth16_sha256=hashlib.sha256(d16.tobytes()).hexdigest(),
                     cloud_sha256=hashlib.sha256(cloud.tobytes()).hexdigest(), stats=stats)
 print("golden vectors written:", os.listdir(OUT))
+# the whole plane extractor (block PCA, clustering, erosion, region growing): ICL intrinsics, light dropout
+I4 = synth.ICL
+frame4, drop4 = 100, 0.001
+_, depth4, _, _ = synth.surfel_frame(frame4, intr=I4, dropout=drop4)
+mem4, npl4, blk4 = oracle_lib.peac_run(synth.depth_u16(depth4), I4["fx"], I4["fy"], I4["cx"], I4["cy"], np.float32(1.0 / 5000.0))
+np.savez_compressed(os.path.join(OUT, "peac_membership_640x480.npz"), frame=frame4, dropout=drop4, nplanes=npl4, membership=mem4, blocks=blk4)
+print("peac membership golden:", npl4, "planes")

@@ -312,3 +312,44 @@ def descriptor_distance(a, b):
     f.argtypes = [C.c_void_p, C.c_void_p]
     a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
     return np.array([f(_p(a[i]), _p(b[i])) for i in range(len(a))], np.int32)
+
+
+PEAC_PARAMS_DTYPE = np.dtype([(n, "<i4") for n in ("window_w", "window_h", "min_support", "max_step", "do_refine", "erode_type", "init_loose", "_pad")] +
+                             [(n, "<f8") for n in ("depth_sigma", "std_tol_init", "std_tol_merge", "z_near", "z_far", "angle_near", "angle_far",
+                                                   "similarity_th_merge", "similarity_th_refine", "depth_alpha", "depth_change_tol")])
+PEAC_BLOCK_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")] +
+                            [("center", "<f8", (3,)), ("normal", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8")])
+
+
+def peac_default_params():
+    p = np.zeros(1, PEAC_PARAMS_DTYPE)
+    load().dll.mslo_peac_default_params(_p(p))
+    return p
+
+
+def peac_run(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None):
+    """oracle/peac_oracle.cpp: the whole plane extractor on one [H, W] uint16 depth image -> (membership [ch, cw] i32, n_planes, blocks)."""
+    d = np.ascontiguousarray(depth_u16, np.uint16)
+    H, W = d.shape
+    cw, ch = (W + 1) // 2, (H + 1) // 2
+    prm = peac_default_params() if params is None else params
+    nb = (cw // int(prm["window_w"][0])) * (ch // int(prm["window_h"][0]))
+    member = np.zeros((ch, cw), np.int32)
+    blocks = np.zeros(nb, PEAC_BLOCK_DTYPE)
+    n = C.c_int32(0)
+    f = load().dll.mslo_peac_run
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p]
+    f(_p(d), d.strides[0], W, H, fx, fy, cx, cy, depth_map_factor, _p(prm), _p(member), C.byref(n), _p(blocks))
+    return member, n.value, blocks
+
+
+def eig33sym(K):
+    K = np.ascontiguousarray(K, np.float64)
+    s = np.zeros(3); V = np.zeros((3, 3))
+    f = load().dll.mslo_eig33sym
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(_p(K), _p(s), _p(V))
+    return s, V
