@@ -14,9 +14,9 @@ One *step* = one batch of F synthetic RGB-D frames through the hot path on each 
         sequence) + surfel fusion of every frame (keyframe_every = 1, the most demanding cadence) into a device-resident
         map of ~1 M live surfels, 640x480, TUM1 intrinsics.
   --config 2: ORBextractor only.                      --config 3: SurfelFusion only (~1 M live surfels).
-  --config 4: ICL-NUIM intrinsics (fy = -480), ORB on every frame, SurfelFusion on every k-th frame (--keyframe-every,
-        default 4; the reference's cadence is data dependent, src/Tracking.cc:1433-1508), plane membership variant B
-        (three rectangular plane regions) standing in for the PEAC output.
+  --config 4: ICL-NUIM intrinsics (fy = -480), ORB on every frame; on every k-th frame (--keyframe-every, default 4; the
+        reference's cadence is data dependent, src/Tracking.cc:1433-1508) the PEAC plane extractor (msl_peac_membership_batch) and
+        SurfelFusion with its membership image.
   --config 5: the frontend workload on 1280x960 frames (2x TUM1 intrinsics); meant for --gpus 8, one sequence per GPU.
 
 Each rank owns an independent sequence (weak scaling); the only inter-GPU traffic is one RCCL all_gather of per-sequence
@@ -43,9 +43,9 @@ CONFIGS = {
                      name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
     "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 2: ORBextractor only"),
     "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 3: SurfelFusion only"),
-    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="B", kfe=4,
-              name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + SurfelFusion every k-th frame, "
-                   "plane membership variant B in place of the PEAC output"),
+    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001,
+              name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + PEAC plane extractor and SurfelFusion every k-th "
+                   "frame (block fit on the GPU, clustering on host threads; its membership image feeds the fusion)"),
     "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1,
               name="BASELINE config 5: ORB + SurfelFusion on every frame, 1280x960 sequences"),
 }
@@ -87,13 +87,13 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
-def build_inputs(rank, D, n_surfels, W, H, intr, variant, need_orb_texture=True):
+def build_inputs(rank, D, n_surfels, W, H, intr, variant, need_orb_texture=True, dropout=0.02):
     """D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host)."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
     grays, depths, poses = [], [], []
     member = None
     for f in range(D):
-        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=7 + 1000 * rank)
+        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=7 + 1000 * rank, dropout=dropout)
         # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
         grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f, W, H) if need_orb_texture else g)
         depths.append(depth)
@@ -210,7 +210,8 @@ def main():
     nsub = F // B
     nkf = B // kfe if do_sf else 0   # keyframes per library call
     intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
-    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg["variant"])
+    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg["variant"], dropout=cfg.get("dropout", 0.02))
+    use_peac = bool(cfg.get("peac")) and do_sf
 
     orb = sf = None
     d_gray = torch.from_numpy(grays).to(dev).repeat(F // D, 1, 1).contiguous()
@@ -227,16 +228,35 @@ def main():
         sf.map_upload(smap)
         d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
         d_member = torch.from_numpy(member).to(dev)
+        if use_peac:
+            from manhattanslam_amd import peac
+            # raw 16-bit depth of the keyframes (5000 units per metre), resident in HBM like the other inputs
+            d_depth16 = torch.from_numpy(np.stack([synth.depth_u16(d) for d in depths]).view(np.int16)).to(dev).repeat(F // D, 1, 1).contiguous()
+            peac_prm = peac.default_params()
+            h_member = np.zeros((nkf * nsub, H // 2, W // 2), np.int32)
+            h_nplanes = np.zeros(nkf * nsub, np.int32)
         kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
     torch.cuda.synchronize()
 
     kf_no = [0]
+    peac_dev = [None]
     cap_ = orb.capacity if do_orb else 0
 
     def sub_orb(sb):
         orb.extract_batch_device(d_gray[sb * B:], d_kps[sb * B * cap_ * 28:], d_desc[sb * B * cap_ * 32:], d_n[sb * B:], B, W, H)
 
     def sub_sf(sb):
+        if use_peac:
+            if sb == 0:
+                # plane membership of the step's keyframes in one call: block fit on the GPU, clustering on one host thread per keyframe
+                # (synchronous: the sequential AHC is the slow part), then back to HBM
+                peac.plane_membership_device(d_depth16, kfe, nkf * nsub, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], np.float32(1.0 / 5000.0),
+                                             peac_prm, h_member, h_nplanes, device=local_rank)
+                peac_dev[0] = torch.from_numpy(h_member).to(dev)
+            sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], peac_dev[0][sb * nkf:], kf_poses[sb], device=True,
+                                   member_shared=False, frame_step=kfe, member_frame_step=1)
+            kf_no[0] += nkf
+            return
         # the superpixel stage of a call's keyframes is frame-batched, the map stage runs keyframe after keyframe
         sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], d_member, kf_poses[sb], device=True,
                                member_shared=True, frame_step=kfe)
@@ -324,7 +344,7 @@ def main():
         "config": {"workload": f"{cfg['name']} (keyframe_every={kfe}), {W}x{H}, one independent sequence per GPU",
                    "config": args.config, "frames_per_step": F, "frames_per_call": B, "keyframes_per_step": nkf * nsub, "keyframe_every": kfe, "distinct_frames": D,
                    "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg), "intrinsics": cfg["intr"],
-                   "membership": cfg["variant"], "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4)},
+                   "membership": "PEAC plane extractor (msl_peac_membership_batch)" if use_peac else cfg["variant"], "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4)},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else "no committed PMC summary for this config",

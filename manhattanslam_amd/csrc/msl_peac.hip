@@ -21,7 +21,9 @@
 #include "msl_common.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <map>
 #include <mutex>
@@ -166,6 +168,17 @@ __global__ __launch_bounds__(256) void k_peac_cloud(PeacDev P) {
     o[0] = x; o[1] = y; o[2] = z;
 }
 
+// Raw depth of the cloud's vertices (even rows / columns) packed to [frames][ch][cw]: what the host-side region growing reads --
+// a quarter of the image, so device-resident input costs one small copy instead of the whole frame.
+__global__ __launch_bounds__(256) void k_peac_half(PeacDev P, uint16_t *out) {
+    const int frame = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P.cw * P.ch) return;
+    const int row = i / P.cw, col = i - row * P.cw;
+    const uint8_t *img = reinterpret_cast<const uint8_t *>(P.depth) + (size_t)frame * P.frameStrideBytes;
+    out[(size_t)frame * P.cw * P.ch + i] = *reinterpret_cast<const uint16_t *>(img + (size_t)(2 * row) * P.strideBytes + 2 * (size_t)(2 * col));
+}
+
 // One wave per window.  LDS: nine arrays of winW * winH products (a missing point contributes +0.0, which leaves every partial
 // sum unchanged, so the additions that matter happen in the reference's raster order).
 __global__ __launch_bounds__(64) void k_peac_fit(PeacDev P) {
@@ -241,21 +254,32 @@ struct Node {
 
 class FrameSegmenter {
 public:
-    FrameSegmenter(const msl_peac_params &prm, const uint16_t *img, size_t strideBytes, int cw, int ch, float fx, float fy, float cx, float cy, float factor)
-        : T{prm}, img_(img), stride_(strideBytes), W(cw), H(ch), fx_(fx), fy_(fy), cx_(cx), cy_(cy), factor_(factor), winW(prm.window_w),
+    FrameSegmenter(const msl_peac_params &prm, const uint16_t *halfDepth /* [ch][cw] raw depth of the cloud vertices */, int cw, int ch, float fx, float fy, float cx,
+                   float cy, float factor)
+        : T{prm}, img_(halfDepth), W(cw), H(ch), fx_(fx), fy_(fy), cx_(cx), cy_(cy), factor_(factor), winW(prm.window_w),
           winH(prm.window_h), Nw(cw / prm.window_w), Nh(ch / prm.window_h) {}
 
     // returns the number of extracted planes; member[H * W] receives PlaneFitter::membershipImg
     int run(const msl_peac_block *blocks, int32_t *member) {
+        const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto t0 = now();
         parent_.resize((size_t)Nw * Nh); setSize_.assign((size_t)Nw * Nh, 1);
         for (size_t i = 0; i < parent_.size(); i++) parent_[i] = (int)i;
         nodes_.clear(); nodes_.reserve((size_t)Nw * Nh * 2);
         Heap heap{MseGreater{this}};
         build_graph(blocks, heap);
+        auto t1 = now();
         cluster(heap);
+        auto t2 = now();
         member_ = member;
         std::fill(member, member + (size_t)W * H, -1);
         if (T.p.do_refine) refine();
+        auto t3 = now();
+        if (timing) {
+            auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+            fprintf(stderr, "[msl_peac] graph %ld us, cluster %ld us (%zu nodes), refine %ld us (queue %zu)\n", us(t0, t1), us(t1, t2), nodes_.size(), us(t2, t3), growQ_.size());
+        }
         return (int)planes_.size();
     }
 
@@ -267,7 +291,7 @@ private:
     typedef std::priority_queue<int, std::vector<int>, MseGreater> Heap;
 
     Thresholds T;
-    const uint16_t *img_; size_t stride_;
+    const uint16_t *img_;
     int W, H; float fx_, fy_, cx_, cy_, factor_;
     int winW, winH, Nw, Nh;
     std::vector<Node> nodes_;
@@ -373,8 +397,8 @@ private:
         std::sort(planes_.begin(), planes_.end(), [this](int a, int b) { return nodes_[b].N < nodes_[a].N; });   // PlaneSegSizeCmp
     }
 
-    bool point(int row, int col, double pt[3]) const {   // ImagePointCloud::get on the fly
-        const double z = vertex_z(img_, stride_, factor_, row, col);
+    bool point(int row, int col, double pt[3]) const {   // ImagePointCloud::get on the fly, from the packed vertex depths
+        const double z = (double)img_[(size_t)row * W + col] * factor_;
         pt[2] = z;
         if (z == 0) return false;
         vertex_xy(fx_, fy_, cx_, cy_, row, col, z, pt[0], pt[1]);
@@ -487,7 +511,7 @@ private:
     }
 };
 
-struct Scratch { void *depth = nullptr, *blocks = nullptr, *cloud = nullptr; size_t depthCap = 0, blocksCap = 0, cloudCap = 0; };
+struct Scratch { void *depth = nullptr, *blocks = nullptr, *cloud = nullptr, *half = nullptr; size_t depthCap = 0, blocksCap = 0, cloudCap = 0, halfCap = 0; };
 Scratch g_scratch[16];
 std::mutex g_scratchMutex;
 
@@ -505,8 +529,8 @@ hipError_t grow(void *&p, size_t &cap, size_t need) {
 // cloud (optional) + block fit for n_frames images; dBlocksOut receives the device pointer of the [frames][Nh * Nw] blocks.
 // The caller holds g_scratchMutex.
 int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t frameStrideBytes, int width, int height, int n_frames, msl_mem mem, float fx,
-               float fy, float cx, float cy, float factor, const msl_peac_params &prm, double *cloudDev, msl_peac_block **dBlocksOut, const uint16_t **dDepthOut,
-               size_t *dFrameStride, msl_peac_block *blocksUser /* device output buffer or nullptr */) {
+               float fy, float cx, float cy, float factor, const msl_peac_params &prm, double *cloudDev, msl_peac_block **dBlocksOut, uint16_t **dHalfOut /* nullptr: not wanted */,
+               msl_peac_block *blocksUser /* device output buffer or nullptr */) {
     if (!depth || width < 2 || height < 2 || n_frames < 1 || prm.window_w < 1 || prm.window_h < 1 || prm.window_w * prm.window_h > 4096 ||
         strideBytes < (size_t)width * 2 || (n_frames > 1 && frameStrideBytes < strideBytes * (size_t)(height - 1) + (size_t)width * 2) || fx == 0 || fy == 0) {
         set_error("msl_peac: invalid argument");
@@ -539,8 +563,13 @@ int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t fra
     if (cloudDev) hipLaunchKernelGGL(k_peac_cloud, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P);
     hipLaunchKernelGGL(k_peac_fit, dim3((unsigned)nBlocks, (unsigned)n_frames), dim3(64), sizeof(double) * 9 * prm.window_w * prm.window_h, 0, P);
     PEAC_TRY(hipGetLastError());
+    if (dHalfOut) {
+        PEAC_TRY(grow(sc.half, sc.halfCap, sizeof(uint16_t) * nVert * n_frames));
+        hipLaunchKernelGGL(k_peac_half, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P, (uint16_t *)sc.half);
+        PEAC_TRY(hipGetLastError());
+        *dHalfOut = (uint16_t *)sc.half;
+    }
     *dBlocksOut = P.blocks;
-    if (dDepthOut) { *dDepthOut = P.depth; *dFrameStride = P.frameStrideBytes; }
     return MSL_OK;
 }
 
@@ -564,7 +593,7 @@ int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_by
     std::lock_guard<std::mutex> lock(g_scratchMutex);
     msl_peac_block *dBlocks = nullptr;
     int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, nullptr,
-                        &dBlocks, nullptr, nullptr, out_mem == MSL_MEM_DEVICE ? blocks_out : nullptr);
+                        &dBlocks, nullptr, out_mem == MSL_MEM_DEVICE ? blocks_out : nullptr);
     if (rc != MSL_OK) return rc;
     const size_t nBlocks = (size_t)(((width + 1) / 2) / params->window_w) * (((height + 1) / 2) / params->window_h);
     if (out_mem == MSL_MEM_HOST) PEAC_TRY(hipMemcpy(blocks_out, dBlocks, sizeof(msl_peac_block) * nBlocks * n_frames, hipMemcpyDeviceToHost));
@@ -596,7 +625,7 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
     }
     msl_peac_block *dBlocks = nullptr;
     int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, prm, dCloud, &dBlocks,
-                        nullptr, nullptr, nullptr);
+                        nullptr, nullptr);
     if (rc != MSL_OK) return rc;
     // this entry point returns the Stats part only
     std::vector<msl_peac_block> hb(nBlocks * n_frames);
@@ -617,35 +646,28 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
                               int32_t *membership_out, int32_t *n_planes_out) {
     if (!params || !membership_out || params->min_support < 1) { set_error("msl_peac_membership_batch: invalid argument"); return MSL_ERR_INVALID; }
     std::vector<msl_peac_block> hb;
-    std::vector<uint8_t> hostDepth;   // host copy of device-resident depth (the region growing reads single pixels)
+    std::vector<uint16_t> half;       // raw depth of the cloud vertices, [frames][ch][cw]
     const int cw = (width + 1) / 2, ch = (height + 1) / 2;
-    size_t nBlocks = 0, hostFrameStride = frame_stride_bytes;
-    const uint16_t *hostBase = depth;
+    size_t nBlocks = 0;
     {
         std::lock_guard<std::mutex> lock(g_scratchMutex);
         msl_peac_block *dBlocks = nullptr;
-        const uint16_t *dDepth = nullptr; size_t dStride = 0;
+        uint16_t *dHalf = nullptr;
         int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, nullptr,
-                            &dBlocks, &dDepth, &dStride, nullptr);
+                            &dBlocks, &dHalf, nullptr);
         if (rc != MSL_OK) return rc;
         nBlocks = (size_t)(cw / params->window_w) * (ch / params->window_h);
         hb.resize(nBlocks * n_frames);
+        half.resize((size_t)cw * ch * n_frames);
         PEAC_TRY(hipMemcpy(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost));
-        if (mem == MSL_MEM_DEVICE) {
-            const size_t frameBytes = depth_stride_bytes * (size_t)(height - 1) + (size_t)width * 2;
-            hostDepth.resize(frameBytes * n_frames);
-            for (int f = 0; f < n_frames; f++)
-                PEAC_TRY(hipMemcpy(hostDepth.data() + f * frameBytes, (const uint8_t *)depth + f * frame_stride_bytes, frameBytes, hipMemcpyDeviceToHost));
-            hostBase = (const uint16_t *)hostDepth.data(); hostFrameStride = frameBytes;
-        }
+        PEAC_TRY(hipMemcpy(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost));
     }
     auto one = [&](int f) {
-        FrameSegmenter seg(*params, (const uint16_t *)((const uint8_t *)hostBase + (size_t)f * hostFrameStride), depth_stride_bytes, cw, ch, fx, fy, cx, cy,
-                           depth_map_factor);
+        FrameSegmenter seg(*params, half.data() + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
         const int n = seg.run(hb.data() + (size_t)f * nBlocks, membership_out + (size_t)f * cw * ch);
         if (n_planes_out) n_planes_out[f] = n;
     };
-    const int nThreads = std::min(n_frames, std::max(1, std::min(16, (int)std::thread::hardware_concurrency())));
+    const int nThreads = std::min(n_frames, std::max(1, std::min(64, (int)std::thread::hardware_concurrency())));
     if (nThreads <= 1) {
         for (int f = 0; f < n_frames; f++) one(f);
     } else {

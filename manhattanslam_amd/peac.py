@@ -5,7 +5,7 @@ ahc::PlaneFitter::initGraph (include/peac/AHCPlaneFitter.hpp:756-776, include/pe
 """
 import numpy as np
 
-from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, PEAC_PARAMS_DTYPE, PEAC_BLOCK_DTYPE, MSL_MEM_HOST
+from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, PEAC_PARAMS_DTYPE, PEAC_BLOCK_DTYPE, MSL_MEM_HOST, MSL_MEM_DEVICE
 
 
 def block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), depth_alpha=0.04, depth_change_tol=0.02,
@@ -63,3 +63,10 @@ def plane_membership(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, d
     check(lib.msl_peac_membership_batch(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor, ptr(prm),
                                         ptr(member), ptr(n)), "msl_peac_membership_batch")
     return member, n
+
+
+def plane_membership_device(d_depth16, frame_step, n_frames, width, height, fx, fy, cx, cy, depth_map_factor, params, member_out, nplanes_out, device=0):
+    """Device-resident 16-bit depth frames (torch tensor, frame j of the call = frame j * frame_step of the tensor); membership and plane
+    counts land in the caller's host arrays ([n_frames, ceil(H/2), ceil(W/2)] int32, [n_frames] int32)."""
+    check(lib.msl_peac_membership_batch(device, ptr(d_depth16), 2 * width, 2 * width * height * int(frame_step), width, height, n_frames, MSL_MEM_DEVICE, fx, fy,
+                                        cx, cy, depth_map_factor, ptr(params), ptr(member_out), ptr(nplanes_out)), "msl_peac_membership_batch")

@@ -107,17 +107,18 @@ class SurfelFusion:
     def set_batch_capacity(self, max_frames):
         check(lib.msl_sf_set_batch_capacity(self._h, int(max_frames)), "msl_sf_set_batch_capacity")
 
-    def fuse_resident_batch(self, refs, grays, depths, members, poses, device=False, member_shared=False, frame_step=1):
+    def fuse_resident_batch(self, refs, grays, depths, members, poses, device=False, member_shared=False, frame_step=1, member_frame_step=None):
         """Keyframes in order.  grays (n,H,W) u8, depths (n,H,W) f32, members (n,H/2,W/2) i32 (or (H/2,W/2) with
         member_shared=True), poses (n,16) column-major; host numpy arrays or, with device=True, torch tensors.
         frame_step = k: keyframe j is frame j * k of the image arrays (SurfelFusion on every k-th frame of a sequence)."""
         n = len(refs)
         k = int(frame_step)
+        km = k if member_frame_step is None else int(member_frame_step)   # membership images may come one per keyframe (PEAC output)
         refs = np.ascontiguousarray(refs, np.int32)
         poses = np.ascontiguousarray(np.stack([_pose16(p) for p in poses]), np.float32)
         w, h = self.width, self.height
         check(lib.msl_sf_fuse_resident_batch(self._h, n, ptr(refs), ptr(grays), w, k * w * h, ptr(depths), 4 * w, 4 * k * w * h, ptr(members),
-                                             4 * (w // 2), 0 if member_shared else 4 * k * (w // 2) * (h // 2),
+                                             4 * (w // 2), 0 if member_shared else 4 * km * (w // 2) * (h // 2),
                                              MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch")
 
     def counters(self):
