@@ -215,6 +215,10 @@ MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8
 MSL_API int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out);
 MSL_API int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n);
 MSL_API int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out);
+/* System::saveSurfels (src/System.cc:296-382) on the cloud of SurfelMapping::Stop (src/SurfelMapping.cpp:62-104): msl_sf_map_export(min_update_times)
+ * followed by the caller's inactive surfels, written as the reference's ASCII PLY (vertex: x y z nx ny nz red green blue alpha quality radius; one
+ * camera element).  (The map-plane points Stop() appends are Map data outside this library; pass them through `inactive` if wanted.) */
+MSL_API int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path);
 
 /* ---- widening, SURVEY.md 8(f) rank 2: the data-parallel front of the PEAC plane extractor (producer of membershipImg) ----
  * msl_peac_block_stats: for n_frames raw 16-bit depth images

@@ -69,6 +69,7 @@ SIGNATURES = {
     "msl_sf_map_detach": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),
+    "msl_sf_export_ply": (_i, [_vp, _i, _vp, _sz, C.c_char_p]),
     "msl_peac_default_params": (None, [_vp]),
     "msl_peac_block_fit": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _i]),
     "msl_peac_membership_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),

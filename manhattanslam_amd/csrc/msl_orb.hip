@@ -497,10 +497,20 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_blur: GaussianBlur 7x7 sigma 2 (integer kernel {18,34,49,55,49,34,18}, >>16 with rounding),
+// k_blur: GaussianBlur 7x7 sigma 2 (integer kernel {18,34,49,55,49,34,18} by default, >>16 with rounding),
 // reflect-101 on the level's own borders.  Tile 64 x 32 outputs per workgroup.
 // ---------------------------------------------------------------------------------------------
 constexpr int BT_W = 64, BT_H = 32;
+// Which OpenCV generation's 8-bit Gaussian kernel is pinned: 0 = per-coefficient rounding {18,34,49,55,..}
+// (OpenCV 3.x, sum 257), 1 = error-diffused "bit-exact" kernel {18,34,48,56,..} (later releases, sum 256).  Row sums stay <= 65535.
+#ifndef MSL_BLUR_VARIANT
+#define MSL_BLUR_VARIANT 0
+#endif
+#if MSL_BLUR_VARIANT == 1
+constexpr int GK0 = 18, GK1 = 34, GK2 = 48, GK3 = 56;
+#else
+constexpr int GK0 = 18, GK1 = 34, GK2 = 49, GK3 = 55;
+#endif
 
 __device__ __forceinline__ int reflect101(int p, int len) {
     while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
@@ -547,7 +557,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
         unsigned o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++)   // output column 4 j + k reads staged bytes 4 j + k + 1 .. + 7
-            o[k] = (unsigned)(18 * (bb[k + 1] + bb[k + 7]) + 34 * (bb[k + 2] + bb[k + 6]) + 49 * (bb[k + 3] + bb[k + 5]) + 55 * bb[k + 4]);
+            o[k] = (unsigned)(GK0 * (bb[k + 1] + bb[k + 7]) + GK1 * (bb[k + 2] + bb[k + 6]) + GK2 * (bb[k + 3] + bb[k + 5]) + GK3 * bb[k + 4]);
         uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
         *reinterpret_cast<uint2 *>(&s_row[r * BT_W + 4 * j]) = pk;
     }
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
         const int x = tx0 + 4 * j, y = ty0 + r;
         if (x >= D.w || y >= D.h) continue;
         int acc[4] = {0, 0, 0, 0};
-        constexpr int K7[7] = {18, 34, 49, 55, 49, 34, 18};
+        constexpr int K7[7] = {GK0, GK1, GK2, GK3, GK2, GK1, GK0};
 #pragma unroll
         for (int k = 0; k < 7; k++) {
             const uint2 q = *reinterpret_cast<const uint2 *>(&s_row[(r + k) * BT_W + 4 * j]);

@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 #include <vector>
 
 using namespace msl;
@@ -2038,6 +2039,40 @@ int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, si
 int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out) {
     return map_select(h, 1, min_update_times, false, out, cap, n_out, "msl_sf_map_export");
 }
+// System::saveSurfels (src/System.cc:296-382) for the cloud SurfelMapping::Stop builds (src/SurfelMapping.cpp:62-104): the local surfels
+// seen at least min_update_times times (filtered on the device, map order), then the caller's inactive surfels.  ASCII PLY with the
+// element / property layout the reference hands to tinyply; NaN positions are skipped (:311-312); alpha = 1, quality = weight,
+// radius = size * 1000 (SurfelMapping.cpp:80).  Number formatting is that of a default std::ostream (tinyply itself is a third party).
+int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path) {
+    if (!h || !path || (n_inactive && !inactive)) { set_error("msl_sf_export_ply: invalid argument"); return MSL_ERR_INVALID; }
+    size_t n = 0;
+    int rc = msl_sf_map_export(h, min_update_times, nullptr, 0, &n);
+    if (rc != MSL_OK && rc != MSL_ERR_CAPACITY) return rc;
+    std::vector<msl_surfel> pts(n + n_inactive);
+    if (n) { rc = msl_sf_map_export(h, min_update_times, pts.data(), n, &n); if (rc != MSL_OK) return rc; }
+    for (size_t i = 0; i < n_inactive; i++) pts[n + i] = inactive[i];
+    size_t count = 0;
+    for (const msl_surfel &e : pts) count += std::isnan(e.px) ? 0 : 1;
+    std::ofstream os(path, std::ios::out);
+    if (os.fail()) { set_error("msl_sf_export_ply: cannot open %s", path); return MSL_ERR_INVALID; }
+    os << "ply\nformat ascii 1.0\nelement vertex " << count << "\n";
+    for (const char *p : {"x", "y", "z", "nx", "ny", "nz"}) os << "property float " << p << "\n";
+    for (const char *p : {"red", "green", "blue", "alpha"}) os << "property uchar " << p << "\n";
+    for (const char *p : {"quality", "radius"}) os << "property float " << p << "\n";
+    os << "element camera 1\n";
+    for (const char *p : {"view_px", "view_py", "view_pz", "x_axisx", "x_axisy", "x_axisz", "y_axisx", "y_axisy", "y_axisz", "z_axisx", "z_axisy", "z_axisz",
+                          "focal", "scalex", "scaley", "centerx", "centery"})
+        os << "property float " << p << "\n";
+    os << "property int viewportx\nproperty int viewporty\nproperty float k1\nproperty float k2\nend_header\n";
+    for (const msl_surfel &e : pts) {
+        if (std::isnan(e.px)) continue;
+        os << e.px << " " << e.py << " " << e.pz << " " << e.nx << " " << e.ny << " " << e.nz << " " << (unsigned)(uint8_t)e.r << " " << (unsigned)(uint8_t)e.g << " "
+           << (unsigned)(uint8_t)e.b << " 1 " << e.weight << " " << e.size * 1000 << "\n";
+    }
+    os << "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 " << (int)count << " 1 0 0\n";
+    return os.fail() ? MSL_ERR_INVALID : MSL_OK;
+}
+
 int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     if (!h || (n && !surfels)) { set_error("msl_sf_map_append: invalid argument"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));

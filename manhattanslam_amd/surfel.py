@@ -91,6 +91,11 @@ class SurfelFusion:
         check(fn(self._h, int(arg), ptr(out), len(out), C.byref(n)), what)
         return out[:n.value]
 
+    def export_ply(self, path, min_update_times=5, inactive=None):
+        """System::saveSurfels on SurfelMapping::Stop's cloud: local surfels with updateTimes >= min_update_times, then `inactive`."""
+        ina = np.zeros(0, SURFEL_DTYPE) if inactive is None else np.ascontiguousarray(inactive, SURFEL_DTYPE)
+        check(lib.msl_sf_export_ply(self._h, int(min_update_times), ptr(ina) if len(ina) else None, len(ina), str(path).encode()), "msl_sf_export_ply")
+
     def map_append(self, surfels):
         surfels = np.ascontiguousarray(surfels, SURFEL_DTYPE)
         check(lib.msl_sf_map_append(self._h, ptr(surfels) if len(surfels) else None, len(surfels)), "msl_sf_map_append")

@@ -176,7 +176,35 @@ inline int reflect101(int p, int len) {
     return p;
 }
 
+// MSL_BLUR_VARIANT selects which OpenCV generation's 8-bit kernel is pinned (README.md:43 lists 3.3.0 and 3.4.3 as tested):
+//   0 (default)  every coefficient rounded on its own, round(k * 256) = {18,34,49,55,49,34,18} (sum 257): OpenCV <= 3.4.0
+//                (getGaussianKernel -> convertTo(CV_32S, 256)); the Q8.8 ufixedpoint16 kernel of the 3.4.x fixed-point path rounds
+//                the same coefficients the same way and its saturating u16 / u32 arithmetic cannot saturate for this kernel
+//                (255 * 257 = 65535), so both generations give the same bytes;
+//   1            the "bit-exact" Gaussian of later releases (4.x): the rounding error of each coefficient is carried to the next
+//                one and the centre takes the remainder, {18,34,48,56,48,34,18} (sum 256).
+// Both use (acc + 2^15) >> 16 with reflect-101 borders.  The same macro switches k_blur in the product.
+#ifndef MSL_BLUR_VARIANT
+#define MSL_BLUR_VARIANT 0
+#endif
 void gaussian_kernel_q8(int k[7]) {
+#if MSL_BLUR_VARIANT == 1
+    {   // getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED (error diffusion from the border towards the centre)
+        double kd[7], sigmaX = 2.0, scale2X = -0.5 / (sigmaX * sigmaX), sum = 0;
+        for (int i = 0; i < 7; i++) { const double x = i - 3.0; kd[i] = std::exp(scale2X * x * x); sum += kd[i]; }
+        double err = 0;
+        long long tot = 0;
+        for (int i = 0; i < 3; i++) {
+            const double adj = kd[i] / sum * 256.0 + err;
+            const int v0 = cv_round(adj);
+            err = adj - (double)v0;
+            k[i] = k[6 - i] = v0;
+            tot += v0;
+        }
+        k[3] = (int)(256 - 2 * tot);
+        return;
+    }
+#endif
     // getGaussianKernel(7, 2, CV_32F) then convertTo(CV_32S, 256)
     float cf[7];
     double sigmaX = 2.0, scale2X = -0.5 / (sigmaX * sigmaX), sum = 0;

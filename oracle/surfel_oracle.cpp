@@ -69,6 +69,20 @@ void inverse4(const T *m, T *inv) {
         for (int c = 0; c < 4; c++) inv[c * 4 + r] = cof[c][r] / det;  // inverse = adj / det, adj = cof^T
 }
 
+// src/SurfelFusion.cpp:488: `float updateDiff = fabs(preIntensity - sumIntensity) + fabs(preX - sumX) + fabs(preY - sumY);` with an
+// UNQUALIFIED fabs on floats.  Which overload that is depends on the headers in scope: with only <cmath> (and no using-directive)
+// it would be C's ::fabs(double) -- three double terms, added in double, rounded once by the assignment; once any header pulls
+// in libstdc++'s <math.h> wrapper (OpenCV 3.x's legacy C headers do, via opencv2/opencv.hpp) the float overload is visible in
+// the global namespace and the sum is a float chain with a rounding after every addition.  Pinned: the float chain.  The two
+// differ by one ulp for some inputs (tests/test_oracle_surfel.py::test_fabs_pin_known_answer), which only matters when the
+// result sits exactly at the 0.2 stability threshold.
+inline float update_diff(float preIntensity, float sumIntensity, float preX, float sumX, float preY, float sumY) {
+    return std::fabs(preIntensity - sumIntensity) + std::fabs(preX - sumX) + std::fabs(preY - sumY);
+}
+inline float update_diff_double_overload(float preIntensity, float sumIntensity, float preX, float sumX, float preY, float sumY) {
+    return (float)(std::fabs((double)(preIntensity - sumIntensity)) + std::fabs((double)(preX - sumX)) + std::fabs((double)(preY - sumY)));
+}
+
 struct Fusion {
     int W, H, spW, spH;
     float fx, fy, cx, cy, fuseFar, fuseNear;
@@ -245,7 +259,7 @@ struct Fusion {
                 const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
                 S.meanIntensity = sumIntensity; S.x = sumX; S.y = sumY;
                 vec3b(sumY, sumX, S.r, S.g, S.b);
-                float updateDiff = std::fabs(preIntensity - sumIntensity) + std::fabs(preX - sumX) + std::fabs(preY - sumY);
+                float updateDiff = update_diff(preIntensity, sumIntensity, preX, sumX, preY, sumY);
                 if (updateDiff < 0.2) S.stable = 1;
                 if (sumDepthNum > 0) {
                     float meanDepth = sumDepth / sumDepthNum;
@@ -609,6 +623,10 @@ MSLO_API size_t mslo_fuse_map_compact(msl_surfel *local, size_t n_local, const m
     return l.size();
 }
 MSLO_API void mslo_inverse4f(const float *m, float *inv) { inverse4<float>(m, inv); }
+// the pinned (float chain) and the alternative (C ::fabs(double)) reading of src/SurfelFusion.cpp:488
+MSLO_API float mslo_update_diff(float a0, float a1, float b0, float b1, float c0, float c1, int double_overload) {
+    return double_overload ? update_diff_double_overload(a0, a1, b0, b1, c0, c1) : update_diff(a0, a1, b0, b1, c0, c1);
+}
 
 // ---- map maintenance ----
 // inner loop of moveAddSurfels for one leaving pose (src/SurfelMapping.cpp:212-225); returns the number moved

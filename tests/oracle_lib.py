@@ -7,7 +7,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
-OLIB = os.path.join(ODIR, "libmsl_oracle.so")
+OLIB = os.environ.get("MSL_ORACLE_LIB", os.path.join(ODIR, "libmsl_oracle.so"))   # MSL_ORACLE_LIB: the blur-variant oracle (tests only)
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                            ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
@@ -24,7 +24,7 @@ SEED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("normX", "<
 def build():
     srcs = [os.path.join(ODIR, f) for f in ("orb_oracle.cpp", "surfel_oracle.cpp", "peac_oracle.cpp", "match_oracle.cpp", "Makefile")]
     if not os.path.exists(OLIB) or any(os.path.getmtime(s) > os.path.getmtime(OLIB) for s in srcs if os.path.exists(s)):
-        subprocess.check_call(["make", "-C", ODIR], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ODIR, "all", "variants"], stdout=subprocess.DEVNULL)
     return OLIB
 
 

@@ -225,3 +225,29 @@ def test_frame_epilogue_known_answers(oracle):
     rad = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
     xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x); yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
     assert np.abs(xd * I["fx"] + I["cx"] - kps["x"]).max() < 0.05 and np.abs(yd * I["fy"] + I["cy"] - kps["y"]).max() < 0.05
+
+
+def test_second_gaussian_generation_variant(tmp_path):
+    """MSL_BLUR_VARIANT=1 (oracle/libmsl_oracle_blur1.so): the error-diffused 'bit-exact' kernel of later OpenCV releases sums to 256,
+    so a constant image stays constant (the default kernel sums to 257: 100 -> 101) and the impulse response is the outer product."""
+    import ctypes as C
+    import os
+    from tests import oracle_lib
+    oracle_lib.build()
+    dll = C.CDLL(os.path.join(oracle_lib.ODIR, "libmsl_oracle_blur1.so"))
+    k = np.zeros(7, np.int32)
+    dll.mslo_gaussian_kernel.argtypes = [C.c_void_p]
+    dll.mslo_gaussian_kernel(k.ctypes.data_as(C.c_void_p))
+    assert list(k) == [18, 34, 48, 56, 48, 34, 18] and k.sum() == 256
+    dll.mslo_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    src = np.full((40, 50), 100, np.uint8); dst = np.zeros_like(src)
+    dll.mslo_gaussian_blur7(src.ctypes.data_as(C.c_void_p), 50, 40, dst.ctypes.data_as(C.c_void_p))
+    assert np.all(dst == 100)
+    src = np.zeros((21, 21), np.uint8); src[10, 10] = 255
+    dll.mslo_gaussian_blur7(src.ctypes.data_as(C.c_void_p), 21, 21, dst[:21, :21].copy().ctypes.data_as(C.c_void_p))
+    out = np.zeros((21, 21), np.uint8)
+    dll.mslo_gaussian_blur7(src.ctypes.data_as(C.c_void_p), 21, 21, out.ctypes.data_as(C.c_void_p))
+    want = (255 * np.outer(k, k) + 32768) >> 16
+    assert np.array_equal(out[7:14, 7:14], want) and out.sum() == want.sum()
+    # the default library keeps the 3.x kernel
+    assert list(oracle_lib.load().gaussian_kernel()) == [18, 34, 49, 55, 49, 34, 18]

@@ -135,3 +135,30 @@ def test_golden_surfel():
     assert lo[g["changed_index"]].tobytes() == g["changed_surfels"].tobytes()
     assert sf.seeds().tobytes() == g["seeds"].tobytes()
     assert hashlib.sha256(sf.index().tobytes()).hexdigest() == str(g["index_sha256"])
+
+
+def test_fabs_pin_known_answer():
+    """src/SurfelFusion.cpp:488 sums three unqualified fabs() of floats.  The oracle pins the float overload (a float chain);
+    C's ::fabs(double) would add in double and round once.  Known answer where the two readings differ by one ulp."""
+    import ctypes as C
+    from tests import oracle_lib
+    f = oracle_lib.load().dll.mslo_update_diff
+    f.restype = C.c_float
+    f.argtypes = [C.c_float] * 6 + [C.c_int]
+    f32 = np.float32
+    # |d1| + |d2| + |d3| with d = (0.1, 0.05, 0.05000001): float chain rounds after every add
+    rng = np.random.default_rng(5)
+    found = None
+    for _ in range(20000):
+        a, b, c = (f32(x) for x in rng.uniform(0.01, 0.2, 3))
+        chain = f32(f32(a + b) + c)
+        once = f32(np.float64(a) + np.float64(b) + np.float64(c))
+        if chain != once:
+            found = (a, b, c, chain, once)
+            break
+    assert found is not None
+    a, b, c, chain, once = found
+    z = f32(0)
+    assert f32(f(float(a), 0.0, float(b), 0.0, float(c), 0.0, 0)) == chain        # pinned: std::fabs(float)
+    assert f32(f(float(a), 0.0, float(b), 0.0, float(c), 0.0, 1)) == once         # alternative: ::fabs(double)
+    assert abs(float(chain) - float(once)) <= float(np.spacing(chain)) and z == 0

@@ -171,3 +171,34 @@ def test_frame_epilogue_matches_oracle(oracle, dist):
         if dist:
             assert np.abs(un - np.stack([kg["x"], kg["y"]], 1)).max() > 1.0      # the distortion really moves points
     ex.close()
+
+
+def test_second_gaussian_generation_variant_library():
+    """The product built with MSL_BLUR_VARIANT=1 (manhattanslam_amd/variants/libmsl_blur1.so) against the oracle built the same way:
+    blurred levels byte-identical, full extraction bit-exact, and different from the default kernel's descriptors."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "manhattanslam_amd", "variants", "libmsl_blur1.so")
+    olib = os.path.join(root, "oracle", "libmsl_oracle_blur1.so")
+    assert os.path.exists(lib) and os.path.exists(olib), "python -c 'import __graft_entry__ as g; g.build()' builds both variants"
+    script = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from manhattanslam_amd import ORBextractor, synth\n"
+        "from tests import oracle_lib\n"
+        "o = oracle_lib.load()\n"
+        "assert list(o.gaussian_kernel()) == [18, 34, 48, 56, 48, 34, 18]\n"
+        "img = synth.orb_frame(synth.ORB_SEED + 4)\n"
+        "ex = ORBextractor(1000, 1.2, 8, 20, 7)\n"
+        "kg, dg = ex(img)\n"
+        "oe = o.orb_create()\n"
+        "ko, do = oe.extract(img)\n"
+        "assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do)\n"
+        "for l in (0, 3, 7):\n"
+        "    assert np.array_equal(ex.debug_level(0, l, blurred=True), oe.level(l, blurred=True))\n"
+        "print('variant ok', len(kg))\n" % root)
+    env = dict(os.environ, MSL_LIB=lib, MSL_ORACLE_LIB=olib)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr

@@ -440,3 +440,30 @@ def test_resident_map_grows_without_reserve(oracle):
     assert len(mo) > 80000, len(mo)
     assert_surfels_close(g.map_download(), mo, "map grown by batches")
     g.close()
+
+
+def test_export_ply_matches_map_export(oracle, tmp_path):
+    """System::saveSurfels layout (src/System.cc:296-382): vertex lines = the updateTimes >= 5 surfels in map order + the inactive ones."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, _ = _mk(synth.TUM1)
+    m = synth.surfel_map(5000, ref=0).astype(SURFEL_DTYPE)
+    g.map_upload(m)
+    ina = synth.surfel_map(40, ref=0, seed=99).astype(SURFEL_DTYPE)
+    ina["px"][3] = np.nan                                    # skipped (:311-312)
+    path = tmp_path / "Surfels.ply"
+    g.export_ply(path, 5, ina)
+    lines = open(path).read().splitlines()
+    hdr = lines.index("end_header")
+    want = np.concatenate([g.map_export(5), ina[~np.isnan(ina["px"])]])
+    assert lines[0] == "ply" and lines[1] == "format ascii 1.0" and lines[2] == f"element vertex {len(want)}"
+    assert lines[3:15] == [f"property float {p}" for p in ("x", "y", "z", "nx", "ny", "nz")] + [f"property uchar {p}" for p in ("red", "green", "blue", "alpha")] + \\
+        ["property float quality", "property float radius"]
+    body = np.array([[float(v) for v in ln.split()] for ln in lines[hdr + 1:hdr + 1 + len(want)]])
+    assert body.shape == (len(want), 12)
+    for col, f in enumerate(("px", "py", "pz", "nx", "ny", "nz")):
+        assert np.allclose(body[:, col], want[f], rtol=2e-5, atol=1e-6)          # default ostream precision: 6 significant digits
+    assert np.array_equal(body[:, 6].astype(int), want["r"] & 255) and np.all(body[:, 9] == 1)
+    assert np.allclose(body[:, 10], want["weight"], rtol=2e-5) and np.allclose(body[:, 11], want["size"] * 1000, rtol=2e-5)
+    cam = lines[hdr + 1 + len(want)].split()
+    assert len(cam) == 21 and int(cam[17]) == len(want) and len(lines) == hdr + 2 + len(want)
+    g.close()
