@@ -456,8 +456,8 @@ def test_export_ply_matches_map_export(oracle, tmp_path):
     hdr = lines.index("end_header")
     want = np.concatenate([g.map_export(5), ina[~np.isnan(ina["px"])]])
     assert lines[0] == "ply" and lines[1] == "format ascii 1.0" and lines[2] == f"element vertex {len(want)}"
-    assert lines[3:15] == [f"property float {p}" for p in ("x", "y", "z", "nx", "ny", "nz")] + [f"property uchar {p}" for p in ("red", "green", "blue", "alpha")] + \\
-        ["property float quality", "property float radius"]
+    assert lines[3:15] == [f"property float {p}" for p in ("x", "y", "z", "nx", "ny", "nz")] + [f"property uchar {p}" for p in ("red", "green", "blue", "alpha")] + [
+        "property float quality", "property float radius"]
     body = np.array([[float(v) for v in ln.split()] for ln in lines[hdr + 1:hdr + 1 + len(want)]])
     assert body.shape == (len(want), 12)
     for col, f in enumerate(("px", "py", "pz", "nx", "ny", "nz")):
