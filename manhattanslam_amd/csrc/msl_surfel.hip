@@ -1584,7 +1584,13 @@ struct msl_sf {
     bool propLds = false;        // t(s) of one keyframe fits the LDS: single-launch relaxation
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
-    size_t liveBound = 0;        // host-side upper bound of the live count: last synced count + nseeds per keyframe enqueued since
+    size_t liveBound = 0;        // host-side upper bound of the live count: last known count + nseeds per keyframe enqueued since
+    // asynchronous refresh of that bound: after every batch the live count is copied to pinned memory behind an event; a later call picks
+    // up whatever has arrived, so the bound follows the real count a couple of batches late instead of forcing a pipeline drain
+    // every capacity / nseeds keyframes
+    static constexpr int NSNAP = 4;
+    long long *h_snap = nullptr; hipEvent_t snapEv[NSNAP] = {}; unsigned long long snapKf[NSNAP] = {}; bool snapBusy[NSNAP] = {};
+    unsigned long long kfEnq = 0; int snapNext = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
@@ -1693,6 +1699,7 @@ int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
     h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
+    for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;   // (their events have fired: the stream is idle)
     return MSL_OK;
 }
 
@@ -1735,6 +1742,12 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         // overflow it.  Every keyframe adds at most nseeds surfels, so the host only needs an upper bound of the live count; the
         // exact count is read back (one sync) only when that bound reaches the capacity.
         const size_t need = (size_t)n * (size_t)D.nseeds;
+        for (int i = 0; i < msl_sf::NSNAP; i++)
+            if (h->snapBusy[i] && hipEventQuery(h->snapEv[i]) == hipSuccess) {
+                h->snapBusy[i] = false;
+                const size_t cand = (size_t)h->h_snap[i] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
+                if (cand < h->liveBound) h->liveBound = cand;
+            }
         if (h->liveBound + need > h->mapCap) {
             int rc = read_ctr(h);
             if (rc != MSL_OK) return rc;
@@ -1746,6 +1759,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             }
         }
         h->liveBound += need;
+        h->kfEnq += (unsigned long long)n;
     }
     const int set = (int)(h->batchNo & 1), slot0 = set * h->maxBatch;
     hipStream_t sp = h->preStream, sm = h->mapStream;
@@ -1836,6 +1850,14 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
+    if (compact && h->h_snap) {   // snapshot of the live count after this batch (picked up by a later call, never waited for)
+        const int i = h->snapNext;
+        if (!h->snapBusy[i]) {
+            MSL_HIP_TRY(hipMemcpyAsync(&h->h_snap[i], h->d_ctr, sizeof(long long), hipMemcpyDeviceToHost, sm));
+            MSL_HIP_TRY(hipEventRecord(h->snapEv[i], sm));
+            h->snapKf[i] = h->kfEnq; h->snapBusy[i] = true; h->snapNext = (i + 1) % msl_sf::NSNAP;
+        }
+    }
     MSL_HIP_TRY(hipGetLastError());
     h->lastSlot = slot0 + n - 1;
     h->batchNo++;
@@ -1871,6 +1893,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
+    ok = ok && hipHostMalloc(&h->h_snap, sizeof(long long) * msl_sf::NSNAP) == hipSuccess;
+    for (int i = 0; i < msl_sf::NSNAP && ok; i++) ok = hipEventCreateWithFlags(&h->snapEv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
     ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D) == hipSuccess;
@@ -1903,6 +1927,8 @@ void msl_sf_destroy(msl_sf *h) {
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
     F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
+    if (h->h_snap) (void)hipHostFree(h->h_snap);
+    for (int i = 0; i < msl_sf::NSNAP; i++) if (h->snapEv[i]) (void)hipEventDestroy(h->snapEv[i]);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
     delete h;
