@@ -32,7 +32,6 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
-#include <unordered_map>
 #include <vector>
 
 using namespace msl;
@@ -108,10 +107,6 @@ struct SfDev {
     unsigned *tickets;           // [2] hand-off counters (k_fuse, k_compact)
     unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
-    int mapPrio;                 // experiment knob: wave priority of the map kernel
-    unsigned *ls;                // [16] log state of the resident map (see k_fuse)
-    unsigned *delSeq;            // [cap] keyframe (launch number) that deleted the record
-    unsigned long long *birth;   // [cap] keyframe << 32 | seed of the records appended since the log began
     const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
 };
 
@@ -1020,71 +1015,6 @@ __device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_fla
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// ---- the per-surfel fusion chain (src/SurfelFusion.cpp:167-283), shared by the resident and the host-vector kernels ----
-// Geometry of one record against the keyframe (phase A).  Returns 0: nothing to do, 1: stale -> delete, 2: already deleted,
-// 3: in view (pzv, offD, offI are its camera depth and the offsets of its pixel in the depth / superpixel-index images;
-// the offsets are valid addresses for every record so the caller can issue the lookups unconditionally).
-__device__ __forceinline__ int fuse_classify(const SfDev &P, const FrameDev &F, float x, float y, float z, int ut, int lu, bool present,
-                                             float &pzv, unsigned &offD, unsigned &offI) {
-    float pc[4];
-    mul4(F.invPose, x, y, z, 1.0f, pc);
-    const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
-    const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
-    const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
-    const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
-    // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of
-    // the image either way
-    const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
-    const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
-    int st = 0;
-    if (present) st = (F.ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
-    pzv = pc[2];
-    const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
-    offD = (unsigned)pVc * (unsigned)P.dstride + (unsigned)pUc;   // images are far below 2^32 elements
-    offI = (unsigned)(pVc * P.W + pUc);
-    return st;
-}
-// Seed tests + weighted fusion of one in-view record that passed the occlusion test (phase B).
-// Returns 0: record untouched, 1: delete (normals disagree), 2: fused (hr / C rewritten, the caller marks the seed).
-__device__ __forceinline__ int fuse_update(const FrameDev &F, float cameraF, const msl_seed &S, HotRec &hr, ColdRec &C) {
-    const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
-    if (S.normX == 0 && S.normY == 0 && S.normZ == 0) return 0;
-    if (S.viewCos < MAX_ANGLE_COS) return 0;
-    float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
-    tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
-    if (pz < S.meanDepth - tolerateDiff) return 0;
-    if (pz > S.meanDepth + tolerateDiff) return 0;
-    float nc[3];
-    mul3(F.invPose, C.nx, C.ny, C.nz, nc);
-    const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-    if (normDiffCos < MAX_ANGLE_COS) return 1;
-    const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
-    const float oldWeight = C.weight;
-    const float newWeight = get_weight(S.meanDepth);
-    const float sumWeight = oldWeight + newWeight;
-    float spPW[4];
-    mul4(F.pose, S.posX, S.posY, S.posZ, 1.0f, spPW);
-    const float fusedPx = (Lpx * oldWeight + newWeight * spPW[0]) / sumWeight;
-    const float fusedPy = (Lpy * oldWeight + newWeight * spPW[1]) / sumWeight;
-    const float fusedPz = (Lpz * oldWeight + newWeight * spPW[2]) / sumWeight;
-    float fusedNx = nc[0] * oldWeight + newWeight * S.normX;
-    float fusedNy = nc[1] * oldWeight + newWeight * S.normY;
-    float fusedNz = nc[2] * oldWeight + newWeight * S.normZ;
-    const double newNormLength = (double)sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
-    fusedNx = (float)((double)fusedNx / newNormLength); fusedNy = (float)((double)fusedNy / newNormLength);
-    fusedNz = (float)((double)fusedNz / newNormLength);
-    float newNormW[3];
-    mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
-    hr.px = fusedPx; hr.py = fusedPy; hr.pz = fusedPz; hr.updateTimes = hr.updateTimes + 1; hr.lastUpdate = F.ref;
-    C.r = S.r; C.g = S.g; C.b = S.b;
-    C.nx = newNormW[0]; C.ny = newNormW[1]; C.nz = newNormW[2];
-    C.weight = sumWeight;
-    C.color = S.meanIntensity;
-    const float newSize = S.size * fabsf(S.meanDepth / (cameraF * S.viewCos));
-    if (newSize < C.size) C.size = newSize;
-    return 2;
-}
-
 // k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks).
 //   Phase A (streaming): each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records
 //   per lane.  The ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.
@@ -1093,7 +1023,7 @@ __device__ __forceinline__ int fuse_update(const FrameDev &F, float cameraF, con
 //   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
 // Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
 
-__global__ __launch_bounds__(FUSE_NT) void k_fuse_hv(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
+__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
     // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
     // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
     // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
@@ -1111,6 +1041,7 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse_hv(SfDev P, int slot, FrameDev
     const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
     const unsigned short *index = P.index + (size_t)slot * P.npx;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
+    const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     const int wv = threadIdx.x >> 6;
     for (long long bq = blockIdx.x; bq < nW; bq += gridDim.x) {
@@ -1147,7 +1078,23 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse_hv(SfDev P, int slot, FrameDev
             for (int k = 0; k < 4; k++) {
                 const long long i = i0 + k;
                 const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
-                state[k] = fuse_classify(P, F, x, y, z, (int)w[5 * k + 3], (int)w[5 * k + 4], hasSub && i < n, pzv[k], offD[k], offI[k]);
+                const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
+                float pc[4];
+                mul4(F.invPose, x, y, z, 1.0f, pc);
+                const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
+                const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+                const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+                const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
+                // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of
+                // the image either way
+                const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
+                const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+                int st = 0;
+                if (hasSub && i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+                state[k] = st; pzv[k] = pc[2];
+                const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+                offD[k] = (unsigned)pVc * (unsigned)P.dstride + (unsigned)pUc;   // images are far below 2^32 elements
+                offI[k] = (unsigned)(pVc * P.W + pUc);
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) { dep[k] = F.depthG()[offD[k]]; spi[k] = index[offI[k]]; }
@@ -1175,14 +1122,47 @@ __global__ __launch_bounds__(FUSE_NT) void k_fuse_hv(SfDev P, int slot, FrameDev
             // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
             // fourth dependent round trip on this latency-bound chain
             const msl_seed S = seeds[spIndex];
-            HotRec hr = M.hot[i];
+            const HotRec hr = M.hot[i];
             ColdRec C = M.cold[i];
             // common use of one field per load instruction (see phase A): all three records are in flight together
             asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
-            const int act = fuse_update(F, cameraF, S, hr, C);
-            if (act == 0) continue;
-            if (act == 1) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
-            M.hot[i] = hr;
+            const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
+            if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
+            if (S.viewCos < MAX_ANGLE_COS) continue;
+            float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
+            tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
+            if (pz < S.meanDepth - tolerateDiff) continue;
+            if (pz > S.meanDepth + tolerateDiff) continue;
+            float nc[3];
+            mul3(F.invPose, C.nx, C.ny, C.nz, nc);
+            const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
+            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
+            const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
+            const float oldWeight = C.weight;
+            const float newWeight = get_weight(S.meanDepth);
+            const float sumWeight = oldWeight + newWeight;
+            float spPW[4];
+            mul4(F.pose, S.posX, S.posY, S.posZ, 1.0f, spPW);
+            const float fusedPx = (Lpx * oldWeight + newWeight * spPW[0]) / sumWeight;
+            const float fusedPy = (Lpy * oldWeight + newWeight * spPW[1]) / sumWeight;
+            const float fusedPz = (Lpz * oldWeight + newWeight * spPW[2]) / sumWeight;
+            float fusedNx = nc[0] * oldWeight + newWeight * S.normX;
+            float fusedNy = nc[1] * oldWeight + newWeight * S.normY;
+            float fusedNz = nc[2] * oldWeight + newWeight * S.normZ;
+            const double newNormLength = (double)sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
+            fusedNx = (float)((double)fusedNx / newNormLength); fusedNy = (float)((double)fusedNy / newNormLength);
+            fusedNz = (float)((double)fusedNz / newNormLength);
+            float newNormW[3];
+            mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
+            HotRec Hn;
+            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = hr.updateTimes + 1; Hn.lastUpdate = ref;
+            C.r = S.r; C.g = S.g; C.b = S.b;
+            C.nx = newNormW[0]; C.ny = newNormW[1]; C.nz = newNormW[2];
+            C.weight = sumWeight;
+            C.color = S.meanIntensity;
+            const float newSize = S.size * fabsf(S.meanDepth / (cameraF * S.viewCos));
+            if (newSize < C.size) C.size = newSize;
+            M.hot[i] = Hn;
             M.cold[i] = C;
             fused[spIndex] = 1;
             nupd++;
@@ -1220,236 +1200,6 @@ __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const
 }
 __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
     M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
-}
-
-// =============================================================================================
-// Resident map, log-structured between synchronisation points
-// =============================================================================================
-// The reference's per-keyframe slot refill + tail compaction (SurfelMapping.cpp:366-391) only decides WHERE records live in
-// mvLocalSurfels; nothing in the fusion chain depends on a record's position.  Between two points at which the caller can observe
-// the map (msl_sf_sync and every accessor) the resident map is therefore kept as a log: a keyframe deletes in place
-// (updateTimes = 0, plus the keyframe number in delSeq) and appends the surfels the PREVIOUS keyframe spawned at the physical end
-// (tagged keyframe << 32 | seed in birth).  One launch per keyframe does everything; the dependent second kernel of a
-// literal implementation -- half of the serial chain -- is gone.  At a synchronisation point the host replays the reference's
-// refill / tail-move loop over record ids (a few integers per event) and one gather kernel puts the records into the exact
-// order the reference's vector would have.
-//
-// ls[0..3]  physical size at the start of launch seq (slot seq & 3)     ls[4..7]  records appended by launch seq (slot seq & 3)
-// ls[8]     number of per-workgroup updated counts written by the last launch
-// Streaming part: persistent single-wave workgroups.  Wave g of NW owns the sub-blocks (256 consecutive records) g, g + NW, ...
-// and runs them through a software pipeline, so that a wave always has one sub-block of hot records and one set of depth /
-// superpixel lookups in flight while it classifies another:
-//     classify(k) -> issue lookups(k) -> issue hot loads(k + 2) -> finish(k - 1): occlusion test, survivors to the wave's LDS list
-// Survivors (the few per cent that need the seed tests and the fusion) are taken off the list 64 at a time, one per lane.
-// A quarter of the waves of the former one-sub-block-per-wave launch keep the same data rate, and the batched superpixel /
-// ORB kernels running beside the map chain keep their occupancy.
-constexpr int SURV_CAP = 4 * SUB_ITEMS;   // one pass of four sub-blocks
-struct HotQ { uint4 q[5]; };                     // 4 hot records of one lane
-struct LookQ { float dep[4]; unsigned spi[4]; float pzv[4]; int state[4]; long long i0; };
-
-__device__ __forceinline__ void fuse_load_hot(const MapSoA &M, long long sb, long long nSub, HotQ &H) {
-    const long long i0 = (sb < nSub ? sb : 0) * SUB_ITEMS + 4 * (long long)threadIdx.x;   // (capacity is a multiple of 4096: in bounds)
-    const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);
-#pragma unroll
-    for (int j = 0; j < 5; j++) H.q[j] = hp[j];
-}
-__device__ __forceinline__ void fuse_classify_issue(const SfDev &P, const FrameDev &F, const unsigned short *index, long long sb, long long nSub,
-                                                    long long n, const HotQ &H, LookQ &L) {
-    const unsigned w[20] = {H.q[0].x, H.q[0].y, H.q[0].z, H.q[0].w, H.q[1].x, H.q[1].y, H.q[1].z, H.q[1].w, H.q[2].x, H.q[2].y,
-                            H.q[2].z, H.q[2].w, H.q[3].x, H.q[3].y, H.q[3].z, H.q[3].w, H.q[4].x, H.q[4].y, H.q[4].z, H.q[4].w};
-    const bool has = sb < nSub;
-    L.i0 = (has ? sb : 0) * SUB_ITEMS + 4 * (long long)threadIdx.x;
-    unsigned offD[4], offI[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
-        L.state[k] = fuse_classify(P, F, x, y, z, (int)w[5 * k + 3], (int)w[5 * k + 4], has && L.i0 + k < n, L.pzv[k], offD[k], offI[k]);
-    }
-    // all eight lookups leave together (lanes without an in-view surfel read some valid pixel): ONE dependent round trip
-#pragma unroll
-    for (int k = 0; k < 4; k++) { L.dep[k] = F.depthG()[offD[k]]; L.spi[k] = index[offI[k]]; }
-}
-
-__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, unsigned seq, const msl_surfel *prevCand,
-                                             const uint8_t *prevOk, const uint8_t *prevFused, unsigned nSpawn) {
-    __shared__ unsigned s_idx[SURV_CAP];
-    __shared__ unsigned short s_sp[SURV_CAP];
-    if (P.mapPrio) __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
-    const unsigned spv = (seq - 1) & 3u, sc = seq & 3u;
-    const long long n = (long long)P.ls[spv] + (long long)P.ls[4 + spv];   // physical size when this launch starts
-    const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS;
-    const unsigned NW = gridDim.x - nSpawn;                                   // streaming waves
-    const MapSoA &M = P.map;
-    const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
-    const unsigned short *index = P.index + (size_t)slot * P.npx;
-    uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
-    const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        P.ls[sc] = (unsigned)n;              // read by the next launch (and by the host at a synchronisation point)
-        P.ls[4 + ((seq + 1) & 3u)] = 0;      // the next launch's append counter
-        P.ls[8] = gridDim.x;                 // per-workgroup updated counts written by this launch
-    }
-    if (blockIdx.x >= NW) {
-        // The surfels keyframe seq-1 spawned (initializeSurfels, :285-331: candidate ok and seed not consumed by a fusion) enter the
-        // map now.  The reference had them in the vector before this keyframe's fusion, so they go through the same chain first.
-        const int s = (int)((blockIdx.x - NW) * 64 + threadIdx.x);
-        const bool spawn = s < P.nseeds && prevOk[s] && !prevFused[s];
-        HotRec hr{}; ColdRec C{};
-        bool del = false, upd = false;
-        if (spawn) {
-            const msl_surfel e = prevCand[s];
-            hr.px = e.px; hr.py = e.py; hr.pz = e.pz; hr.updateTimes = e.updateTimes; hr.lastUpdate = e.lastUpdate;
-            C.nx = e.nx; C.ny = e.ny; C.nz = e.nz; C.size = e.size; C.color = e.color; C.r = e.r; C.g = e.g; C.b = e.b; C.weight = e.weight;
-            float pzv; unsigned offD, offI;
-            const int st = fuse_classify(P, F, hr.px, hr.py, hr.pz, hr.updateTimes, hr.lastUpdate, true, pzv, offD, offI);
-            if (st == 1) { hr.updateTimes = 0; del = true; }
-            else if (st == 3) {
-                const float dep = F.depthG()[offD];
-                const unsigned spi = index[offI];
-                if ((double)pzv < (double)dep - 1.0) { hr.updateTimes = 0; del = true; }
-                else {
-                    const msl_seed S = seeds[spi];
-                    const int act = fuse_update(F, cameraF, S, hr, C);
-                    if (act == 1) { hr.updateTimes = 0; del = true; }
-                    else if (act == 2) { fused[spi] = 1; upd = true; }
-                }
-            }
-        }
-        const unsigned long long m = __ballot(spawn);
-        const unsigned tot = (unsigned)__popcll(m), ex = (unsigned)__popcll(m & ((1ull << threadIdx.x) - 1ull));
-        unsigned base = 0;
-        if (threadIdx.x == 0 && tot) base = atomicAdd(&P.ls[4 + sc], tot);
-        base = __shfl(base, 0, 64);
-        if (spawn) {
-            const unsigned long long pos = (unsigned long long)n + base + ex;
-            if (pos < P.cap) {
-                M.hot[pos] = hr; M.cold[pos] = C;
-                P.birth[pos] = ((unsigned long long)(seq - 1) << 32) | (unsigned)s;
-                P.delSeq[pos] = del ? seq : 0u;
-            } else P.ctr[5] = 20;   // capacity (the host sizes the map so that this cannot happen)
-        }
-        const unsigned nu = (unsigned)__popcll(__ballot(upd));
-        if (threadIdx.x == 0) P.blockUpd[blockIdx.x] = nu;
-        return;
-    }
-    const unsigned g = blockIdx.x;
-    unsigned nlist = 0, nupd = 0;
-    const unsigned long long ltMask = (1ull << threadIdx.x) - 1ull;
-    // Nothing but loads between the pipeline stages: records to delete and survivors both go to the wave's LDS list and are
-    // dealt with after the pass (stores or further loads in data-dependent numbers would make the in-flight count unknowable).
-    auto finish = [&](const LookQ &L) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const bool del = L.state[k] == 1 || (L.state[k] == 3 && (double)L.pzv[k] < (double)L.dep[k] - 1.0);
-            const bool keep = del || L.state[k] == 3;   // (state 2: an already deleted record stays a hole until the next synchronisation point)
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const unsigned e = nlist + (unsigned)__popcll(m & ltMask);
-                s_idx[e] = (unsigned)(L.i0 + k); s_sp[e] = del ? (unsigned short)IDX_NONE : (unsigned short)L.spi[k];
-            }
-            nlist += (unsigned)__popcll(m);
-        }
-    };
-    auto drain = [&]() {   // one list entry per lane and round
-        __builtin_amdgcn_wave_barrier();
-        for (unsigned e0 = 0; e0 < nlist; e0 += 64) {
-            const unsigned e = e0 + threadIdx.x;
-            const bool in = e < nlist;
-            const long long i = s_idx[in ? e : 0];
-            const unsigned spIndex = s_sp[in ? e : 0];
-            const bool del0 = spIndex == IDX_NONE;
-            // seed, hot record (just streamed: cache hit) and cold record in ONE round trip; the cold record of a surfel that fails the
-            // seed tests is read for nothing (36 B), which is cheaper than another dependent round trip
-            const msl_seed S = seeds[del0 ? 0u : spIndex];
-            HotRec hr = M.hot[i];
-            ColdRec C = M.cold[i];
-            asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
-            const int act = !in ? 0 : (del0 ? 1 : fuse_update(F, cameraF, S, hr, C));
-            if (act == 1) { M.hot[i].updateTimes = 0; P.delSeq[i] = seq; }
-            else if (act == 2) { M.hot[i] = hr; M.cold[i] = C; fused[spIndex] = 1; }
-            nupd += (unsigned)__popcll(__ballot(act == 2));
-        }
-        nlist = 0;
-        __builtin_amdgcn_wave_barrier();
-    };
-    // Four sub-blocks per pass as straight-line code (the host sizes the grid so that one pass covers the map): the compiler's
-    // wait-count insertion then knows exactly how many loads are in flight at every use, which it does not across a loop back edge.
-    HotQ Ha, Hb;
-    LookQ La, Lb;
-    for (long long sb = g; sb < nSub; sb += 4ll * NW) {
-        fuse_load_hot(M, sb, nSub, Ha);
-        fuse_load_hot(M, sb + NW, nSub, Hb);
-        fuse_classify_issue(P, F, index, sb, nSub, n, Ha, La);
-        fuse_load_hot(M, sb + 2ll * NW, nSub, Ha);
-        fuse_classify_issue(P, F, index, sb + NW, nSub, n, Hb, Lb);
-        fuse_load_hot(M, sb + 3ll * NW, nSub, Hb);
-        finish(La);
-        fuse_classify_issue(P, F, index, sb + 2ll * NW, nSub, n, Ha, La);
-        finish(Lb);
-        fuse_classify_issue(P, F, index, sb + 3ll * NW, nSub, n, Hb, Lb);
-        finish(La);
-        finish(Lb);
-        drain();
-    }
-    if (threadIdx.x == 0) P.blockUpd[blockIdx.x] = nupd;
-}
-
-// ---- synchronisation point: bring the log into the reference's order ------------------------------------------------------
-// The surfels the LAST keyframe spawned (they would have been appended by the next launch), unfused.
-__global__ __launch_bounds__(FUSE_NT) void k_spawn_pending(SfDev P, unsigned seq, const msl_surfel *prevCand, const uint8_t *prevOk,
-                                                           const uint8_t *prevFused) {
-    __shared__ unsigned s_wave[17];
-    __shared__ unsigned s_base;
-    const unsigned sc = seq & 3u, sn = (seq + 1) & 3u;
-    const unsigned long long n = (unsigned long long)P.ls[sc] + P.ls[4 + sc];
-    const int s = (int)(blockIdx.x * FUSE_NT + threadIdx.x);
-    const bool spawn = s < P.nseeds && prevOk[s] && !prevFused[s];
-    unsigned tot;
-    const unsigned ex = block_excl_scan(spawn ? 1u : 0u, s_wave, &tot);
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&P.ls[4 + sn], tot) : 0u;
-    __syncthreads();
-    if (!spawn) return;
-    const unsigned long long pos = n + s_base + ex;
-    if (pos < P.cap) {
-        store_surfel(P.map, (long long)pos, prevCand[s]);
-        P.birth[pos] = ((unsigned long long)seq << 32) | (unsigned)s;
-        P.delSeq[pos] = 0u;
-    } else P.ctr[5] = 20;
-}
-// Lists the holes of the log: (physical index, keyframe that deleted it; 0 = was already deleted when the log began)
-__global__ __launch_bounds__(256) void k_collect_holes(SfDev P, long long nPhys, unsigned *idxOut, unsigned *seqOut, unsigned *count) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= nPhys || P.map.hot[i].updateTimes != 0) return;
-    const unsigned j = atomicAdd(count, 1u);
-    idxOut[j] = (unsigned)i; seqOut[j] = P.delSeq[i];
-}
-__global__ __launch_bounds__(256) void k_soa_pick(MapSoA M, msl_surfel *tmp, const unsigned *src, long long m) {
-    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= m) return;
-    const HotRec h = M.hot[src[j]];
-    const ColdRec c = M.cold[src[j]];
-    msl_surfel e;
-    e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz;
-    e.size = c.size; e.color = c.color; e.r = c.r; e.g = c.g; e.b = c.b; e.weight = c.weight;
-    e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
-    tmp[j] = e;
-}
-__global__ __launch_bounds__(256) void k_soa_place(MapSoA M, const msl_surfel *tmp, const unsigned *dst, long long m) {
-    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (j < m) store_surfel(M, dst[j], tmp[j]);
-}
-__global__ void k_ls_begin(unsigned *ls, const long long *ctr) {
-    if (threadIdx.x < 16) ls[threadIdx.x] = (threadIdx.x == 0 || threadIdx.x == 9) ? (unsigned)ctr[0] : 0u;   // ls[9]: size when the log began
-}
-__global__ void k_ls_end(long long *ctr, long long n, long long K, long long D, long long nBefore, const unsigned *blockUpd, const unsigned *ls) {
-    __shared__ unsigned s_u;
-    if (threadIdx.x == 0) s_u = 0;
-    __syncthreads();
-    unsigned u = 0;
-    for (unsigned i = threadIdx.x; i < ls[8]; i += blockDim.x) u += blockUpd[i];
-    if (u) atomicAdd(&s_u, u);
-    __syncthreads();
-    if (threadIdx.x == 0) { ctr[0] = n; ctr[1] = K; ctr[2] = D; ctr[3] = s_u; ctr[4] = nBefore; ctr[6] = n; }
 }
 
 // Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
@@ -1839,15 +1589,9 @@ struct msl_sf {
     // up whatever has arrived, so the bound follows the real count a couple of batches late instead of forcing a pipeline drain
     // every capacity / nseeds keyframes
     static constexpr int NSNAP = 4;
-    unsigned *h_snap = nullptr; hipEvent_t snapEv[NSNAP] = {}; unsigned long long snapKf[NSNAP] = {}; bool snapBusy[NSNAP] = {};
+    long long *h_snap = nullptr; hipEvent_t snapEv[NSNAP] = {}; unsigned long long snapKf[NSNAP] = {}; bool snapBusy[NSNAP] = {};
     unsigned long long kfEnq = 0; int snapNext = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
-    // log-structured resident map (see k_fuse): state between two synchronisation points
-    unsigned *d_ls = nullptr, *d_delSeq = nullptr; unsigned long long *d_birth = nullptr;
-    bool lsDirty = false;        // keyframes were fused since the map was last brought into the reference's order
-    unsigned lsSeq = 0;          // launches since then
-    const msl_surfel *prevCand = nullptr; const uint8_t *prevOk = nullptr, *prevFused = nullptr;   // slot of the last keyframe enqueued
-    hipEvent_t evHead = nullptr; bool evHeadValid = false;   // first map launch of the last batch (it reads the previous batch's last slot)
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     KernelProfiler prof;
 };
@@ -1861,7 +1605,6 @@ void set_map_ptrs(msl_sf *h) {
     M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
-    h->dev.ls = h->d_ls; h->dev.delSeq = h->d_delSeq; h->dev.birth = h->d_birth;
 }
 
 int sync_all(msl_sf *h) {
@@ -1873,8 +1616,7 @@ int sync_all(msl_sf *h) {
 // (Re)allocate the resident map for `cap` surfels, preserving the first `keep` entries.
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
-    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nds = nullptr;
-    unsigned long long *nbi = nullptr;
+    float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
@@ -1883,8 +1625,6 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
-        MSL_HIP_TRY(hipMalloc(&nds, sizeof(unsigned) * cap));
-        MSL_HIP_TRY(hipMalloc(&nbi, sizeof(unsigned long long) * cap));
         if (keep && h->d_mapStore) {
             int rc = sync_all(h);
             if (rc != MSL_OK) return rc;
@@ -1894,14 +1634,18 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         return MSL_OK;
     };
     const int arc = attempt();
-    auto F = [](auto *p) { if (p) (void)hipFree(p); };
     if (arc != MSL_OK) {   // nothing of a failed attempt stays allocated; the old map is untouched
-        F(nstore); F(nbs); F(nbu); F(ndl); F(nso); F(nds); F(nbi);
+        if (nstore) (void)hipFree(nstore);
+        if (nbs) (void)hipFree(nbs);
+        if (nbu) (void)hipFree(nbu);
+        if (ndl) (void)hipFree(ndl);
+        if (nso) (void)hipFree(nso);
         return arc;
     }
-    F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_delSeq); F(h->d_birth);
-    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso;
-    h->d_delSeq = nds; h->d_birth = nbi; h->mapCap = cap;
+    if (h->d_mapStore) {
+        (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
+    }
+    h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->mapCap = cap;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -1949,112 +1693,8 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     return MSL_OK;
 }
 
-int ensure_aos(msl_sf *h, size_t n) {
-    if (n > h->aosCap) {
-        if (h->d_aos) (void)hipFree(h->d_aos);
-        h->d_aos = nullptr; h->aosCap = 0;
-        MSL_HIP_TRY(hipMalloc(&h->d_aos, sizeof(msl_surfel) * n));
-        h->aosCap = n;
-    }
-    return MSL_OK;
-}
-
-// Synchronisation point of the log-structured resident map (both streams idle): append what the last keyframe spawned, replay the
-// reference's per-keyframe refill / tail-move loop (SurfelMapping.cpp:366-391) over record ids, gather the records into that order.
-int ls_flush(msl_sf *h) {
-    if (!h->lsDirty) return MSL_OK;
-    hipStream_t s = h->mapStream;
-    SfDev &D = h->dev;
-    const unsigned seq = h->lsSeq;
-    const unsigned nSpawnWg = (unsigned)((D.nseeds + FUSE_NT - 1) / FUSE_NT);
-    if (seq && h->prevCand) hipLaunchKernelGGL(k_spawn_pending, dim3(nSpawnWg), dim3(FUSE_NT), 0, s, D, seq, h->prevCand, h->prevOk, h->prevFused);
-    unsigned ls[16];
-    MSL_HIP_TRY(hipMemcpyAsync(ls, h->d_ls, sizeof(ls), hipMemcpyDeviceToHost, s));
-    MSL_HIP_TRY(hipStreamSynchronize(s));
-    const size_t n0 = ls[9];
-    const size_t nPhys = std::min<size_t>((size_t)ls[seq & 3] + ls[4 + (seq & 3)] + ls[4 + ((seq + 1) & 3)], h->mapCap);
-    // holes and births of the log
-    std::vector<unsigned> holeIdx, holeSeq;
-    std::vector<unsigned long long> birth(nPhys > n0 ? nPhys - n0 : 0);
-    {
-        unsigned *d_count = h->d_ls + 12;   // scratch word of the log state
-        MSL_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned), s));
-        if (nPhys) hipLaunchKernelGGL(k_collect_holes, dim3((unsigned)((nPhys + 255) / 256)), dim3(256), 0, s, D, (long long)nPhys, h->d_delList, h->d_srcOf, d_count);
-        unsigned cnt = 0;
-        MSL_HIP_TRY(hipMemcpyAsync(&cnt, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-        MSL_HIP_TRY(hipStreamSynchronize(s));
-        holeIdx.resize(cnt); holeSeq.resize(cnt);
-        if (cnt) {
-            MSL_HIP_TRY(hipMemcpyAsync(holeIdx.data(), h->d_delList, sizeof(unsigned) * cnt, hipMemcpyDeviceToHost, s));
-            MSL_HIP_TRY(hipMemcpyAsync(holeSeq.data(), h->d_srcOf, sizeof(unsigned) * cnt, hipMemcpyDeviceToHost, s));
-        }
-        if (!birth.empty()) MSL_HIP_TRY(hipMemcpyAsync(birth.data(), h->d_birth + n0, sizeof(unsigned long long) * birth.size(), hipMemcpyDeviceToHost, s));
-        MSL_HIP_TRY(hipStreamSynchronize(s));
-    }
-    // events per keyframe: holes (by the keyframe that deleted them; records that were deleted before the log began count
-    // for its first keyframe, as the reference lists every updateTimes == 0 entry), births (in seed order)
-    const unsigned nkf = seq;
-    std::vector<std::vector<unsigned>> holesOf(nkf + 1);
-    for (size_t j = 0; j < holeIdx.size(); j++) {
-        unsigned k = holeSeq[j] == 0 ? 1u : holeSeq[j];
-        if (k > nkf) k = nkf;
-        if (nkf) holesOf[k].push_back(holeIdx[j]);
-    }
-    std::vector<std::pair<unsigned long long, unsigned>> births(birth.size());   // (keyframe << 32 | seed, physical index)
-    for (size_t j = 0; j < birth.size(); j++) births[j] = {birth[j], (unsigned)(n0 + j)};
-    std::sort(births.begin(), births.end());
-    // The reference's vector as a list of record ids, kept sparse: position p < n0 holds record p unless `at` says otherwise
-    // (positions >= n0 always have an entry); `where` is the inverse for records that moved.  Cost: O(events), not O(map).
-    std::unordered_map<unsigned, unsigned> at, where;
-    size_t len = n0;
-    auto rec_at = [&](unsigned p) { auto it = at.find(p); return it != at.end() ? it->second : p; };
-    auto pos_of = [&](unsigned r) { auto it = where.find(r); return it != where.end() ? it->second : r; };
-    size_t bi = 0;
-    long long lastK = 0, lastD = 0, lastBefore = (long long)n0;
-    std::vector<unsigned> holes;
-    for (unsigned k = 1; k <= nkf; k++) {
-        holes.clear();
-        for (unsigned pidx : holesOf[k]) holes.push_back(pos_of(pidx));
-        std::sort(holes.begin(), holes.end());
-        lastBefore = (long long)len; lastD = (long long)holes.size(); lastK = 0;
-        for (; bi < births.size() && (unsigned)(births[bi].first >> 32) == k; bi++, lastK++) {   // new surfel -> largest hole, else appended
-            const unsigned rec = births[bi].second;
-            const unsigned p = holes.empty() ? (unsigned)len++ : holes.back();
-            if (!holes.empty()) holes.pop_back();
-            at[p] = rec; where[rec] = p;
-        }
-        while (!holes.empty()) {   // local[deletedIndex.back()] = local.back(); both pop
-            const unsigned last = (unsigned)(len - 1), rec = rec_at(last), p = holes.back();
-            at[p] = rec; where[rec] = p;
-            at.erase(last);
-            holes.pop_back(); len--;
-        }
-    }
-    const size_t n = len;
-    std::vector<unsigned> src, dst;
-    for (const auto &kv : at)
-        if (kv.first < n && kv.second != kv.first) { dst.push_back(kv.first); src.push_back(kv.second); }
-    if (!src.empty()) {   // gather the sources first: a source position may itself be a destination
-        const size_t m = src.size();
-        int rc = ensure_aos(h, m);
-        if (rc != MSL_OK) return rc;
-        MSL_HIP_TRY(hipMemcpyAsync(h->d_srcOf, src.data(), sizeof(unsigned) * m, hipMemcpyHostToDevice, s));
-        MSL_HIP_TRY(hipMemcpyAsync(h->d_delList, dst.data(), sizeof(unsigned) * m, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_soa_pick, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, D.map, h->d_aos, h->d_srcOf, (long long)m);
-        hipLaunchKernelGGL(k_soa_place, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, D.map, h->d_aos, h->d_delList, (long long)m);
-        MSL_HIP_TRY(hipStreamSynchronize(s));   // src / dst go out of scope
-    }
-    hipLaunchKernelGGL(k_ls_end, dim3(1), dim3(256), 0, s, h->d_ctr, (long long)n, lastK, lastD, lastBefore, h->d_blockUpd, h->d_ls);
-    MSL_HIP_TRY(hipStreamSynchronize(s));
-    h->lsDirty = false; h->lsSeq = 0; h->prevCand = nullptr; h->prevOk = h->prevFused = nullptr;
-    return MSL_OK;
-}
-
 int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
-    MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
-    int rc = ls_flush(h);
-    if (rc != MSL_OK) return rc;
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 16, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
@@ -2105,10 +1745,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         for (int i = 0; i < msl_sf::NSNAP; i++)
             if (h->snapBusy[i] && hipEventQuery(h->snapEv[i]) == hipSuccess) {
                 h->snapBusy[i] = false;
-                const unsigned *sn = h->h_snap + 8 * i;   // ls[0..7] as of some recent launch
-                size_t phys = 0;
-                for (int q = 0; q < 4; q++) phys = std::max(phys, (size_t)sn[q] + (size_t)sn[4 + q]);
-                const size_t cand = phys + (size_t)(h->kfEnq - h->snapKf[i] + 1) * (size_t)D.nseeds;   // size then + what was enqueued since
+                const size_t cand = (size_t)h->h_snap[i] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
                 if (cand < h->liveBound) h->liveBound = cand;
             }
         if (h->liveBound + need > h->mapCap) {
@@ -2127,7 +1764,6 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     const int set = (int)(h->batchNo & 1), slot0 = set * h->maxBatch;
     hipStream_t sp = h->preStream, sm = h->mapStream;
     if (h->evMapValid[set] && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evMap[set], 0));   // the set's previous user is done
-    if (h->evHeadValid && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evHead, 0));        // ... and so is the launch that appended its last keyframe's surfels
     D.gstride = gs; D.gbytes = gs * (size_t)(H - 1) + W; D.dstride = ds / 4; D.mstride = ms / 4;
     // bytes actually present in the caller's buffers: the last row carries no stride padding
     const size_t gb = gs * (size_t)(H - 1) + W, db = ds * (size_t)(H - 1) + (size_t)W * 4, mb = ms * (size_t)(H / 2 - 1) + (size_t)(W / 2) * 4;
@@ -2205,40 +1841,19 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
-    // k_fuse's grid covers the host-side upper bound of the map size (the kernel loops if the map is larger): at 1 M surfels half
+    // k_fuse's grid covers the host-side upper bound of the live count (the kernel loops if the map is larger): at 1 M surfels half
     // of the former fixed 4096 workgroups had nothing to do
     const size_t boundLive = compact ? h->liveBound : h->mapCap;
-    static const size_t gridCap = getenv("MSL_FUSE_GRID") ? (size_t)atoi(getenv("MSL_FUSE_GRID")) : 65536;
-    const unsigned fuseGrid = (unsigned)std::min<size_t>(gridCap, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
-    if (compact) {
-        if (!h->lsDirty) {   // the log begins: the map is in the reference's order, ctr[0] records
-            const size_t n0 = std::min(h->liveBound, h->mapCap);   // >= the current size
-            if (n0) MSL_HIP_TRY(hipMemsetAsync(h->d_delSeq, 0, sizeof(unsigned) * n0, sm));
-            hipLaunchKernelGGL(k_ls_begin, dim3(1), dim3(64), 0, sm, h->d_ls, h->d_ctr);
-            h->lsDirty = true; h->lsSeq = 0; h->prevCand = nullptr;
-        }
-        const unsigned spawnWg = (unsigned)((D.nseeds + 63) / 64);
-        // one pass of four sub-blocks per wave covers the map; at least 1024 waves (one per SIMD)
-        static const unsigned waveMin = getenv("MSL_FUSE_WAVES_TOTAL") ? (unsigned)atoi(getenv("MSL_FUSE_WAVES_TOTAL")) : 1024u;
-        const size_t subBound = h->liveBound / SUB_ITEMS + 1;
-        const unsigned streamWg = (unsigned)std::min<size_t>(65536, std::max<size_t>(waveMin, ((subBound + 3) / 4 + 255) & ~(size_t)255));
-        for (int f = 0; f < n; f++) {
-            const unsigned seq = ++h->lsSeq;
-            const unsigned ns = h->prevCand ? spawnWg : 0u;
-            LAUNCH(SK_FUSE, sm, k_fuse, dim3(streamWg + ns), dim3(64), P, f, h->h_frames[slot0 + f], seq, h->prevCand, h->prevOk, h->prevFused, ns);
-            const size_t so = (size_t)(slot0 + f) * D.nseeds;
-            h->prevCand = D.cand + so; h->prevOk = D.candOk + so; h->prevFused = D.fused + so;
-            if (f == 0 && sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evHead, sm)); h->evHeadValid = true; }
-        }
-    } else {
-        LAUNCH(SK_FUSE, sm, k_fuse_hv, dim3(fuseGrid), dim3(FUSE_NT), P, 0, h->h_frames[slot0]);
-        LAUNCH(SK_COMPACT, sm, k_compact, dim3(1), dim3(256), P, 0, 1);   // ordered list of the new surfels
+    const unsigned fuseGrid = (unsigned)std::min<size_t>(65536, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
+    for (int f = 0; f < n; f++) {
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f]);
+        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
-    if (compact && h->h_snap) {   // snapshot of the log state after this batch (picked up by a later call, never waited for)
+    if (compact && h->h_snap) {   // snapshot of the live count after this batch (picked up by a later call, never waited for)
         const int i = h->snapNext;
         if (!h->snapBusy[i]) {
-            MSL_HIP_TRY(hipMemcpyAsync(h->h_snap + 8 * i, h->d_ls, sizeof(unsigned) * 8, hipMemcpyDeviceToHost, sm));
+            MSL_HIP_TRY(hipMemcpyAsync(&h->h_snap[i], h->d_ctr, sizeof(long long), hipMemcpyDeviceToHost, sm));
             MSL_HIP_TRY(hipEventRecord(h->snapEv[i], sm));
             h->snapKf[i] = h->kfEnq; h->snapBusy[i] = true; h->snapNext = (i + 1) % msl_sf::NSNAP;
         }
@@ -2270,10 +1885,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         int lo = 0, hi = 0;
         ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&h->preStream, hipStreamNonBlocking, lo) == hipSuccess;
-        const char *mp = getenv("MSL_MAP_STREAM_PRIO");
-        const int mprio = mp && !strcmp(mp, "lo") ? lo : (mp && !strcmp(mp, "mid") ? (lo + hi) / 2 : hi);
-        ok = ok && hipStreamCreateWithPriority(&h->mapStream, hipStreamNonBlocking, mprio) == hipSuccess;
-        D.mapPrio = getenv("MSL_MAP_WAVE_PRIO") ? atoi(getenv("MSL_MAP_WAVE_PRIO")) : 1;
+        ok = ok && hipStreamCreateWithPriority(&h->mapStream, hipStreamNonBlocking, hi) == hipSuccess;
     }
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreateWithFlags(&h->evPre[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->evMap[i], hipEventDisableTiming) == hipSuccess &&
@@ -2281,9 +1893,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
-    ok = ok && hipHostMalloc(&h->h_snap, sizeof(unsigned) * 8 * msl_sf::NSNAP) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_ls, sizeof(unsigned) * 16) == hipSuccess && hipMemset(h->d_ls, 0, sizeof(unsigned) * 16) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&h->evHead, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipHostMalloc(&h->h_snap, sizeof(long long) * msl_sf::NSNAP) == hipSuccess;
     for (int i = 0; i < msl_sf::NSNAP && ok; i++) ok = hipEventCreateWithFlags(&h->snapEv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
@@ -2315,11 +1925,10 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_ls); F(h->d_delSeq); F(h->d_birth); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_snap) (void)hipHostFree(h->h_snap);
     for (int i = 0; i < msl_sf::NSNAP; i++) if (h->snapEv[i]) (void)hipEventDestroy(h->snapEv[i]);
-    if (h->evHead) (void)hipEventDestroy(h->evHead);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
     delete h;
@@ -2338,7 +1947,7 @@ int msl_sf_set_stream(msl_sf *h, void *hip_stream) {
 int msl_sf_set_batch_capacity(msl_sf *h, int max_frames) {
     if (!h || max_frames < 1 || max_frames > 4096) { set_error("msl_sf_set_batch_capacity: invalid argument"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));
-    int rc = read_ctr(h);   // (the log refers to the slot buffers)
+    int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
     if (max_frames == h->maxBatch) return MSL_OK;
     return alloc_slots(h, max_frames);
@@ -2361,12 +1970,21 @@ int msl_sf_map_reserve(msl_sf *h, size_t capacity) {
     return map_realloc(h, capacity, (size_t)h->h_ctr[0]);
 }
 
+static int ensure_aos(msl_sf *h, size_t n) {
+    if (n > h->aosCap) {
+        if (h->d_aos) (void)hipFree(h->d_aos);
+        h->d_aos = nullptr; h->aosCap = 0;
+        MSL_HIP_TRY(hipMalloc(&h->d_aos, sizeof(msl_surfel) * n));
+        h->aosCap = n;
+    }
+    return MSL_OK;
+}
+
 int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     if (!h || (n && !host)) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
-    h->lsDirty = false; h->lsSeq = 0; h->prevCand = nullptr;   // the uploaded vector replaces the map, pending log included
     if (n + (size_t)h->dev.nseeds > h->mapCap) {
         rc = map_realloc(h, n + n / 4 + 4 * (size_t)h->dev.nseeds, 0);
         if (rc != MSL_OK) return rc;

@@ -1,0 +1,34 @@
+"""Superpixel stage alone: per-kernel event timings (tiny map)."""
+import sys, os, time, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from manhattanslam_amd import SurfelFusion, synth, SURFEL_DTYPE
+I = synth.TUM1
+F = 32
+frames = [synth.surfel_frame(f) for f in range(F)]
+grays = np.stack([synth.orb_frame(synth.ORB_SEED + f) for f in range(F)]); depths = np.stack([f[1] for f in frames]); member = frames[0][2]
+poses = [f[3] for f in frames]
+sf = SurfelFusion(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+sf.set_batch_capacity(F); sf.map_reserve(2200000)
+sf.map_upload(synth.surfel_map(1000, ref=0, seed=11, min_update_times=5).astype(SURFEL_DTYPE))
+dg, dd, dm = torch.from_numpy(grays).cuda(), torch.from_numpy(depths).cuda(), torch.from_numpy(member).cuda()
+k = [0]
+def step():
+    sf.fuse_resident_batch(np.arange(k[0], k[0] + F), dg, dd, dm, poses, device=True, member_shared=True); k[0] += F
+for _ in range(3): step()
+sf.sync()
+names = sf.kernel_names()
+tot = 0
+for nm in names:
+    if nm.startswith("(") or nm in ("copy", "k_convert"): continue
+    sf.profile_enable(1 << names.index(nm))
+    t0 = time.perf_counter()
+    for _ in range(8): step()
+    sf.sync()
+    dt = time.perf_counter() - t0
+    ms, nl = sf.profile_read()[nm]
+    per_frame = ms * 1e3 / (8 * F)
+    tot += per_frame
+    print(f"{nm:18s} launches {nl:4d} avg {ms*1e3/max(nl,1):8.2f} us  per keyframe {per_frame:6.2f} us   (run {dt/(8*F)*1e6:.1f} us/kf)")
+print("sum per keyframe", round(tot, 2))
