@@ -282,6 +282,12 @@ MSL_API int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_s
 MSL_API int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
                                       int height, int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
                                       const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
+/* The host stage of msl_peac_membership_batch alone (graph initialisation, clustering, erosion, region growing; persistent worker threads, one
+ * frame per thread at a time), on block fits the caller already has (blocks: HOST, [n_frames][Nh * Nw] as msl_peac_block_fit returns them) and the
+ * HOST depth images they came from.  No device is touched: this is the part of the extractor that is sequential by construction. */
+MSL_API int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
+                                            int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                            const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
 
 /* ---- widening, SURVEY.md 8(f) rank 3: Hamming matching by projection, the next consumer of the ORB descriptors ----
  * msl_match_by_projection_batch: n_pairs independent calls of

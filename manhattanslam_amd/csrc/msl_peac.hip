@@ -29,6 +29,13 @@
 #include <mutex>
 #include <queue>
 #include <thread>
+#include <functional>
+#include <condition_variable>
+#include <atomic>
+#include <memory>
+#include <sched.h>
+#include <cstring>
+#include <cstdio>
 #include <vector>
 
 namespace {
@@ -57,7 +64,10 @@ __host__ __device__ inline double hypot_pos(double x, double y) {   // Eigen::nu
 // Eigen::SelfAdjointEigenSolver<Matrix3d>::compute as LA::eig33sym uses it: s[0] <= s[1] <= s[2], V[:][i] the eigenvector of s[i].
 // (lower triangle scaled by its largest coefficient, closed-form 3x3 Householder tridiagonalisation, implicit symmetric QR with
 // Wilkinson shift and the 2-epsilon deflation test, eigenvalues sorted increasingly with their vectors)
-__host__ __device__ inline void eig33sym(const double K[3][3], double s[3], double V[3][3]) {
+// VECTORS = false leaves out the accumulation of the rotations (q never feeds back into the diagonal / sub-diagonal updates, so the eigenvalues are the
+// same bits either way): the clustering only needs the smallest eigenvalue of every candidate merge and the vectors of the one it accepts.
+template <bool VECTORS>
+__host__ __device__ inline void eig33sym_t(const double K[3][3], double s[3], double V[3][3]) {
     double a00 = K[0][0], a10 = K[1][0], a11 = K[1][1], a20 = K[2][0], a21 = K[2][1], a22 = K[2][2];
     double scale = fmax(fmax(fmax(fabs(a00), fabs(a10)), fmax(fabs(a11), fabs(a20))), fmax(fabs(a21), fabs(a22)));
     if (scale == 0) scale = 1;
@@ -75,7 +85,7 @@ __host__ __device__ inline void eig33sym(const double K[3][3], double s[3], doub
         const double qq = 2.0 * m01 * a21 + m02 * (a22 - a11);
         d1 = a11 + m02 * qq; d2 = a22 - m02 * qq;
         e0 = beta; e1 = a21 - m01 * qq;
-        q[1][1] = m01; q[1][2] = m02; q[2][1] = m02; q[2][2] = -m01;
+        if (VECTORS) { q[1][1] = m01; q[1][2] = m02; q[2][1] = m02; q[2][2] = -m01; }
     }
     double dg[3] = {d0, d1, d2}, sb[2] = {e0, e1};
     int end = 2, start = 0, iter = 0;
@@ -110,11 +120,12 @@ __host__ __device__ inline void eig33sym(const double K[3][3], double s[3], doub
             if (k > start) sb[k - 1] = c * sb[k - 1] - sn * z;
             x = sb[k];
             if (k < end - 1) { z = -sn * sb[k + 1]; sb[k + 1] = c * sb[k + 1]; }
-            for (int r = 0; r < 3; r++) {
-                const double xi = q[r][k], yi = q[r][k + 1];
-                q[r][k] = c * xi - sn * yi;
-                q[r][k + 1] = sn * xi + c * yi;
-            }
+            if (VECTORS)
+                for (int r = 0; r < 3; r++) {
+                    const double xi = q[r][k], yi = q[r][k + 1];
+                    q[r][k] = c * xi - sn * yi;
+                    q[r][k + 1] = sn * xi + c * yi;
+                }
         }
     }
     for (int i = 0; i < 2; ++i) {   // selection sort, columns follow
@@ -122,12 +133,13 @@ __host__ __device__ inline void eig33sym(const double K[3][3], double s[3], doub
         for (int j = 1; j < 3 - i; j++) if (dg[i + j] < dg[i + k]) k = j;
         if (k > 0) {
             const double t = dg[i]; dg[i] = dg[k + i]; dg[k + i] = t;
-            for (int r = 0; r < 3; r++) { const double u = q[r][i]; q[r][i] = q[r][k + i]; q[r][k + i] = u; }
+            if (VECTORS) for (int r = 0; r < 3; r++) { const double u = q[r][i]; q[r][i] = q[r][k + i]; q[r][k + i] = u; }
         }
     }
     for (int i = 0; i < 3; i++) s[i] = dg[i] * scale;
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) V[r][c] = q[r][c];
+    if (VECTORS) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) V[r][c] = q[r][c];
 }
+__host__ __device__ inline void eig33sym(const double K[3][3], double s[3], double V[3][3]) { eig33sym_t<true>(K, s, V); }
 
 // ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183)
 __host__ __device__ inline void plane_fit(const msl_peac_stats &st, double center[3], double normal[3], double &mse, double &curvature) {
@@ -143,6 +155,18 @@ __host__ __device__ inline void plane_fit(const msl_peac_stats &st, double cente
     normal[0] = sgn > 0 ? V[0][0] : -V[0][0]; normal[1] = sgn > 0 ? V[1][0] : -V[1][0]; normal[2] = sgn > 0 ? V[2][0] : -V[2][0];
     mse = sv[0] * sc;
     curvature = sv[0] / (sv[0] + sv[1] + sv[2]);
+}
+
+// the MSE plane_fit would report, without centre / normal / curvature (the same K, the same eigenvalue bits)
+__host__ __device__ inline double plane_mse(const msl_peac_stats &st) {
+    const double sc = ((double)1.0) / st.N;
+    double K[3][3] = {{st.sxx - st.sx * st.sx * sc, st.sxy - st.sx * st.sy * sc, st.sxz - st.sx * st.sz * sc},
+                      {0, st.syy - st.sy * st.sy * sc, st.syz - st.sy * st.sz * sc},
+                      {0, 0, st.szz - st.sz * st.sz * sc}};
+    K[1][0] = K[0][1]; K[2][0] = K[0][2]; K[2][1] = K[1][2];
+    double sv[3];
+    eig33sym_t<false>(K, sv, nullptr);
+    return sv[0] * sc;
 }
 
 // z of cloud vertex (row, col): (double)depth(2 row, 2 col) * depthMapFactor (src/PlaneExtractor.cpp:64)
@@ -252,25 +276,28 @@ struct Node {
     std::vector<int> nbs;   // adjacent node ids, ascending (= the reference's std::set<PlaneSeg*> with addresses pinned to creation order)
 };
 
-class FrameSegmenter {
+// One object per worker thread, reused for every frame that thread segments: all containers keep their capacity, so the steady state allocates
+// nothing (64 threads that each mmap / munmap a few hundred KB per frame serialise on the process's address-space lock).
+class alignas(128) FrameSegmenter {   // own cache lines: the vectors' end pointers inside the object change on every push
 public:
-    FrameSegmenter(const msl_peac_params &prm, const uint16_t *halfDepth /* [ch][cw] raw depth of the cloud vertices */, int cw, int ch, float fx, float fy, float cx,
-                   float cy, float factor)
-        : T{prm}, img_(halfDepth), W(cw), H(ch), fx_(fx), fy_(fy), cx_(cx), cy_(cy), factor_(factor), winW(prm.window_w),
-          winH(prm.window_h), Nw(cw / prm.window_w), Nh(ch / prm.window_h) {}
+    void configure(const msl_peac_params &prm, const uint16_t *halfDepth /* [ch][cw] raw depth of the cloud vertices */, int cw, int ch, float fx, float fy,
+                   float cx, float cy, float factor) {
+        T.p = prm; img_ = halfDepth; W = cw; H = ch; fx_ = fx; fy_ = fy; cx_ = cx; cy_ = cy; factor_ = factor;
+        winW = prm.window_w; winH = prm.window_h; Nw = cw / prm.window_w; Nh = ch / prm.window_h;
+    }
 
     // returns the number of extracted planes; member[H * W] receives PlaneFitter::membershipImg
     int run(const msl_peac_block *blocks, int32_t *member) {
-        const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
+        const char *tenv = getenv("MSL_PEAC_TIMING");
+        const bool timing = tenv && atoi(tenv) >= 2;
         auto now = []() { return std::chrono::steady_clock::now(); };
         auto t0 = now();
         parent_.resize((size_t)Nw * Nh); setSize_.assign((size_t)Nw * Nh, 1);
         for (size_t i = 0; i < parent_.size(); i++) parent_[i] = (int)i;
-        nodes_.clear(); nodes_.reserve((size_t)Nw * Nh * 2);
-        Heap heap{MseGreater{this}};
-        build_graph(blocks, heap);
+        nNodes_ = 0; planes_.clear(); growQ_.clear(); heap_.clear();
+        build_graph(blocks);
         auto t1 = now();
-        cluster(heap);
+        cluster();
         auto t2 = now();
         member_ = member;
         std::fill(member, member + (size_t)W * H, -1);
@@ -278,7 +305,7 @@ public:
         auto t3 = now();
         if (timing) {
             auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-            fprintf(stderr, "[msl_peac] graph %ld us, cluster %ld us (%zu nodes), refine %ld us (queue %zu)\n", us(t0, t1), us(t1, t2), nodes_.size(), us(t2, t3), growQ_.size());
+            fprintf(stderr, "[msl_peac] graph %ld us, cluster %ld us (%zu nodes), refine %ld us (queue %zu)\n", us(t0, t1), us(t1, t2), (size_t)nNodes_, us(t2, t3), growQ_.size());
         }
         return (int)planes_.size();
     }
@@ -288,13 +315,26 @@ private:
         const FrameSegmenter *f;
         bool operator()(int a, int b) const { return f->nodes_[b].mse < f->nodes_[a].mse; }
     };
-    typedef std::priority_queue<int, std::vector<int>, MseGreater> Heap;
+    // std::priority_queue<int, std::vector<int>, MseGreater> spelled out (push_heap / pop_heap on a member vector: the same sequence of
+    // comparisons, hence the same order among equal keys, without a fresh container per run)
+    std::vector<int> heap_;
+    void heap_push(int id) { heap_.push_back(id); std::push_heap(heap_.begin(), heap_.end(), MseGreater{this}); }
+    int heap_pop() { std::pop_heap(heap_.begin(), heap_.end(), MseGreater{this}); const int id = heap_.back(); heap_.pop_back(); return id; }
 
     Thresholds T;
-    const uint16_t *img_;
-    int W, H; float fx_, fy_, cx_, cy_, factor_;
-    int winW, winH, Nw, Nh;
-    std::vector<Node> nodes_;
+    const uint16_t *img_ = nullptr;
+    int W = 0, H = 0; float fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0, factor_ = 0;
+    int winW = 0, winH = 0, Nw = 0, Nh = 0;
+    std::vector<Node> nodes_;                 // node pool: [0, nNodes_) are live; the rest keep their neighbour vectors' capacity for the next frame
+    int nNodes_ = 0;
+    std::vector<int> G_, u_, oldPlanes_, relabel_;
+    std::vector<char> validPlane_;
+    std::vector<float> distMap_;
+    int add_node(const Node &src) {
+        if ((size_t)nNodes_ == nodes_.size()) nodes_.emplace_back();
+        nodes_[nNodes_] = src;                // (src.nbs is empty: the slot's vector is cleared, not reallocated)
+        return nNodes_++;
+    }
     std::vector<int> parent_, setSize_;       // disjoint set over the windows (DisjointSet.hpp)
     std::vector<int> planes_;                 // extractedPlanes, node ids
     std::vector<int> blkMap_;
@@ -314,15 +354,16 @@ private:
     void connect(int a, int b) { link_one(nodes_[a].nbs, b); link_one(nodes_[b].nbs, a); }
     void isolate(int a) { for (int nb : nodes_[a].nbs) unlink_one(nodes_[nb].nbs, a); nodes_[a].nbs.clear(); }
 
-    void build_graph(const msl_peac_block *blocks, Heap &heap) {
-        std::vector<int> G((size_t)Nw * Nh, -1);   // node id of an accepted window
+    void build_graph(const msl_peac_block *blocks) {
+        std::vector<int> &G = G_;   // node id of an accepted window
+        G.assign((size_t)Nw * Nh, -1);
         for (int b = 0; b < Nw * Nh; b++) {
             const msl_peac_block &B = blocks[b];
             Node nd;
             nd.st = B.stats; nd.mse = B.mse; nd.curvature = B.curvature; nd.rid = b; nd.nouse = B.stats.nouse != 0; nd.N = nd.nouse ? 0 : B.stats.N;
             for (int k = 0; k < 3; k++) { nd.center[k] = B.center[k]; nd.normal[k] = B.normal[k]; }
-            nodes_.push_back(nd);
-            if (nd.mse < T.t_mse_init(nd.center[2]) && !nd.nouse) { G[b] = b; heap.push(b); }
+            add_node(nd);
+            if (nd.mse < T.t_mse_init(nd.center[2]) && !nd.nouse) { G[b] = b; heap_push(b); }
         }
         // edges between horizontally / vertically adjacent accepted windows whose two outer neighbours agree in normal (:849-927)
         auto sweep = [&](int outerN, int innerN, int outerStride, int innerStride) {
@@ -342,6 +383,13 @@ private:
         sweep(Nw, Nh, 1, Nw);
     }
 
+    double merged_mse(int a, int b) const {
+        msl_peac_stats t;
+        const msl_peac_stats &x = nodes_[a].st, &y = nodes_[b].st;
+        t.sx = x.sx + y.sx; t.sy = x.sy + y.sy; t.sz = x.sz + y.sz; t.sxx = x.sxx + y.sxx; t.syy = x.syy + y.syy; t.szz = x.szz + y.szz;
+        t.sxy = x.sxy + y.sxy; t.syz = x.syz + y.syz; t.sxz = x.sxz + y.sxz; t.N = x.N + y.N; t.nouse = 0;
+        return plane_mse(t);
+    }
     Node merged_node(int a, int b) const {   // PlaneSeg(pa, pb) (AHCPlaneSeg.hpp:299-322)
         Node nd;
         const msl_peac_stats &x = nodes_[a].st, &y = nodes_[b].st;
@@ -354,33 +402,35 @@ private:
         return nd;
     }
 
-    void cluster(Heap &heap) {   // ahCluster (:939-1143)
+    void cluster() {   // ahCluster (:939-1143) on heap_
         int step = 0;
-        while (!heap.empty() && step <= T.p.max_step) {
-            const int p = heap.top();
-            heap.pop();
+        while (!heap_.empty() && step <= T.p.max_step) {
+            const int p = heap_pop();
             if (nodes_[p].nouse) continue;
             // try to merge with every neighbour (ascending id), keep the merge with the smallest MSE
+            // (only the MSE of every candidate is needed to choose; the full node -- centre, normal, curvature -- is built for the winner alone)
             bool have = false;
-            Node best;
-            int bestNb = -1;
+            double bestMse = 0;
+            int bestN = 0, bestNb = -1;
             for (int nb : nodes_[p].nbs) {
                 if (similarity(nodes_[p], nodes_[nb]) < T.p.similarity_th_merge) continue;
-                const Node m = merged_node(p, nb);
-                if (!have || best.mse > m.mse || (best.mse == m.mse && best.N < m.mse)) { best = m; bestNb = nb; have = true; }   // (sic: N against mse, :1005)
+                const double mse = merged_mse(p, nb);
+                if (!have || bestMse > mse || (bestMse == mse && bestN < mse)) { bestMse = mse; bestN = nodes_[p].st.N + nodes_[nb].st.N; bestNb = nb; have = true; }   // (sic: N against mse, :1005)
             }
+            Node best;
+            if (have) best = merged_node(p, bestNb);
             if (have && best.mse < T.t_mse_merge(best.center[2])) {
-                nodes_.push_back(best);
-                const int id = (int)nodes_.size() - 1;   // accepted merges get ascending ids: the newest node sorts last among neighbours
-                heap.push(id);
+                const int id = add_node(best);   // accepted merges get ascending ids: the newest node sorts last among neighbours
+                heap_push(id);
                 // mergeNbsFrom (AHCPlaneSeg.hpp:398-436)
                 unite(nodes_[p].rid, nodes_[bestNb].rid);
-                std::vector<int> u;
+                std::vector<int> &u = u_;
+                u.clear();
                 std::set_union(nodes_[p].nbs.begin(), nodes_[p].nbs.end(), nodes_[bestNb].nbs.begin(), nodes_[bestNb].nbs.end(), std::back_inserter(u));
                 unlink_one(u, p); unlink_one(u, bestNb);
                 isolate(p); isolate(bestNb);
                 for (int nb : u) link_one(nodes_[nb].nbs, id);
-                nodes_[id].nbs.swap(u);
+                nodes_[id].nbs.assign(u.begin(), u.end());
                 nodes_[p].nouse = nodes_[bestNb].nouse = true;
             } else {
                 if (nodes_[p].N >= T.p.min_support) planes_.push_back(p);
@@ -388,9 +438,8 @@ private:
             }
             ++step;
         }
-        while (!heap.empty()) {
-            const int p = heap.top();
-            heap.pop();
+        while (!heap_.empty()) {
+            const int p = heap_pop();
             if (nodes_[p].N >= T.p.min_support) planes_.push_back(p);
             isolate(p);
         }
@@ -453,7 +502,8 @@ private:
     }
 
     void grow_regions() {   // floodFill (:422-471)
-        std::vector<float> distMap((size_t)H * W, std::numeric_limits<float>::max());
+        std::vector<float> &distMap = distMap_;
+        distMap.assign((size_t)H * W, std::numeric_limits<float>::max());
         for (size_t k = 0; k < growQ_.size(); ++k) {
             const int seed = growQ_[k].first, plid = growQ_[k].second;
             const int sy = seed / W, sx = seed - sy * W;
@@ -488,16 +538,18 @@ private:
     }
 
     void refine() {   // refineDetails (:296-372)
-        std::vector<char> validPlane;
+        std::vector<char> &validPlane = validPlane_;
         erode_blocks(validPlane);
         grow_regions();
-        const std::vector<int> old = planes_;
+        std::vector<int> &old = oldPlanes_;
+        old.assign(planes_.begin(), planes_.end());
         planes_.clear();
-        Heap heap{MseGreater{this}};
+        heap_.clear();
         for (size_t i = 0; i < old.size(); ++i)
-            if (validPlane[i]) heap.push(old[i]);
-        cluster(heap);
-        std::vector<int> relabel(old.size(), -1);
+            if (validPlane[i]) heap_push(old[i]);
+        cluster();
+        std::vector<int> &relabel = relabel_;
+        relabel.assign(old.size(), -1);
         for (size_t i = 0; i < old.size(); ++i) {
             if (!validPlane[i]) continue;
             const int root = find(nodes_[old[i]].rid);
@@ -511,7 +563,90 @@ private:
     }
 };
 
-struct Scratch { void *depth = nullptr, *blocks = nullptr, *cloud = nullptr, *half = nullptr; size_t depthCap = 0, blocksCap = 0, cloudCap = 0, halfCap = 0; };
+// CPUs this process may actually use: hardware threads, limited by the affinity mask and by the cgroup CPU quota (cpu.max of cgroup v2 /
+// cpu.cfs_quota_us of v1).  More runnable threads than that only burn the quota early in each period and are then throttled together
+// (measured on a 256-thread host with a 16-CPU quota: 64 workers -> every third call stalled for 60-80 ms).
+int usable_cpus() {
+    int n = std::max(1, (int)std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (fscanf(fq, "%lld", &quota) != 1) quota = -1;
+        fclose(fq);
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1ll, (quota + period - 1) / period));
+    return n;
+}
+
+// Host workers for the per-frame clustering (frames are independent).  The WORKSPACES persist between calls (no allocation, no page faults in
+// the steady state); the threads are started per call (freshly created threads are spread over idle cores at once; ~20 us each).  The caller
+// takes part with its own workspace, so a one-frame call starts no thread at all.
+class SegPool {
+public:
+    static SegPool &get() { static SegPool p; return p; }
+    // fn(frame, workspace) for frame = 0 .. nFrames-1, each exactly once; returns when all are done
+    void run(int nFrames, const std::function<void(int, FrameSegmenter &)> &fn) {
+        std::lock_guard<std::mutex> one(callMutex_);   // one batch at a time
+        if (nFrames <= 0) return;
+        const int nWorkers = std::min(nFrames - 1, maxWorkers_);
+        while ((int)ws_.size() < nWorkers + 1) ws_.emplace_back(new FrameSegmenter);
+        std::atomic<int> next{0};
+        auto work = [&](FrameSegmenter &ws) {
+            for (;;) {
+                const int f = next.fetch_add(1);
+                if (f >= nFrames) break;
+                fn(f, ws);
+            }
+        };
+        std::vector<std::thread> threads;
+        threads.reserve(nWorkers);
+        for (int t = 0; t < nWorkers; t++) threads.emplace_back([&, t]() { work(*ws_[t + 1]); });
+        work(*ws_[0]);
+        for (auto &th : threads) th.join();
+    }
+
+private:
+    SegPool() : maxWorkers_(std::max(0, std::min(64, usable_cpus()) - 1)) {}
+    const int maxWorkers_;
+    std::mutex callMutex_;
+    std::vector<std::unique_ptr<FrameSegmenter>> ws_;
+};
+
+// graph initialisation + clustering + erosion + region growing of n_frames frames: blocks [frames][nBlocks], half [frames][ch][cw]
+void segment_frames(const msl_peac_params &prm, const msl_peac_block *blocks, size_t nBlocks, const uint16_t *half, int cw, int ch, int n_frames, float fx,
+                    float fy, float cx, float cy, float depth_map_factor, int32_t *membership_out, int32_t *n_planes_out) {
+    const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<long> startUs(timing ? n_frames : 0), durUs(timing ? n_frames : 0);
+    SegPool::get().run(n_frames, [&](int f, FrameSegmenter &seg) {
+        const auto a = std::chrono::steady_clock::now();
+        seg.configure(prm, half + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
+        const int n = seg.run(blocks + (size_t)f * nBlocks, membership_out + (size_t)f * cw * ch);
+        if (n_planes_out) n_planes_out[f] = n;
+        if (timing) {
+            startUs[f] = (long)std::chrono::duration_cast<std::chrono::microseconds>(a - t0).count();
+            durUs[f] = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - a).count();
+        }
+    });
+    if (timing && n_frames > 1) {
+        long ms = 0, md = 0, sd = 0;
+        for (int f = 0; f < n_frames; f++) { ms = std::max(ms, startUs[f]); md = std::max(md, durUs[f]); sd += durUs[f]; }
+        fprintf(stderr, "[msl_peac] pool: latest frame start %ld us, longest frame %ld us, mean frame %ld us\n", ms, md, sd / n_frames);
+    }
+}
+
+struct Scratch {
+    void *depth = nullptr, *blocks = nullptr, *cloud = nullptr, *half = nullptr; size_t depthCap = 0, blocksCap = 0, cloudCap = 0, halfCap = 0;
+    // The extractor's own stream (non-blocking, highest priority): its few small kernels and copies must neither wait for nor hold up the frame-batched
+    // ORB / surfel work queued on the device.  Work the caller enqueued on the legacy default stream before the call is still ordered first (event).
+    hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+};
 Scratch g_scratch[16];
 std::mutex g_scratchMutex;
 
@@ -547,12 +682,20 @@ int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t fra
     const size_t nBlocks = (size_t)P.Nw * P.Nh, nVert = (size_t)P.cw * P.ch;
     if (nBlocks == 0) { set_error("msl_peac: image smaller than one window"); return MSL_ERR_INVALID; }
     Scratch &sc = g_scratch[device & 15];
+    if (!sc.stream) {
+        int lo = 0, hi = 0;
+        PEAC_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PEAC_TRY(hipStreamCreateWithPriority(&sc.stream, hipStreamNonBlocking, hi));
+        PEAC_TRY(hipEventCreateWithFlags(&sc.ev, hipEventDisableTiming));
+    }
+    const hipStream_t st = sc.stream;
+    if (mem == MSL_MEM_DEVICE) { PEAC_TRY(hipEventRecord(sc.ev, 0)); PEAC_TRY(hipStreamWaitEvent(st, sc.ev, 0)); }
     if (mem == MSL_MEM_HOST) {
         // bytes actually present in the caller's buffer: the last row carries no stride padding
         const size_t frameBytes = strideBytes * (size_t)(height - 1) + (size_t)width * 2, slot = (frameBytes + 255) & ~(size_t)255;
         PEAC_TRY(grow(sc.depth, sc.depthCap, slot * n_frames));
         for (int f = 0; f < n_frames; f++)
-            PEAC_TRY(hipMemcpyAsync((uint8_t *)sc.depth + f * slot, (const uint8_t *)depth + f * frameStrideBytes, frameBytes, hipMemcpyHostToDevice, 0));
+            PEAC_TRY(hipMemcpyAsync((uint8_t *)sc.depth + f * slot, (const uint8_t *)depth + f * frameStrideBytes, frameBytes, hipMemcpyHostToDevice, st));
         P.depth = (const uint16_t *)sc.depth; P.frameStrideBytes = slot;
     } else {
         P.depth = depth;
@@ -560,12 +703,12 @@ int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t fra
     if (blocksUser) P.blocks = blocksUser;
     else { PEAC_TRY(grow(sc.blocks, sc.blocksCap, sizeof(msl_peac_block) * nBlocks * n_frames)); P.blocks = (msl_peac_block *)sc.blocks; }
     P.cloud = cloudDev;
-    if (cloudDev) hipLaunchKernelGGL(k_peac_cloud, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P);
-    hipLaunchKernelGGL(k_peac_fit, dim3((unsigned)nBlocks, (unsigned)n_frames), dim3(64), sizeof(double) * 9 * prm.window_w * prm.window_h, 0, P);
+    if (cloudDev) hipLaunchKernelGGL(k_peac_cloud, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_peac_fit, dim3((unsigned)nBlocks, (unsigned)n_frames), dim3(64), sizeof(double) * 9 * prm.window_w * prm.window_h, st, P);
     PEAC_TRY(hipGetLastError());
     if (dHalfOut) {
         PEAC_TRY(grow(sc.half, sc.halfCap, sizeof(uint16_t) * nVert * n_frames));
-        hipLaunchKernelGGL(k_peac_half, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, 0, P, (uint16_t *)sc.half);
+        hipLaunchKernelGGL(k_peac_half, dim3((unsigned)((nVert + 255) / 256), (unsigned)n_frames), dim3(256), 0, st, P, (uint16_t *)sc.half);
         PEAC_TRY(hipGetLastError());
         *dHalfOut = (uint16_t *)sc.half;
     }
@@ -596,8 +739,9 @@ int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_by
                         &dBlocks, nullptr, out_mem == MSL_MEM_DEVICE ? blocks_out : nullptr);
     if (rc != MSL_OK) return rc;
     const size_t nBlocks = (size_t)(((width + 1) / 2) / params->window_w) * (((height + 1) / 2) / params->window_h);
-    if (out_mem == MSL_MEM_HOST) PEAC_TRY(hipMemcpy(blocks_out, dBlocks, sizeof(msl_peac_block) * nBlocks * n_frames, hipMemcpyDeviceToHost));
-    else PEAC_TRY(hipDeviceSynchronize());
+    const hipStream_t st = g_scratch[device & 15].stream;
+    if (out_mem == MSL_MEM_HOST) PEAC_TRY(hipMemcpyAsync(blocks_out, dBlocks, sizeof(msl_peac_block) * nBlocks * n_frames, hipMemcpyDeviceToHost, st));
+    PEAC_TRY(hipStreamSynchronize(st));
     return MSL_OK;
 }
 
@@ -629,14 +773,17 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
     if (rc != MSL_OK) return rc;
     // this entry point returns the Stats part only
     std::vector<msl_peac_block> hb(nBlocks * n_frames);
-    PEAC_TRY(hipMemcpy(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost));
+    const hipStream_t st = g_scratch[device & 15].stream;
+    PEAC_TRY(hipMemcpyAsync(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost, st));
+    PEAC_TRY(hipStreamSynchronize(st));
     std::vector<msl_peac_stats> hs(hb.size());
     for (size_t i = 0; i < hb.size(); i++) hs[i] = hb[i].stats;
     if (out_mem == MSL_MEM_HOST) {
         memcpy(stats_out, hs.data(), sizeof(msl_peac_stats) * hs.size());
-        if (cloud_out) PEAC_TRY(hipMemcpy(cloud_out, dCloud, sizeof(double) * 3 * nVert * n_frames, hipMemcpyDeviceToHost));
+        if (cloud_out) { PEAC_TRY(hipMemcpyAsync(cloud_out, dCloud, sizeof(double) * 3 * nVert * n_frames, hipMemcpyDeviceToHost, st)); PEAC_TRY(hipStreamSynchronize(st)); }
     } else {
-        PEAC_TRY(hipMemcpy(stats_out, hs.data(), sizeof(msl_peac_stats) * hs.size(), hipMemcpyHostToDevice));
+        PEAC_TRY(hipMemcpyAsync(stats_out, hs.data(), sizeof(msl_peac_stats) * hs.size(), hipMemcpyHostToDevice, st));
+        PEAC_TRY(hipStreamSynchronize(st));
     }
     return MSL_OK;
 }
@@ -649,6 +796,8 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
     std::vector<uint16_t> half;       // raw depth of the cloud vertices, [frames][ch][cw]
     const int cw = (width + 1) / 2, ch = (height + 1) / 2;
     size_t nBlocks = 0;
+    const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
     {
         std::lock_guard<std::mutex> lock(g_scratchMutex);
         msl_peac_block *dBlocks = nullptr;
@@ -659,23 +808,39 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
         nBlocks = (size_t)(cw / params->window_w) * (ch / params->window_h);
         hb.resize(nBlocks * n_frames);
         half.resize((size_t)cw * ch * n_frames);
-        PEAC_TRY(hipMemcpy(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost));
-        PEAC_TRY(hipMemcpy(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost));
+        const hipStream_t st = g_scratch[device & 15].stream;
+        PEAC_TRY(hipMemcpyAsync(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost, st));
+        PEAC_TRY(hipMemcpyAsync(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost, st));
+        PEAC_TRY(hipStreamSynchronize(st));
     }
-    auto one = [&](int f) {
-        FrameSegmenter seg(*params, half.data() + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
-        const int n = seg.run(hb.data() + (size_t)f * nBlocks, membership_out + (size_t)f * cw * ch);
-        if (n_planes_out) n_planes_out[f] = n;
-    };
-    const int nThreads = std::min(n_frames, std::max(1, std::min(64, (int)std::thread::hardware_concurrency())));
-    if (nThreads <= 1) {
-        for (int f = 0; f < n_frames; f++) one(f);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nThreads; t++)
-            pool.emplace_back([&, t]() { for (int f = t; f < n_frames; f += nThreads) one(f); });
-        for (auto &th : pool) th.join();
+    const auto tb1 = std::chrono::steady_clock::now();
+    segment_frames(*params, hb.data(), nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
+    if (timing) {
+        const auto tb2 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        fprintf(stderr, "[msl_peac] batch of %d: device fit + copies %ld us, host clustering %ld us\n", n_frames, us(tb0, tb1), us(tb1, tb2));
     }
+    return MSL_OK;
+}
+
+int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
+                                    int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
+    if (!blocks || !depth || !params || !membership_out || params->min_support < 1 || params->window_w < 1 || params->window_h < 1 || width < 2 || height < 2 ||
+        n_frames < 0 || depth_stride_bytes < (size_t)width * 2) {
+        set_error("msl_peac_membership_from_blocks: invalid argument");
+        return MSL_ERR_INVALID;
+    }
+    const int cw = (width + 1) / 2, ch = (height + 1) / 2;
+    const size_t nBlocks = (size_t)(cw / params->window_w) * (ch / params->window_h);
+    std::vector<uint16_t> half((size_t)cw * ch * n_frames);   // raw depth of the cloud vertices (even rows / columns), as k_peac_half packs it
+    for (int f = 0; f < n_frames; f++)
+        for (int r = 0; r < ch; r++) {
+            const uint16_t *row = reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(depth) + (size_t)f * frame_stride_bytes + (size_t)(2 * r) * depth_stride_bytes);
+            uint16_t *o = half.data() + ((size_t)f * ch + r) * cw;
+            for (int c = 0; c < cw; c++) o[c] = row[2 * c];
+        }
+    segment_frames(*params, blocks, nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
     return MSL_OK;
 }
 

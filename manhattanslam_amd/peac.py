@@ -65,6 +65,19 @@ def plane_membership(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, d
     return member, n
 
 
+def plane_membership_from_blocks(blocks, depth_u16, fx, fy, cx, cy, depth_map_factor, params=None):
+    """The host stage alone (clustering, erosion, region growing) on block fits [F, Nh * Nw] PEAC_BLOCK_DTYPE and the depth images they came from."""
+    d = _frames(depth_u16)
+    F, H, W = d.shape
+    prm = default_params() if params is None else params
+    b = np.ascontiguousarray(blocks, PEAC_BLOCK_DTYPE).reshape(F, -1)
+    member = np.zeros((F, (H + 1) // 2, (W + 1) // 2), np.int32)
+    n = np.zeros(F, np.int32)
+    check(lib.msl_peac_membership_from_blocks(ptr(b), ptr(d), d.strides[1], d.strides[0], W, H, F, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(member),
+                                              ptr(n)), "msl_peac_membership_from_blocks")
+    return member, n
+
+
 def plane_membership_device(d_depth16, frame_step, n_frames, width, height, fx, fy, cx, cy, depth_map_factor, params, member_out, nplanes_out, device=0):
     """Device-resident 16-bit depth frames (torch tensor, frame j of the call = frame j * frame_step of the tensor); membership and plane
     counts land in the caller's host arrays ([n_frames, ceil(H/2), ceil(W/2)] int32, [n_frames] int32)."""

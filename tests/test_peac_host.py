@@ -1,0 +1,85 @@
+"""Host stage of the PEAC extractor (graph initialisation, agglomerative clustering, erosion, region growing, relabelling) through the C ABI
+(msl_peac_membership_from_blocks: no device involved) against the CPU oracle, on the oracle's own block fits.  Runs without a GPU."""
+import numpy as np
+import pytest
+
+
+def _depth(k, intr, dropout, w=640, h=480):
+    from manhattanslam_amd import synth
+    _, depth, _, _ = synth.surfel_frame(k, w=w, h=h, intr=intr, dropout=dropout)
+    return synth.depth_u16(depth)
+
+
+def _scenes(intr):
+    frames = []
+    for k, dr, box in ((0, 0.0, False), (40, 0.0005, False), (100, 0.001, True), (170, 0.0, True), (250, 0.003, False), (300, 0.02, False)):
+        d = _depth(k, intr, dr)
+        if box:
+            d[150:330, 260:470] = 5000                 # 1 m box front: a plane of its own
+        frames.append(d)
+    return frames
+
+
+@pytest.mark.parametrize("intr_name", ["ICL", "TUM1"])
+def test_host_stage_matches_oracle(oracle, intr_name):
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = getattr(synth, intr_name)
+    fac = np.float32(1 / 5000.0)
+    frames = _scenes(I)
+    ref = [oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac) for d in frames]
+    blocks = np.stack([r[2] for r in ref])
+    got, n = peac.plane_membership_from_blocks(blocks, np.stack(frames), I["fx"], I["fy"], I["cx"], I["cy"], fac)
+    for f, (want, nw, _) in enumerate(ref):
+        assert n[f] == nw, (f, n[f], nw)
+        assert np.array_equal(got[f], want), (f, np.argwhere(got[f] != want)[:5])
+    assert sum(r[1] for r in ref) >= 6 and n[5] == 0
+
+
+def test_worker_workspaces_are_reusable(oracle):
+    """The worker threads keep their workspaces between calls: a frame gives the same image whatever was segmented before it, in calls of
+    different sizes, geometries and parameters."""
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = synth.ICL
+    fac = np.float32(1 / 5000.0)
+    frames = _scenes(I)
+    ref = [oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac) for d in frames]
+    blocks = np.stack([r[2] for r in ref])
+    big = _depth(60, synth.scaled_intrinsics(synth.TUM1, 1280), 0.002, 1280, 960)
+    Ib = synth.scaled_intrinsics(synth.TUM1, 1280)
+    pb = oracle_lib.peac_default_params(); pb["window_w"] = 8; pb["window_h"] = 6; pb["min_support"] = 1000
+    wb, nb, bb = oracle_lib.peac_run(big, Ib["fx"], Ib["fy"], Ib["cx"], Ib["cy"], fac, params=pb)
+    for order in ([3], [0, 1, 2, 3, 4, 5], [5, 2], [2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2], [4, 3, 1]):
+        got, n = peac.plane_membership_from_blocks(blocks[order], np.stack([frames[i] for i in order]), I["fx"], I["fy"], I["cx"], I["cy"], fac)
+        for j, i in enumerate(order):
+            assert n[j] == ref[i][1] and np.array_equal(got[j], ref[i][0]), (order, j)
+        p = peac.default_params(); p["window_w"] = 8; p["window_h"] = 6; p["min_support"] = 1000
+        gb, ngb = peac.plane_membership_from_blocks(bb[None], big, Ib["fx"], Ib["fy"], Ib["cx"], Ib["cy"], fac, params=p)
+        assert ngb[0] == nb and np.array_equal(gb[0], wb)
+
+
+def test_host_stage_parameters(oracle):
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = synth.TUM1
+    fac = np.float32(1 / 5000.0)
+    d = _depth(100, I, 0.001)
+    d[150:330, 260:470] = 5000
+    for kw in (dict(init_loose=1), dict(erode_type=1), dict(do_refine=0), dict(erode_type=0, min_support=500), dict(window_w=8, window_h=6, min_support=1000)):
+        p = peac.default_params()
+        po = oracle_lib.peac_default_params()
+        for k, v in kw.items():
+            p[k] = v; po[k] = v
+        want, nw, blocks = oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=po)
+        got, n = peac.plane_membership_from_blocks(blocks[None], d, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
+        assert n[0] == nw and np.array_equal(got[0], want), kw
+
+
+def test_invalid_arguments_are_rejected():
+    from manhattanslam_amd import peac, synth, MslError
+    I = synth.TUM1
+    p = peac.default_params(); p["min_support"] = 0
+    with pytest.raises(MslError):
+        peac.plane_membership_from_blocks(np.zeros((1, 768), peac.PEAC_BLOCK_DTYPE), np.zeros((480, 640), np.uint16), I["fx"], I["fy"], I["cx"], I["cy"],
+                                          np.float32(1 / 5000.0), params=p)

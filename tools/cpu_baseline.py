@@ -87,6 +87,27 @@ def mem_available_bytes():
     return 8 << 30
 
 
+def usable_cpus():
+    """Logical CPUs limited by the affinity mask and the cgroup CPU quota (cpu.max): more runnable processes than that are only throttled."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, -(-int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                n = min(n, max(1, -(-q // p)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=48, help="frames of the single-thread sample")
@@ -104,8 +125,8 @@ def main():
     W, H = (int(v) for v in args.size.lower().split("x"))
     do_orb, do_sf, kfe = not args.no_orb, not args.no_surfel, args.keyframe_every
     inp = build_inputs(args.distinct_frames, args.surfels if do_sf else 16, W, H, args.intrinsics)
-    ncpu = os.cpu_count() or 1
-    out = {"host_cpus": ncpu, "kind": "port",
+    ncpu = usable_cpus()
+    out = {"host_cpus": os.cpu_count() or 1, "usable_cpus": ncpu, "kind": "port",
            "code": "oracle/libmsl_oracle.so (CPU restatement of src/ORBextractor.cc + src/SurfelFusion.cpp + SurfelMapping::fuseMap; g++ -O3, no -march=native)"}
     what = ("ORB + " if do_orb else "") + (f"SurfelFusion every {kfe} frame(s), {args.surfels} seeded surfels" if do_sf else "no surfel stage")
 
@@ -139,7 +160,7 @@ def main():
         else:
             wall = max(r[1] for r in res) - min(r[0] for r in res)
             out["throughput"] = {"value": round(P * args.frames_per_proc / wall, 2), "unit": "frames/s", "cores": P,
-                                 "sample": f"{P} independent sequences (one single-threaded process per logical CPU) x {args.frames_per_proc} frames, "
+                                 "sample": f"{P} independent sequences (one single-threaded process per CPU this container may use: affinity mask and cgroup cpu.max) x {args.frames_per_proc} frames, "
                                            f"{what}, {W}x{H}",
                                  "wall_s": round(wall, 3)}
     print(json.dumps(out), flush=True)

@@ -148,7 +148,7 @@ def cpu_baseline(args, cfg, W, H, kfe):
         return {"error": f"cpu baseline failed: {e!r}"}
     top = res.get("throughput") if "value" in res.get("throughput", {}) else res.get("single_thread", {})
     out = {"value": top.get("value"), "unit": top.get("unit", "frames/s"), "cores": top.get("cores"), "kind": "port", "sample": top.get("sample"),
-           "host_cpus": res.get("host_cpus"), "usable_cpus": res.get("usable_cpus"), "code": res.get("code")}
+           "host_cpus": res.get("host_cpus"), "code": res.get("code")}
     for k in ("single_thread", "surfel_10_threads", "throughput"):
         if k in res:
             out[k] = res[k]
@@ -233,21 +233,8 @@ def main():
             # raw 16-bit depth of the keyframes (5000 units per metre), resident in HBM like the other inputs
             d_depth16 = torch.from_numpy(np.stack([synth.depth_u16(d) for d in depths]).view(np.int16)).to(dev).repeat(F // D, 1, 1).contiguous()
             peac_prm = peac.default_params()
-            # The extractor of the NEXT step's keyframes runs on a host thread (block fit on the GPU, clustering on the library's worker
-            # threads) while this step's ORB / SurfelFusion calls are enqueued, the way the reference runs plane extraction in the tracking
-            # thread and surfel mapping in its own (src/Tracking.cc:228, src/SurfelMapping.cpp:46-60).  Every timed step still pays one full
-            # extraction of its nkf * nsub keyframes: the one in flight at the end of the region is waited for inside it (sync_all).
-            import concurrent.futures
-            h_member = [np.zeros((nkf * nsub, H // 2, W // 2), np.int32) for _ in range(2)]
-            h_nplanes = [np.zeros(nkf * nsub, np.int32) for _ in range(2)]
-            peac_pool = concurrent.futures.ThreadPoolExecutor(1)
-            peac_job = [None, 0]   # (future, buffer index)
-
-            def peac_submit():
-                b = peac_job[1] ^ 1
-                peac_job[0] = peac_pool.submit(peac.plane_membership_device, d_depth16, kfe, nkf * nsub, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"],
-                                               np.float32(1.0 / 5000.0), peac_prm, h_member[b], h_nplanes[b], local_rank)
-                peac_job[1] = b
+            h_member = np.zeros((nkf * nsub, H // 2, W // 2), np.int32)
+            h_nplanes = np.zeros(nkf * nsub, np.int32)
         kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
     torch.cuda.synchronize()
 
@@ -261,13 +248,11 @@ def main():
     def sub_sf(sb):
         if use_peac:
             if sb == 0:
-                # plane membership of this step's keyframes (one call: block fit on the GPU, clustering on one host thread per keyframe),
-                # computed while the previous step was enqueued; back to HBM, then start the next step's
-                if peac_job[0] is None:
-                    peac_submit()
-                peac_job[0].result()
-                peac_dev[0] = torch.from_numpy(h_member[peac_job[1]]).to(dev)
-                peac_submit()
+                # plane membership of the step's keyframes in one call: block fit on the GPU, clustering on one host thread per keyframe
+                # (synchronous: the sequential AHC is the slow part), then back to HBM
+                peac.plane_membership_device(d_depth16, kfe, nkf * nsub, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], np.float32(1.0 / 5000.0),
+                                             peac_prm, h_member, h_nplanes, device=local_rank)
+                peac_dev[0] = torch.from_numpy(h_member).to(dev)
             sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], peac_dev[0][sb * nkf:], kf_poses[sb], device=True,
                                    member_shared=False, frame_step=kfe, member_frame_step=1)
             kf_no[0] += nkf
@@ -293,8 +278,6 @@ def main():
                 sub_sf(sb)
 
     def sync_all():
-        if use_peac and peac_job[0] is not None:
-            peac_job[0].result()
         if do_orb:
             orb.sync()
         if do_sf:
