@@ -43,9 +43,10 @@ CONFIGS = {
                      name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
     "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 2: ORBextractor only"),
     "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 3: SurfelFusion only"),
-    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001,
+    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_step=512,
               name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + PEAC plane extractor and SurfelFusion every k-th "
-                   "frame (block fit on the GPU, clustering on host threads; its membership image feeds the fusion)"),
+                   "frame (block fit and agglomerative clustering on the GPU, erosion / region growing on host threads; its membership "
+                   "image feeds the fusion)"),
     "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1,
               name="BASELINE config 5: ORB + SurfelFusion on every frame, 1280x960 sequences"),
 }
@@ -59,7 +60,9 @@ def parse(argv=None):
     ap.add_argument("--config", default="frontend", choices=sorted(CONFIGS))
     ap.add_argument("--size", default=None, help="WxH override (multiples of 8)")
     ap.add_argument("--keyframe-every", type=int, default=None, help="SurfelFusion on every k-th frame")
-    ap.add_argument("--frames-per-step", type=int, default=256, help="frames one step pushes through the hot path (each with its own input memory)")
+    ap.add_argument("--frames-per-step", type=int, default=0, help="frames one step pushes through the hot path (each with its own input memory); "
+                    "0 = the configuration's default (256; config 4: 512, because the plane extractor clusters one keyframe per wave and is "
+                    "latency-bound per call, so its throughput grows with the keyframes handed over at once)")
     ap.add_argument("--batch", type=int, default=32, help="frames per library call; a step issues frames-per-step / batch calls.  The scratch of "
                     "2 x batch keyframe slots plus the map should stay inside the 256 MB Infinity Cache: 128-frame batches measured 35 %% slower")
     ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames generated per sequence (tiled to a step)")
@@ -161,7 +164,7 @@ def dry_run(args, world, rank):
     if world > 1:
         dist.init_process_group("gloo")
         dist.barrier()
-    F = args.frames_per_step
+    F = args.frames_per_step or CONFIGS[args.config].get("frames_per_step", 256)
     local_ms = 10.0 + 5.0 * rank
     counters = [args.steps * F, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
     total_ms, gathered = aggregate(local_ms, counters, world, None)
@@ -202,7 +205,7 @@ def main():
     W, H = (int(v) for v in (args.size or cfg["size"]).lower().split("x"))
     kfe = args.keyframe_every or cfg["kfe"]
     do_orb, do_sf = cfg["orb"], cfg["sf"]
-    F = args.frames_per_step
+    F = args.frames_per_step or cfg.get("frames_per_step", 256)
     B = min(args.batch, F)
     D = min(args.distinct_frames, F)
     if F % B or B % kfe or F % D:

@@ -252,10 +252,11 @@ MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth
  * 3x3 symmetric eigen-solve being LA::eig33sym = Eigen::SelfAdjointEigenSolver<Matrix3d> (include/peac/eig33sym.hpp:71-75).
  * msl_peac_block_fit: cloud + block statistics + PCA on the GPU (one wave per window, FP64, the reference's summation order).
  * msl_peac_membership_batch: PlaneDetection::readDepthImage + runPlaneDetection (src/PlaneExtractor.cpp:44-81) for n_frames
- *   depth images: block fit on the GPU; graph initialisation (AHCPlaneFitter.hpp:756-928), agglomerative clustering (:939-1143),
- *   block erosion (:490-596), region growing (:422-471) and the final merge / relabelling (:296-372) on the host (inherently
- *   sequential: a priority queue of merges, a FIFO flood fill), one frame per worker thread at a time (as many workers as the process may
- *   use CPUs: affinity mask and cgroup quota, at most 64).
+ *   depth images: block fit on the GPU; graph initialisation (AHCPlaneFitter.hpp:756-928) on the host; agglomerative clustering (:939-1143)
+ *   on the GPU, one wave per frame (on the host workers if a frame's node data does not fit the LDS, or with MSL_PEAC_CLUSTER=host); block
+ *   erosion (:490-596), region growing (:422-471) and the final merge / relabelling (:296-372) on the host (order-dependent pixel work: a
+ *   FIFO flood fill), one frame per worker thread at a time (as many workers as the process may use CPUs: affinity mask and cgroup quota,
+ *   at most 64).  Device-resident input must be complete, or enqueued on the legacy default stream, when the call is made.
  *   membership_out (HOST, [n_frames][ceil(h/2)][ceil(w/2)]) = plane_filter.membershipImg as SurfelMapping receives it
  *   (src/Tracking.cc:228): plane id >= 0, -1 = no plane, and -- exactly like the reference -- the region-growing visit counters
  *   -2..-6 on pixels that were tried and rejected.  n_planes_out (HOST, may be NULL) = extractedPlanes.size() per frame. */

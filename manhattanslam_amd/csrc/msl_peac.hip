@@ -254,6 +254,232 @@ __global__ __launch_bounds__(64) void k_peac_fit(PeacDev P) {
     P.blocks[(size_t)frame * P.Nw * P.Nh + b] = B;
 }
 
+// ---- agglomerative clustering on the device: one wave per frame ----------------------------------------------------------------------------
+// ahCluster (AHCPlaneFitter.hpp:939-1143) is a sequential chain of pops, but every pop evaluates ALL neighbours of the popped node (a plane fit
+// each: ~30 000 3x3 eigen-solves per 640x480 frame) -- that part is data parallel, and frames are independent.  One wave per frame: lane 0 keeps the
+// reference's binary heap (libstdc++ push_heap / pop_heap spelled out, so the pop order is the reference's even among equal keys) and the disjoint
+// set in LDS; the neighbours of the popped node are fitted one per lane with the same __host__ __device__ code the host uses (so the same bits),
+// the reference's first-minimum rule picks the merge, and the adjacency -- a bit matrix, whose ascending bit order is the reference's ordered
+// neighbour set -- is updated by all lanes.  The host supplies the initial heap and edges (graph initialisation needs cos()) and continues with the
+// extracted planes (erosion, FIFO region growing: order dependent pixel work that stays on the host).
+struct PlaneOut { double st[9], center[3], normal[3], mse; int32_t id, N, rid, _pad; };
+struct ClusterDev {
+    int nB, maxN, words, minSupport, maxStep, maxE, maxPl;
+    double depthSigma, stdTolMerge, simMerge;
+    const msl_peac_block *blocks;   // [frames][nB]
+    unsigned *rows;                 // [frames][maxN][words] adjacency bit matrix
+    double *gst;                    // [frames][maxN][9] statistics of every node
+    double *gcxy;                   // [frames][maxN][2] centre x, y (output only)
+    const int *heap0, *heapCount;   // [frames][nB], [frames] initial heap
+    const int *edges, *edgeCount;   // [frames][maxE][2], [frames] initial edges
+    int *nPlanes; PlaneOut *planes; // [frames] (-1: more than maxPl), [frames][maxPl] extracted planes in extraction order
+    int *parent, *setSize;          // [frames][nB] disjoint set after the clustering
+};
+__device__ __forceinline__ unsigned ld_ag(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_ag(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agd(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void k_peac_cluster(ClusterDev C) {
+    extern __shared__ double s_mem[];
+    const int f = blockIdx.x, lane = threadIdx.x, nB = C.nB, maxN = C.maxN, words = C.words;
+    double *s_mse = s_mem, *s_nx = s_mse + maxN, *s_ny = s_nx + maxN, *s_nz = s_ny + maxN, *s_cz = s_nz + maxN;
+    double *s_hkey = s_cz + maxN;   // MSE of the node in heap slot i (saves the dependent s_mse[s_heap[i]] read on every comparison)
+    int *s_N = reinterpret_cast<int *>(s_hkey + maxN), *s_rid = s_N + maxN, *s_heap = s_rid + maxN, *s_cand = s_heap + maxN;
+    int *s_parent = s_cand + maxN, *s_size = s_parent + nB;
+    uint8_t *s_nouse = reinterpret_cast<uint8_t *>(s_size + nB);
+    unsigned *rows = C.rows + (size_t)f * maxN * words;
+    double *gst = C.gst + (size_t)f * maxN * 9, *gcxy = C.gcxy + (size_t)f * maxN * 2;
+    const msl_peac_block *blocks = C.blocks + (size_t)f * nB;
+    PlaneOut *planes = C.planes + (size_t)f * C.maxPl;
+    for (int b = lane; b < nB; b += 64) {
+        const msl_peac_block &B = blocks[b];
+        const bool nouse = B.stats.nouse != 0;
+        s_mse[b] = B.mse; s_nx[b] = B.normal[0]; s_ny[b] = B.normal[1]; s_nz[b] = B.normal[2]; s_cz[b] = B.center[2];
+        s_nouse[b] = nouse ? 1 : 0; s_N[b] = nouse ? 0 : B.stats.N; s_rid[b] = b; s_parent[b] = b; s_size[b] = 1;
+        double *g = gst + (size_t)b * 9;
+        g[0] = B.stats.sx; g[1] = B.stats.sy; g[2] = B.stats.sz; g[3] = B.stats.sxx; g[4] = B.stats.syy; g[5] = B.stats.szz; g[6] = B.stats.sxy; g[7] = B.stats.syz; g[8] = B.stats.sxz;
+        gcxy[2 * b] = B.center[0]; gcxy[2 * b + 1] = B.center[1];
+    }
+    int hcount = C.heapCount[f];
+    for (int i = lane; i < hcount; i += 64) { const int id = C.heap0[(size_t)f * nB + i]; s_heap[i] = id; s_hkey[i] = blocks[id].mse; }
+    {
+        const int ne = C.edgeCount[f];
+        const int *E = C.edges + (size_t)f * C.maxE * 2;
+        for (int e = lane; e < ne; e += 64) {
+            const int a = E[2 * e], b = E[2 * e + 1];
+            atomicOr(&rows[(size_t)a * words + (b >> 5)], 1u << (b & 31));
+            atomicOr(&rows[(size_t)b * words + (a >> 5)], 1u << (a & 31));
+        }
+    }
+    __threadfence();   // (once: the plain initialisation stores above become visible to the agent-scope accesses below)
+    __syncthreads();
+    int nNodes = nB, nPl = 0, step = 0;
+    // the set bits of `words` words held one per lane (chunks of 64 words), ascending, into s_cand; returns their number
+    auto list_bits = [&](auto word_of) -> int {
+        int base = 0;
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int w = w0 + lane;
+            unsigned bits = w < words ? word_of(w) : 0u;
+            const unsigned cnt = (unsigned)__popc(bits);
+            const unsigned incl = wave_incl_scan(cnt);
+            int o = base + (int)(incl - cnt);
+            while (bits) { const int b = __ffs((int)bits) - 1; bits &= bits - 1; s_cand[o++] = w * 32 + b; }
+            base += __shfl((int)incl, 63, 64);
+        }
+        __syncthreads();
+        return base;
+    };
+    // PlaneSegMinMSECmp(a, b) = mse[b] < mse[a]; comp(parent, value) in __push_heap reads "value's key < parent's key"
+    auto heap_push = [&](int id, double key) {   // std::push_heap (libstdc++ __push_heap), lane 0
+        int hole = hcount++;
+        int parent = (hole - 1) / 2;
+        while (hole > 0 && key < s_hkey[parent]) { s_heap[hole] = s_heap[parent]; s_hkey[hole] = s_hkey[parent]; hole = parent; parent = (hole - 1) / 2; }
+        s_heap[hole] = id; s_hkey[hole] = key;
+    };
+    auto heap_pop = [&]() -> int {   // top, then std::pop_heap (libstdc++ __pop_heap / __adjust_heap) + pop_back, lane 0
+        const int top = s_heap[0];
+        const int len = --hcount;
+        if (len > 0) {
+            const int value = s_heap[len];
+            const double vkey = s_hkey[len];
+            int hole = 0, child = 0;
+            while (child < (len - 1) / 2) {
+                child = 2 * (child + 1);
+                if (s_hkey[child - 1] < s_hkey[child]) child--;   // comp(first[child], first[child - 1])
+                s_heap[hole] = s_heap[child]; s_hkey[hole] = s_hkey[child]; hole = child;
+            }
+            if ((len & 1) == 0 && child == (len - 2) / 2) { child = 2 * (child + 1); s_heap[hole] = s_heap[child - 1]; s_hkey[hole] = s_hkey[child - 1]; hole = child - 1; }
+            int parent = (hole - 1) / 2;
+            while (hole > 0 && vkey < s_hkey[parent]) { s_heap[hole] = s_heap[parent]; s_hkey[hole] = s_hkey[parent]; hole = parent; parent = (hole - 1) / 2; }
+            s_heap[hole] = value; s_hkey[hole] = vkey;
+        }
+        return top;
+    };
+    auto ds_find = [&](int x) { while (s_parent[x] != x) { s_parent[x] = s_parent[s_parent[x]]; x = s_parent[x]; } return x; };
+    auto emit_plane = [&](int p) {   // extractedPlanes.push_back
+        if (nPl >= C.maxPl) { nPl++; return; }
+        PlaneOut &O = planes[nPl];
+        if (lane < 9) O.st[lane] = ld_agd(&gst[(size_t)p * 9 + lane]);
+        if (lane == 9) { O.center[0] = ld_agd(&gcxy[2 * p]); O.center[1] = ld_agd(&gcxy[2 * p + 1]); O.center[2] = s_cz[p]; }
+        if (lane == 10) { O.normal[0] = s_nx[p]; O.normal[1] = s_ny[p]; O.normal[2] = s_nz[p]; O.mse = s_mse[p]; }
+        if (lane == 11) { O.id = p; O.N = s_N[p]; O.rid = s_rid[p]; O._pad = 0; }
+        nPl++;
+    };
+    // Rows, statistics and centres are read and written at agent scope (L2) only, so program order within the wave plus completion of
+    // the outstanding stores / atomics is all the ordering the next step needs -- no cache write-back or invalidation.
+    auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    auto isolate = [&](int p, int nc) {   // the neighbours of p are s_cand[0..nc)
+        const unsigned clr = ~(1u << (p & 31));
+        for (int i = lane; i < nc; i += 64) atomicAnd(&rows[(size_t)s_cand[i] * words + (p >> 5)], clr);
+        for (int w = lane; w < words; w += 64) st_ag(&rows[(size_t)p * words + w], 0u);
+        drain();
+    };
+    while (hcount > 0 && step <= C.maxStep) {
+        int p = 0;
+        if (lane == 0) p = heap_pop();
+        p = __shfl(p, 0, 64);
+        hcount = __shfl(hcount, 0, 64);
+        __syncthreads();
+        if (s_nouse[p]) continue;
+        const int nc = list_bits([&](int w) { return ld_ag(&rows[(size_t)p * words + w]); });
+        // every candidate merge fitted by one lane; the reference's rule (first strict minimum of the MSE, ascending neighbour order) picks one
+        bool have = false;
+        double bMse = 0, bC0 = 0, bC1 = 0, bC2 = 0, bN0 = 0, bN1 = 0, bN2 = 0;
+        int bNb = -1, bN = 0;
+        const double pnx = s_nx[p], pny = s_ny[p], pnz = s_nz[p];
+        double ps[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) ps[k] = ld_agd(&gst[(size_t)p * 9 + k]);
+        const int pN = s_N[p];
+        for (int c0 = 0; c0 < nc; c0 += 64) {
+            const int ci = c0 + lane;
+            const bool in = ci < nc;
+            const int nb = in ? s_cand[ci] : p;
+            const bool pass = in && fabs(pnx * s_nx[nb] + pny * s_ny[nb] + pnz * s_nz[nb]) >= C.simMerge;
+            double mMse = 0, cen[3] = {0, 0, 0}, nrm[3] = {0, 0, 0};
+            int mN = 0;
+            if (pass) {
+                msl_peac_stats t;
+                double y[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) y[k] = ld_agd(&gst[(size_t)nb * 9 + k]);
+                t.sx = ps[0] + y[0]; t.sy = ps[1] + y[1]; t.sz = ps[2] + y[2]; t.sxx = ps[3] + y[3]; t.syy = ps[4] + y[4]; t.szz = ps[5] + y[5];
+                t.sxy = ps[6] + y[6]; t.syz = ps[7] + y[7]; t.sxz = ps[8] + y[8]; t.N = pN + s_N[nb]; t.nouse = 0;
+                double curv;
+                plane_fit(t, cen, nrm, mMse, curv);
+                mN = t.N;
+            }
+            const unsigned long long pm = __ballot(pass);
+            const int lim = min(64, nc - c0);
+            int jBest = -1;
+            for (int j = 0; j < lim; j++) {
+                if (!((pm >> j) & 1ull)) continue;
+                const double m = __shfl(mMse, j, 64);
+                if (!have || bMse > m || (bMse == m && (double)bN < m)) { have = true; bMse = m; bN = __shfl(mN, j, 64); jBest = j; }   // (sic: N against mse, :1005)
+            }
+            if (jBest >= 0) {   // the best so far lies in this chunk: fetch the rest of its fit
+                bNb = __shfl(nb, jBest, 64);
+                bC0 = __shfl(cen[0], jBest, 64); bC1 = __shfl(cen[1], jBest, 64); bC2 = __shfl(cen[2], jBest, 64);
+                bN0 = __shfl(nrm[0], jBest, 64); bN1 = __shfl(nrm[1], jBest, 64); bN2 = __shfl(nrm[2], jBest, 64);
+            }
+        }
+        const double tm = C.depthSigma * bC2 * bC2 + C.stdTolMerge;   // ParamSet::T_mse(P_MERGING): pow(.., 2) is the product
+        if (have && bMse < tm * tm) {
+            const int id = nNodes++, nb = bNb;
+            if (lane < 9) st_agd(&gst[(size_t)id * 9 + lane], ld_agd(&gst[(size_t)p * 9 + lane]) + ld_agd(&gst[(size_t)nb * 9 + lane]));
+            if (lane == 0) {
+                s_mse[id] = bMse; s_nx[id] = bN0; s_ny[id] = bN1; s_nz[id] = bN2; s_cz[id] = bC2; s_N[id] = bN; s_nouse[id] = 0;
+                s_rid[id] = s_N[p] >= s_N[nb] ? s_rid[p] : s_rid[nb];
+                st_agd(&gcxy[2 * id], bC0); st_agd(&gcxy[2 * id + 1], bC1);
+                heap_push(id, bMse);
+                // mergeNbsFrom (AHCPlaneSeg.hpp:398-436): union of the two disjoint sets
+                const int xr = ds_find(s_rid[p]), yr = ds_find(s_rid[nb]);
+                if (xr != yr) {
+                    if (s_size[xr] < s_size[yr]) { s_parent[xr] = yr; s_size[yr] += s_size[xr]; }
+                    else { s_parent[yr] = xr; s_size[xr] += s_size[yr]; }
+                }
+                s_nouse[p] = 1; s_nouse[nb] = 1;
+            }
+            hcount = __shfl(hcount, 0, 64);
+            // neighbours of the new node = union of both neighbour sets without the two merged nodes; both old rows are cleared
+            const int nu = list_bits([&](int w) {
+                unsigned u = ld_ag(&rows[(size_t)p * words + w]) | ld_ag(&rows[(size_t)nb * words + w]);
+                if (w == (p >> 5)) u &= ~(1u << (p & 31));
+                if (w == (nb >> 5)) u &= ~(1u << (nb & 31));
+                st_ag(&rows[(size_t)id * words + w], u);
+                st_ag(&rows[(size_t)p * words + w], 0u); st_ag(&rows[(size_t)nb * words + w], 0u);
+                return u;
+            });
+            for (int i = lane; i < nu; i += 64) {
+                unsigned *r = rows + (size_t)s_cand[i] * words;
+                atomicOr(&r[id >> 5], 1u << (id & 31));
+                atomicAnd(&r[p >> 5], ~(1u << (p & 31)));
+                atomicAnd(&r[nb >> 5], ~(1u << (nb & 31)));
+            }
+            drain();
+        } else {
+            if (s_N[p] >= C.minSupport) emit_plane(p);
+            isolate(p, nc);
+        }
+        __syncthreads();
+        ++step;
+    }
+    while (hcount > 0) {   // (only reached when max_step stopped the loop above; the reference does not test nouse here either)
+        int p = 0;
+        if (lane == 0) p = heap_pop();
+        p = __shfl(p, 0, 64);
+        hcount = __shfl(hcount, 0, 64);
+        __syncthreads();
+        if (s_N[p] >= C.minSupport) emit_plane(p);
+        const int nc = list_bits([&](int w) { return ld_ag(&rows[(size_t)p * words + w]); });
+        isolate(p, nc);
+        __syncthreads();
+    }
+    if (lane == 0) C.nPlanes[f] = nPl <= C.maxPl ? nPl : -1;
+    for (int b = lane; b < nB; b += 64) { C.parent[(size_t)f * nB + b] = s_parent[b]; C.setSize[(size_t)f * nB + b] = s_size[b]; }
+}
+
 // ---- host side: agglomerative clustering over the block graph -----------------------------------------------------------------
 struct Thresholds {
     msl_peac_params p;
@@ -287,6 +513,46 @@ public:
     }
 
     // returns the number of extracted planes; member[H * W] receives PlaneFitter::membershipImg
+    // Device-clustering path, phase 1: graph initialisation only (AHCPlaneFitter.hpp:756-928); the initial heap (in the order the pushes left
+    // it) and the edge list go to k_peac_cluster.  Returns false if the edge list does not fit.
+    bool graph_for_device(const msl_peac_block *blocks, int *heapOut, int *heapCount, int *edgesOut, int *edgeCount, int maxE) {
+        parent_.resize((size_t)Nw * Nh); setSize_.assign((size_t)Nw * Nh, 1);
+        for (size_t i = 0; i < parent_.size(); i++) parent_[i] = (int)i;
+        nNodes_ = 0; planes_.clear(); growQ_.clear(); heap_.clear();
+        edges_.clear(); recordEdges_ = true;
+        build_graph(blocks);
+        recordEdges_ = false;
+        if ((int)edges_.size() / 2 > maxE) return false;
+        std::copy(heap_.begin(), heap_.end(), heapOut); *heapCount = (int)heap_.size();
+        std::copy(edges_.begin(), edges_.end(), edgesOut); *edgeCount = (int)edges_.size() / 2;
+        return true;
+    }
+    // Phase 2: the planes k_peac_cluster extracted (extraction order) and its disjoint set; erosion, region growing and the final merge follow as
+    // in run().  Only the plane nodes exist here; their ids keep the order of the original ids (the neighbour sets iterate in id order).
+    int finish_from_device(const PlaneOut *pl, int np, const int *parent, const int *setSize, int32_t *member) {
+        parent_.assign(parent, parent + (size_t)Nw * Nh); setSize_.assign(setSize, setSize + (size_t)Nw * Nh);
+        nNodes_ = 0; planes_.clear(); growQ_.clear(); heap_.clear();
+        std::vector<int> &order = relabel_, &newId = oldPlanes_;
+        order.resize(np); newId.resize(np);
+        for (int i = 0; i < np; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [pl](int a, int b) { return pl[a].id < pl[b].id; });
+        for (int k = 0; k < np; k++) {
+            const PlaneOut &O = pl[order[k]];
+            Node nd;
+            nd.st.sx = O.st[0]; nd.st.sy = O.st[1]; nd.st.sz = O.st[2]; nd.st.sxx = O.st[3]; nd.st.syy = O.st[4]; nd.st.szz = O.st[5];
+            nd.st.sxy = O.st[6]; nd.st.syz = O.st[7]; nd.st.sxz = O.st[8]; nd.st.N = O.N; nd.st.nouse = 0;
+            for (int c = 0; c < 3; c++) { nd.center[c] = O.center[c]; nd.normal[c] = O.normal[c]; }
+            nd.mse = O.mse; nd.curvature = 0; nd.N = O.N; nd.rid = O.rid; nd.nouse = false;
+            newId[order[k]] = add_node(nd);
+        }
+        for (int i = 0; i < np; i++) planes_.push_back(newId[i]);
+        std::sort(planes_.begin(), planes_.end(), [this](int a, int b) { return nodes_[b].N < nodes_[a].N; });   // PlaneSegSizeCmp, as at the end of cluster()
+        member_ = member;
+        std::fill(member, member + (size_t)W * H, -1);
+        if (T.p.do_refine) refine();
+        return (int)planes_.size();
+    }
+
     int run(const msl_peac_block *blocks, int32_t *member) {
         const char *tenv = getenv("MSL_PEAC_TIMING");
         const bool timing = tenv && atoi(tenv) >= 2;
@@ -327,7 +593,8 @@ private:
     int winW = 0, winH = 0, Nw = 0, Nh = 0;
     std::vector<Node> nodes_;                 // node pool: [0, nNodes_) are live; the rest keep their neighbour vectors' capacity for the next frame
     int nNodes_ = 0;
-    std::vector<int> G_, u_, oldPlanes_, relabel_;
+    std::vector<int> G_, u_, oldPlanes_, relabel_, edges_;
+    bool recordEdges_ = false;
     std::vector<char> validPlane_;
     std::vector<float> distMap_;
     int add_node(const Node &src) {
@@ -351,7 +618,10 @@ private:
     static double similarity(const Node &a, const Node &b) { return std::abs(a.normal[0] * b.normal[0] + a.normal[1] * b.normal[1] + a.normal[2] * b.normal[2]); }
     static void link_one(std::vector<int> &v, int id) { auto it = std::lower_bound(v.begin(), v.end(), id); if (it == v.end() || *it != id) v.insert(it, id); }
     static void unlink_one(std::vector<int> &v, int id) { auto it = std::lower_bound(v.begin(), v.end(), id); if (it != v.end() && *it == id) v.erase(it); }
-    void connect(int a, int b) { link_one(nodes_[a].nbs, b); link_one(nodes_[b].nbs, a); }
+    void connect(int a, int b) {
+        link_one(nodes_[a].nbs, b); link_one(nodes_[b].nbs, a);
+        if (recordEdges_) { edges_.push_back(a); edges_.push_back(b); }
+    }
     void isolate(int a) { for (int nb : nodes_[a].nbs) unlink_one(nodes_[nb].nbs, a); nodes_[a].nbs.clear(); }
 
     void build_graph(const msl_peac_block *blocks) {
@@ -646,6 +916,9 @@ struct Scratch {
     // The extractor's own stream (non-blocking, highest priority): its few small kernels and copies must neither wait for nor hold up the frame-batched
     // ORB / surfel work queued on the device.  Work the caller enqueued on the legacy default stream before the call is still ordered first (event).
     hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+    // device clustering (k_peac_cluster)
+    void *rows = nullptr, *gst = nullptr, *gcxy = nullptr, *cin = nullptr, *cout = nullptr; size_t rowsCap = 0, gstCap = 0, gcxyCap = 0, cinCap = 0, coutCap = 0;
+    bool clusterLdsSet = false;
 };
 Scratch g_scratch[16];
 std::mutex g_scratchMutex;
@@ -794,6 +1067,10 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
     if (!params || !membership_out || params->min_support < 1) { set_error("msl_peac_membership_batch: invalid argument"); return MSL_ERR_INVALID; }
     std::vector<msl_peac_block> hb;
     std::vector<uint16_t> half;       // raw depth of the cloud vertices, [frames][ch][cw]
+    std::vector<int> hOutI;           // device clustering result: plane count per frame, disjoint-set parents and sizes
+    std::vector<PlaneOut> hPlanes;
+    bool usedDevice = false;
+    int maxPl = 0;
     const int cw = (width + 1) / 2, ch = (height + 1) / 2;
     size_t nBlocks = 0;
     const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
@@ -812,13 +1089,71 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
         PEAC_TRY(hipMemcpyAsync(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipMemcpyAsync(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipStreamSynchronize(st));
+        // Agglomerative clustering on the device (one wave per frame) when a frame's node data fits the LDS; MSL_PEAC_CLUSTER=host keeps it on the
+        // host workers (same results: tests/test_peac_gpu.py runs both).
+        const int maxN = 2 * (int)nBlocks, words = (maxN + 31) / 32;
+        maxPl = (int)std::min<size_t>(nBlocks, 256);
+        const size_t ldsBytes = (size_t)maxN * (6 * sizeof(double) + 4 * sizeof(int) + 1) + 2 * nBlocks * sizeof(int) + 64;
+        const char *mode = getenv("MSL_PEAC_CLUSTER");
+        if (ldsBytes <= 150 * 1024 && !(mode && !strcmp(mode, "host"))) {
+            Scratch &sc = g_scratch[device & 15];
+            const int maxE = 4 * (int)nBlocks;
+            // graph initialisation on the host workers -> initial heap + edge list per frame
+            const size_t inInts = (size_t)n_frames * (nBlocks + 1 + 2 * (size_t)maxE + 1);
+            std::vector<int> hIn(inInts);
+            int *hHeap = hIn.data(), *hHeapN = hHeap + (size_t)n_frames * nBlocks, *hEdges = hHeapN + n_frames, *hEdgeN = hEdges + (size_t)n_frames * maxE * 2;
+            std::atomic<int> bad{0};
+            SegPool::get().run(n_frames, [&](int f, FrameSegmenter &seg) {
+                seg.configure(*params, half.data() + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
+                if (!seg.graph_for_device(hb.data() + (size_t)f * nBlocks, hHeap + (size_t)f * nBlocks, hHeapN + f, hEdges + (size_t)f * maxE * 2, hEdgeN + f, maxE)) bad++;
+            });
+            if (!bad.load()) {
+                const size_t rowsB = sizeof(unsigned) * (size_t)n_frames * maxN * words, gstB = sizeof(double) * 9 * (size_t)n_frames * maxN,
+                             gcxyB = sizeof(double) * 2 * (size_t)n_frames * maxN;
+                const size_t outInts = (size_t)n_frames * (1 + 2 * nBlocks), outB = sizeof(int) * ((outInts + 1) & ~(size_t)1) + sizeof(PlaneOut) * (size_t)n_frames * maxPl;
+                PEAC_TRY(grow(sc.rows, sc.rowsCap, rowsB)); PEAC_TRY(grow(sc.gst, sc.gstCap, gstB)); PEAC_TRY(grow(sc.gcxy, sc.gcxyCap, gcxyB));
+                PEAC_TRY(grow(sc.cin, sc.cinCap, sizeof(int) * inInts)); PEAC_TRY(grow(sc.cout, sc.coutCap, outB));
+                PEAC_TRY(hipMemcpyAsync(sc.cin, hIn.data(), sizeof(int) * inInts, hipMemcpyHostToDevice, st));
+                PEAC_TRY(hipMemsetAsync(sc.rows, 0, rowsB, st));
+                ClusterDev C;
+                C.nB = (int)nBlocks; C.maxN = maxN; C.words = words; C.minSupport = params->min_support; C.maxStep = params->max_step; C.maxE = maxE; C.maxPl = maxPl;
+                C.depthSigma = params->depth_sigma; C.stdTolMerge = params->std_tol_merge; C.simMerge = params->similarity_th_merge;
+                C.blocks = dBlocks; C.rows = (unsigned *)sc.rows; C.gst = (double *)sc.gst; C.gcxy = (double *)sc.gcxy;
+                int *dIn = (int *)sc.cin;
+                C.heap0 = dIn; C.heapCount = dIn + (size_t)n_frames * nBlocks; C.edges = dIn + (size_t)n_frames * (nBlocks + 1);
+                C.edgeCount = dIn + (size_t)n_frames * (nBlocks + 1 + 2 * (size_t)maxE);
+                int *dOut = (int *)sc.cout;
+                C.nPlanes = dOut; C.parent = dOut + n_frames; C.setSize = dOut + n_frames + (size_t)n_frames * nBlocks;
+                C.planes = reinterpret_cast<PlaneOut *>(dOut + ((outInts + 1) & ~(size_t)1));
+                if (!sc.clusterLdsSet) {
+                    PEAC_TRY(hipFuncSetAttribute((const void *)k_peac_cluster, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                    sc.clusterLdsSet = true;
+                }
+                hipLaunchKernelGGL(k_peac_cluster, dim3((unsigned)n_frames), dim3(64), ldsBytes, st, C);
+                PEAC_TRY(hipGetLastError());
+                hOutI.resize(outInts); hPlanes.resize((size_t)n_frames * maxPl);
+                PEAC_TRY(hipMemcpyAsync(hOutI.data(), dOut, sizeof(int) * outInts, hipMemcpyDeviceToHost, st));
+                PEAC_TRY(hipMemcpyAsync(hPlanes.data(), C.planes, sizeof(PlaneOut) * hPlanes.size(), hipMemcpyDeviceToHost, st));
+                PEAC_TRY(hipStreamSynchronize(st));
+                usedDevice = true;
+                for (int f = 0; f < n_frames; f++) if (hOutI[f] < 0) usedDevice = false;   // more planes than the hand-over holds: host path for this call
+            }
+        }
     }
     const auto tb1 = std::chrono::steady_clock::now();
-    segment_frames(*params, hb.data(), nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
+    if (!usedDevice) segment_frames(*params, hb.data(), nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
+    else
+        SegPool::get().run(n_frames, [&](int f, FrameSegmenter &seg) {
+            seg.configure(*params, half.data() + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
+            const int n = seg.finish_from_device(hPlanes.data() + (size_t)f * maxPl, hOutI[f], hOutI.data() + n_frames + (size_t)f * nBlocks,
+                                                 hOutI.data() + n_frames + (size_t)(n_frames + f) * nBlocks, membership_out + (size_t)f * cw * ch);
+            if (n_planes_out) n_planes_out[f] = n;
+        });
     if (timing) {
         const auto tb2 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        fprintf(stderr, "[msl_peac] batch of %d: device fit + copies %ld us, host clustering %ld us\n", n_frames, us(tb0, tb1), us(tb1, tb2));
+        fprintf(stderr, "[msl_peac] batch of %d: device fit%s + copies %ld us, host stage %ld us\n", n_frames, usedDevice ? " + device clustering" : "", us(tb0, tb1),
+                us(tb1, tb2));
     }
     return MSL_OK;
 }

@@ -83,3 +83,34 @@ def test_membership_feeds_surfel_fusion(oracle):
     assert_seeds_close(g.debug_seeds(), o.seeds())
     assert_surfels_close(lg, lo, "local"); assert_surfels_close(ng, no, "new")
     g.close()
+
+
+def test_device_and_host_clustering_agree(oracle, monkeypatch):
+    """The agglomerative clustering runs on the device (k_peac_cluster, one wave per frame) by default and on the host workers with
+    MSL_PEAC_CLUSTER=host (and for frames whose node data does not fit the LDS): the same membership image either way."""
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = synth.ICL
+    fac = np.float32(1 / 5000.0)
+    frames = []
+    for k, dr, box in ((0, 0.0, False), (100, 0.001, True), (170, 0.0, True), (250, 0.003, False), (300, 0.02, False), (33, 0.0005, False), (77, 0.001, True)):
+        d = _depth(k, I, dr)
+        if box:
+            d[150:330, 260:470] = 5000
+        frames.append(d)
+    stack = np.stack(frames)
+    for kw in (dict(), dict(min_support=500, erode_type=0), dict(window_w=8, window_h=6, min_support=1000), dict(max_step=200)):
+        p = peac.default_params()
+        po = oracle_lib.peac_default_params()
+        for k, v in kw.items():
+            p[k] = v; po[k] = v
+        monkeypatch.delenv("MSL_PEAC_CLUSTER", raising=False)
+        dev, nd = peac.plane_membership(stack, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
+        monkeypatch.setenv("MSL_PEAC_CLUSTER", "host")
+        host, nh = peac.plane_membership(stack, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
+        monkeypatch.delenv("MSL_PEAC_CLUSTER", raising=False)
+        assert np.array_equal(nd, nh), (kw, nd, nh)
+        assert np.array_equal(dev, host), (kw, np.argwhere(dev != host)[:5])
+        for f in (1, 4):
+            want, nw, _ = oracle_lib.peac_run(frames[f], I["fx"], I["fy"], I["cx"], I["cy"], fac, params=po)
+            assert nd[f] == nw and np.array_equal(dev[f], want), (kw, f)
