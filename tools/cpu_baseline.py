@@ -112,8 +112,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=48, help="frames of the single-thread sample")
     ap.add_argument("--frames-10t", type=int, default=32, help="keyframes of the 10-thread SurfelFusion sample")
-    ap.add_argument("--frames-per-proc", type=int, default=4, help="frames each process of the throughput run handles")
-    ap.add_argument("--procs", type=int, default=0, help="processes of the throughput run (0 = one per logical CPU, memory permitting)")
+    ap.add_argument("--frames-per-proc", type=int, default=0, help="frames each process of the throughput run handles (0 = 16, negative = no throughput run)")
+    ap.add_argument("--procs", type=int, default=0, help="processes of the throughput run (0 = one per usable CPU, memory permitting)")
     ap.add_argument("--surfels", type=int, default=1_000_000)
     ap.add_argument("--size", default="640x480")
     ap.add_argument("--intrinsics", default="TUM1")
@@ -142,13 +142,15 @@ def main():
                                     "sample": f"{nkf} keyframes, SurfelFusion only with the reference's THREAD_NUM=10 fork/join per stage, "
                                               f"{args.surfels} seeded surfels, {W}x{H}",
                                     "surfel_ms_per_keyframe": round(1e3 * t_sf / max(nkf, 1), 2)}
-    if args.frames_per_proc > 0:
+    if args.frames_per_proc >= 0:
         per_proc = 96 * W * H * 3 + 2 * 56 * (args.surfels if do_sf else 0) + (64 << 20)   # oracle scratch + map + copy + interpreter
         P = args.procs or max(1, min(ncpu, int(0.5 * mem_available_bytes() // per_proc)))
+        # bounded sample: about 15 s of CPU work per process at ~0.11 s per frame (every process handles the same number of frames)
+        fpp = args.frames_per_proc or 16
         ctx = mp.get_context("fork")
         barrier = ctx.Barrier(P)
         q = ctx.Queue()
-        procs = [ctx.Process(target=_worker, args=(inp, W, H, args.frames_per_proc, do_orb, do_sf, kfe, barrier, q)) for _ in range(P)]
+        procs = [ctx.Process(target=_worker, args=(inp, W, H, fpp, do_orb, do_sf, kfe, barrier, q)) for _ in range(P)]
         for p in procs:
             p.start()
         res = [q.get() for _ in procs]
@@ -159,8 +161,8 @@ def main():
             out["throughput"] = {"error": err[0][1]}
         else:
             wall = max(r[1] for r in res) - min(r[0] for r in res)
-            out["throughput"] = {"value": round(P * args.frames_per_proc / wall, 2), "unit": "frames/s", "cores": P,
-                                 "sample": f"{P} independent sequences (one single-threaded process per CPU this container may use: affinity mask and cgroup cpu.max) x {args.frames_per_proc} frames, "
+            out["throughput"] = {"value": round(P * fpp / wall, 2), "unit": "frames/s", "cores": P,
+                                 "sample": f"{P} independent sequences (one single-threaded process per CPU this container may use: affinity mask and cgroup cpu.max) x {fpp} frames, "
                                            f"{what}, {W}x{H}",
                                  "wall_s": round(wall, 3)}
     print(json.dumps(out), flush=True)
