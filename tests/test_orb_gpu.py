@@ -202,3 +202,32 @@ def test_second_gaussian_generation_variant_library():
     env = dict(os.environ, MSL_LIB=lib, MSL_ORACLE_LIB=olib)
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_pyramid_fused_and_per_level_launches_agree(oracle):
+    """k_pyramid (all levels in one launch, tiles chained through LDS) is the default; MSL_ORB_PYRAMID=levels keeps one k_resize launch per
+    level (also the fallback when a tile chain does not fit the LDS).  Both give the oracle's levels, at several geometries."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from manhattanslam_amd import ORBextractor, synth\n"
+        "from tests import oracle_lib\n"
+        "o = oracle_lib.load()\n"
+        "for (w, h, nl, sf) in ((640, 480, 8, 1.2), (1280, 960, 8, 1.2), (752, 480, 5, 1.5), (320, 240, 12, 1.1), (480, 360, 3, 2.0)):\n"
+        "    img = synth.orb_frame(synth.ORB_SEED + 9, w, h)\n"
+        "    ex = ORBextractor(800, sf, nl, 20, 7, max_width=w, max_height=h)\n"
+        "    kg, dg = ex(img)\n"
+        "    oe = o.orb_create(800, sf, nl, 20, 7)\n"
+        "    ko, do = oe.extract(img)\n"
+        "    for l in range(1, nl):\n"
+        "        assert np.array_equal(ex.debug_level(0, l), oe.level(l)), (w, h, l)\n"
+        "    assert kg.tobytes() == ko.tobytes() and np.array_equal(dg, do), (w, h)\n"
+        "print('pyramid ok')\n" % root)
+    for mode in ("fused", "levels"):
+        env = dict(os.environ, MSL_ORB_PYRAMID=mode)
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "pyramid ok" in r.stdout, mode + "\n" + r.stdout + r.stderr
