@@ -835,7 +835,7 @@ inline int cv_floor_d(double v) { int i = (int)v; return i - (i > v); }
 inline int cv_ceil_d(double v) { int i = (int)v; return i + (i < v); }
 
 enum { KID_RESIZE = 0, KID_FAST, KID_OCTREE, KID_BLUR, KID_DESCRIBE, KID_COPY };
-const char *kKernelNames[MSL_ORB_NKERNELS] = {"k_resize", "k_fast", "k_octree", "k_blur", "k_describe", "copy"};
+const char *kKernelNames[MSL_ORB_NKERNELS] = {"k_pyramid", "k_fast", "k_octree", "k_blur", "k_describe", "copy"};
 
 }  // namespace
 
