@@ -1,7 +1,7 @@
 """Floors: superpixel stage alone (tiny map), at several batch sizes."""
 import sys, os, time, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from manhattanslam_amd import SurfelFusion, synth, SURFEL_DTYPE
 I = synth.TUM1
