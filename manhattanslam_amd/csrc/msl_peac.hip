@@ -11,10 +11,12 @@
 //                   raster order (the reference's summation order, so the FP64 sums are the reference's bit for bit); one lane
 //                   runs the PCA plane fit (Stats::compute, :148-183) with the 3x3 symmetric eigen-solve of
 //                   include/peac/eig33sym.hpp:71-75 (Eigen::SelfAdjointEigenSolver, restated below).
-//   Host (sequential by nature: a min-MSE priority queue of merges, a FIFO region growing), one thread per frame, index based
-//   (node pool + sorted adjacency vectors instead of shared_ptr / std::set<PlaneSeg*>):
-//     graph initialisation (AHCPlaneFitter.hpp:756-928), agglomerative clustering (:939-1143), block erosion + seeds (:490-596),
-//     region growing (:422-471), final merge and relabelling (:296-372).
+//     k_peac_cluster ONE WAVE PER FRAME: the agglomerative clustering (AHCPlaneFitter.hpp:939-1143).  A sequential chain of pops, but every pop fits a
+//                   plane for each neighbour of the popped node (one per lane); binary heap and disjoint set in LDS, neighbour sets as a bit matrix.
+//   Host: graph initialisation (AHCPlaneFitter.hpp:756-928; needs cos()), then -- after the device clustering -- block erosion + seeds (:490-596), the
+//   FIFO region growing (:422-471), final merge and relabelling (:296-372): order-dependent pixel work, one frame per worker thread at a time, index based
+//   (node pool + sorted adjacency vectors instead of shared_ptr / std::set<PlaneSeg*>).  The host also keeps the whole clustering (cluster()) for frames
+//   whose node data does not fit the LDS, for MSL_PEAC_CLUSTER=host, and for msl_peac_membership_from_blocks (no device).
 //
 // The membership image keeps every quirk a consumer can observe: rid2plid[] default-inserts plane 0 for an
 // unknown set id, pixels whose plane was eroded keep their old id, rejected pixels keep their visit counters -2..-6.
