@@ -53,3 +53,15 @@ _, depth4, _, _ = synth.surfel_frame(frame4, intr=I4, dropout=drop4)
 mem4, npl4, blk4 = oracle_lib.peac_run(synth.depth_u16(depth4), I4["fx"], I4["fy"], I4["cx"], I4["cy"], np.float32(1.0 / 5000.0))
 np.savez_compressed(os.path.join(OUT, "peac_membership_640x480.npz"), frame=frame4, dropout=drop4, nplanes=npl4, membership=mem4, blocks=blk4)
 print("peac membership golden:", npl4, "planes")
+# SearchByProjection on two seeded synthetic pairs (forward motion, clustered keypoints; no motion, sparse)
+from tests import match_scenes as ms  # noqa: E402
+mp = ms.params(None, 15.0, True, dtype=oracle_lib.MATCH_PARAMS_DTYPE)
+gm = {}
+for name, (seed, nc, nl, tz, cluster) in {"a": (101, 1000, 950, 0.3, True), "b": (102, 900, 850, 0.0, False)}.items():
+    c, l, Tc, Tl = ms.random_pair(seed, mp, n_cur=nc, n_last=nl, tz=tz, cluster=cluster)
+    out, nm = oracle_lib.search_by_projection(mp, c, l, Tc, Tl)
+    gm[f"{name}_spec"] = np.array([seed, nc, nl, int(cluster)], np.int64); gm[f"{name}_tz"] = np.float64(tz)
+    gm[f"{name}_matches"] = out; gm[f"{name}_nmatches"] = np.int32(nm)
+    gm[f"{name}_input_sha256"] = hashlib.sha256(c["desc"].tobytes() + l["desc"].tobytes() + l["xyz"].tobytes()).hexdigest()
+np.savez_compressed(os.path.join(OUT, "match_pairs.npz"), th=15.0, **gm)
+print("match golden:", int(gm["a_nmatches"]), int(gm["b_nmatches"]), "matches")

@@ -54,3 +54,32 @@ def test_peac_golden_bit_exact():
     assert hashlib.sha256(cloud[0].tobytes()).hexdigest() == str(g["cloud_sha256"])
     assert st[0].tobytes() == g["stats"].tobytes()
     assert 0 < int((st[0]["nouse"] == 1).sum()) < st.shape[1]
+
+
+def test_peac_membership_golden_bit_exact():
+    """The whole plane extractor (block fit and clustering on the device, pixel stages on the host) against the committed membership image."""
+    from manhattanslam_amd import synth, peac
+    g = np.load(os.path.join(GOLD, "peac_membership_640x480.npz"))
+    I = synth.ICL
+    _, depth, _, _ = synth.surfel_frame(int(g["frame"]), intr=I, dropout=float(g["dropout"]))
+    d16 = synth.depth_u16(depth)
+    member, n = peac.plane_membership(np.stack([d16, d16, d16]), I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+    for f in range(3):
+        assert n[f] == int(g["nplanes"]) and np.array_equal(member[f], g["membership"]), f
+    assert peac.block_fit(d16, I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))[0].tobytes() == g["blocks"].tobytes()
+
+
+def test_match_golden_bit_exact():
+    from manhattanslam_amd import match, MATCH_PARAMS_DTYPE
+    from tests import match_scenes as ms
+    g = np.load(os.path.join(GOLD, "match_pairs.npz"))
+    p = ms.params(None, float(g["th"]), True, dtype=MATCH_PARAMS_DTYPE)
+    cur, last, Tc, Tl = [], [], [], []
+    for name in ("a", "b"):
+        seed, nc, nl, cluster = (int(v) for v in g[f"{name}_spec"])
+        c, l, a, b = ms.random_pair(seed, p, n_cur=nc, n_last=nl, tz=float(g[f"{name}_tz"]), cluster=bool(cluster))
+        assert hashlib.sha256(c["desc"].tobytes() + l["desc"].tobytes() + l["xyz"].tobytes()).hexdigest() == str(g[f"{name}_input_sha256"])
+        cur.append(c); last.append(l); Tc.append(a); Tl.append(b)
+    got, nm = match.search_by_projection_batch(p, cur, last, np.stack(Tc), np.stack(Tl))
+    for f, name in enumerate(("a", "b")):
+        assert nm[f] == int(g[f"{name}_nmatches"]) and np.array_equal(got[f], g[f"{name}_matches"]), name

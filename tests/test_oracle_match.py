@@ -135,3 +135,19 @@ def test_greedy_blocking_and_overwrite_known_answer(oracle):
                     angle=np.zeros(2, np.float32))
         m, n = oracle_lib.search_by_projection(p, cur, last, np.eye(4, dtype=np.float32), np.eye(4, dtype=np.float32))
         assert list(m) == want and n == nm
+
+
+def test_golden_match(oracle):
+    """Committed golden vectors of SearchByProjection (tests/golden/make_golden.py)."""
+    import hashlib
+    import os
+    from tests import oracle_lib
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "match_pairs.npz"))
+    p = ms.params(None, float(g["th"]), True, dtype=oracle_lib.MATCH_PARAMS_DTYPE)
+    for name in ("a", "b"):
+        seed, nc, nl, cluster = (int(v) for v in g[f"{name}_spec"])
+        c, l, Tc, Tl = ms.random_pair(seed, p, n_cur=nc, n_last=nl, tz=float(g[f"{name}_tz"]), cluster=bool(cluster))
+        assert hashlib.sha256(c["desc"].tobytes() + l["desc"].tobytes() + l["xyz"].tobytes()).hexdigest() == str(g[f"{name}_input_sha256"])
+        out, nm = oracle_lib.search_by_projection(p, c, l, Tc, Tl)
+        assert nm == int(g[f"{name}_nmatches"]) and np.array_equal(out, g[f"{name}_matches"])
+    assert int(g["a_nmatches"]) > 300 and int(g["b_nmatches"]) > 300
