@@ -253,7 +253,8 @@ MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth
  * msl_peac_block_fit: cloud + block statistics + PCA on the GPU (one wave per window, FP64, the reference's summation order).
  * msl_peac_membership_batch: PlaneDetection::readDepthImage + runPlaneDetection (src/PlaneExtractor.cpp:44-81) for n_frames
  *   depth images: block fit on the GPU; graph initialisation (AHCPlaneFitter.hpp:756-928) on the host; agglomerative clustering (:939-1143)
- *   on the GPU, one wave per frame (on the host workers if a frame's node data does not fit the LDS, or with MSL_PEAC_CLUSTER=host); block
+ *   on the GPU, one wave per frame, for calls of more than about three frames per usable CPU (on the host workers for smaller calls -- a lone
+ *   frame is clustered faster by one core --, if a frame's node data does not fit the LDS, or as MSL_PEAC_CLUSTER=host / device says); block
  *   erosion (:490-596), region growing (:422-471) and the final merge / relabelling (:296-372) on the host (order-dependent pixel work: a
  *   FIFO flood fill), one frame per worker thread at a time (as many workers as the process may use CPUs: affinity mask and cgroup quota,
  *   at most 64).  Device-resident input must be complete, or enqueued on the legacy default stream, when the call is made.

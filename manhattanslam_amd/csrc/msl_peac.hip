@@ -862,6 +862,7 @@ int usable_cpus() {
 class SegPool {
 public:
     static SegPool &get() { static SegPool p; return p; }
+    int workers() const { return maxWorkers_ + 1; }   // the caller takes part
     // fn(frame, workspace) for frame = 0 .. nFrames-1, each exactly once; returns when all are done
     void run(int nFrames, const std::function<void(int, FrameSegmenter &)> &fn) {
         std::lock_guard<std::mutex> one(callMutex_);   // one batch at a time
@@ -1091,13 +1092,17 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
         PEAC_TRY(hipMemcpyAsync(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipMemcpyAsync(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipStreamSynchronize(st));
-        // Agglomerative clustering on the device (one wave per frame) when a frame's node data fits the LDS; MSL_PEAC_CLUSTER=host keeps it on the
-        // host workers (same results: tests/test_peac_gpu.py runs both).
+        // Agglomerative clustering on the device (one wave per frame) when a frame's node data fits the LDS and the call is large enough;
+        // MSL_PEAC_CLUSTER=host / device forces one side (same results: tests/test_peac_gpu.py runs both).
         const int maxN = 2 * (int)nBlocks, words = (maxN + 31) / 32;
         maxPl = (int)std::min<size_t>(nBlocks, 256);
         const size_t ldsBytes = (size_t)maxN * (6 * sizeof(double) + 4 * sizeof(int) + 1) + 2 * nBlocks * sizeof(int) + 64;
+        // auto: the device clusters any number of frames in the time of one (~13-20 ms, one latency-bound wave per frame), a host worker needs ~6-7 ms
+        // per frame: the device wins once a call holds more than about three frames per usable CPU.
         const char *mode = getenv("MSL_PEAC_CLUSTER");
-        if (ldsBytes <= 150 * 1024 && !(mode && !strcmp(mode, "host"))) {
+        const bool forceHost = mode && !strcmp(mode, "host"), forceDev = mode && !strcmp(mode, "device");
+        const bool wantDevice = forceDev || (!forceHost && n_frames > 3 * SegPool::get().workers());
+        if (ldsBytes <= 150 * 1024 && wantDevice) {
             Scratch &sc = g_scratch[device & 15];
             const int maxE = 4 * (int)nBlocks;
             // graph initialisation on the host workers -> initial heap + edge list per frame

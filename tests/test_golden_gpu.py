@@ -56,9 +56,10 @@ def test_peac_golden_bit_exact():
     assert 0 < int((st[0]["nouse"] == 1).sum()) < st.shape[1]
 
 
-def test_peac_membership_golden_bit_exact():
+def test_peac_membership_golden_bit_exact(monkeypatch):
     """The whole plane extractor (block fit and clustering on the device, pixel stages on the host) against the committed membership image."""
     from manhattanslam_amd import synth, peac
+    monkeypatch.setenv("MSL_PEAC_CLUSTER", "device")
     g = np.load(os.path.join(GOLD, "peac_membership_640x480.npz"))
     I = synth.ICL
     _, depth, _, _ = synth.surfel_frame(int(g["frame"]), intr=I, dropout=float(g["dropout"]))

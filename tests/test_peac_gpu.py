@@ -86,8 +86,8 @@ def test_membership_feeds_surfel_fusion(oracle):
 
 
 def test_device_and_host_clustering_agree(oracle, monkeypatch):
-    """The agglomerative clustering runs on the device (k_peac_cluster, one wave per frame) by default and on the host workers with
-    MSL_PEAC_CLUSTER=host (and for frames whose node data does not fit the LDS): the same membership image either way."""
+    """The agglomerative clustering runs on the device (k_peac_cluster, one wave per frame) for large calls and on the host workers for small ones
+    (and for frames whose node data does not fit the LDS); MSL_PEAC_CLUSTER=device / host forces one side: the same membership image either way."""
     from manhattanslam_amd import peac, synth
     from tests import oracle_lib
     I = synth.ICL
@@ -104,7 +104,7 @@ def test_device_and_host_clustering_agree(oracle, monkeypatch):
         po = oracle_lib.peac_default_params()
         for k, v in kw.items():
             p[k] = v; po[k] = v
-        monkeypatch.delenv("MSL_PEAC_CLUSTER", raising=False)
+        monkeypatch.setenv("MSL_PEAC_CLUSTER", "device")
         dev, nd = peac.plane_membership(stack, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
         monkeypatch.setenv("MSL_PEAC_CLUSTER", "host")
         host, nh = peac.plane_membership(stack, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
