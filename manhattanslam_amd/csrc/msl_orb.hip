@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
     {
         int pitch;
         const uint8_t *img = level_ptr(P, frame, 0, pitch);
+        const unsigned m = ((1u << 22) + sw - 1) / sw;   // exact floor(i / sw) for i < 2^15, sw < 2^7 (regions are ~100 px wide)
         for (int i = threadIdx.x; i < sw * sh; i += 256) {
-            const int r = i / sw, c = i - r * sw;
+            const int r = (int)(((unsigned long long)(unsigned)i * m) >> 22), c = i - r * sw;
             s_pyr[i] = img[(size_t)(sy0 + r) * pitch + sx0 + c];
         }
     }
@@ -138,8 +139,9 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
         rx = P.pyrX[l * P.pyrTX + ti]; ry = P.pyrY[l * P.pyrTY + tj];
         const int dx0 = rx.needLo, dy0 = ry.needLo, dw = rx.needHi - rx.needLo, dh = ry.needHi - ry.needLo;
         uint8_t *out = P.pyr + (size_t)frame * P.pyrStride + D.off;
+        const unsigned m = ((1u << 22) + dw - 1) / dw;
         for (int i = threadIdx.x; i < dw * dh; i += 256) {
-            const int r = i / dw, c = i - r * dw;
+            const int r = (int)(((unsigned long long)(unsigned)i * m) >> 22), c = i - r * dw;
             const int dx = dx0 + c, dy = dy0 + r;
             const ResizeTap tx = P.taps[D.xtabOff + dx], ty = P.taps[D.ytabOff + dy];
             const uint8_t *r0 = src + (ty.s0 - sy0) * sw - sx0, *r1 = src + (ty.s1 - sy0) * sw - sx0;
@@ -1011,6 +1013,7 @@ int build_geometry(msl_orb *h, int W, int H) {
             if (l >= 1 && (D.lv[l].w < TX || D.lv[l].h < TY)) ok = false;
         }
         b0 = (b0 + 15) & ~(size_t)15;
+        for (int l = 0; l < L; l++) if (ex[l] >= 128 || (size_t)ex[l] * ey[l] >= (1u << 15)) ok = false;   // k_pyramid's multiply-shift row index
         if (ok && b0 + b1 <= 48 * 1024) { D.pyrTX = TX; D.pyrTY = TY; D.pyrBuf0 = (unsigned)b0; h->pyrLds = b0 + b1; }
     }
     D.cellsPerFrame = (int)cells.size();
