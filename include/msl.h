@@ -291,6 +291,23 @@ MSL_API int msl_peac_membership_batch(int device, const uint16_t *depth, size_t 
 MSL_API int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
                                             int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
                                             const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
+/* Everything the reference's PlaneDetection hands on after runPlaneDetection (include/PlaneExtractor.h:57-62, src/PlaneExtractor.cpp:77-80):
+ * msl_peac_membership_batch's outputs plus, per frame,
+ *   planes_out         HOST [n_frames][max_planes]      plane_filter.extractedPlanes[i]: normal, centre, MSE, N (src/Frame.cc:626-632 reads them);
+ *                                                       the call fails with MSL_ERR_CAPACITY if a frame has more than max_planes planes
+ *   vertex_offsets_out HOST [n_frames][max_planes + 1]  plane_vertices_[i] = vertex_indices_out[f][offsets[i] .. offsets[i + 1])
+ *   vertex_indices_out HOST [n_frames][ceil(h/2) * ceil(w/2)]  cloud vertex indices of every plane, raster order inside a plane (the pMembership
+ *                                                       argument of PlaneFitter::run, AHCPlaneFitter.hpp:341-361); needs params->do_refine
+ * msl_peac_extract_from_blocks: the same from block fits the caller already has (host stage only, no device). */
+typedef struct msl_peac_plane { double normal[3], center[3], mse; int32_t N, _pad; } msl_peac_plane;
+MSL_API int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
+                                   int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                   const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,
+                                   msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out);
+MSL_API int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
+                                         int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                         const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,
+                                         msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out);
 
 /* ---- widening, SURVEY.md 8(f) rank 3: Hamming matching by projection, the next consumer of the ORB descriptors ----
  * msl_match_by_projection_batch: n_pairs independent calls of

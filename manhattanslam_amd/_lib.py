@@ -28,6 +28,7 @@ PEAC_PARAMS_DTYPE = np.dtype([(n, "<i4") for n in ("window_w", "window_h", "min_
                                                    "similarity_th_merge", "similarity_th_refine", "depth_alpha", "depth_change_tol")])
 PEAC_BLOCK_DTYPE = np.dtype([(n, "<f8") for n in ("sx", "sy", "sz", "sxx", "syy", "szz", "sxy", "syz", "sxz")] + [("N", "<i4"), ("nouse", "<i4")] +
                             [("center", "<f8", (3,)), ("normal", "<f8", (3,)), ("mse", "<f8"), ("curvature", "<f8")])
+PEAC_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("center", "<f8", (3,)), ("mse", "<f8"), ("N", "<i4"), ("_pad", "<i4")])   # msl_peac_plane
 FRAME_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3", "bf", "minX", "maxX", "minY", "maxY")])
 MATCH_PARAMS_DTYPE = np.dtype([(n, "<f4") for n in ("fx", "fy", "cx", "cy", "bf", "minX", "maxX", "minY", "maxY", "th")] +
                               [("check_orientation", "<i4"), ("nlevels", "<i4"), ("scale_factors", "<f4", (16,))])
@@ -74,6 +75,8 @@ SIGNATURES = {
     "msl_peac_block_fit": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _i]),
     "msl_peac_membership_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     "msl_peac_membership_from_blocks": (_i, [_vp, _vp, _sz, _sz, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
+    "msl_peac_extract_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "msl_peac_extract_from_blocks": (_i, [_vp, _vp, _sz, _sz, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
     "msl_match_by_projection_batch": (_i, [_i, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),
     "msl_match_descriptor_distance": (_i, [_i, _vp, _vp, _i, _vp]),

@@ -506,8 +506,12 @@ struct Node {
 
 // One object per worker thread, reused for every frame that thread segments: all containers keep their capacity, so the steady state allocates
 // nothing (64 threads that each mmap / munmap a few hundred KB per frame serialise on the process's address-space lock).
+// Optional per-frame outputs beyond the membership image: what PlaneDetection hands on (extractedPlanes, plane_vertices_)
+struct PlaneSink { msl_peac_plane *planes; int32_t *offsets, *indices; int maxPlanes; bool overflow; };
+
 class alignas(128) FrameSegmenter {   // own cache lines: the vectors' end pointers inside the object change on every push
 public:
+    void set_sink(PlaneSink *s) { sink_ = s; }
     void configure(const msl_peac_params &prm, const uint16_t *halfDepth /* [ch][cw] raw depth of the cloud vertices */, int cw, int ch, float fx, float fy,
                    float cx, float cy, float factor) {
         T.p = prm; img_ = halfDepth; W = cw; H = ch; fx_ = fx; fy_ = fy; cx_ = cx; cy_ = cy; factor_ = factor;
@@ -552,6 +556,7 @@ public:
         member_ = member;
         std::fill(member, member + (size_t)W * H, -1);
         if (T.p.do_refine) refine();
+        emit_planes();
         return (int)planes_.size();
     }
 
@@ -575,6 +580,7 @@ public:
             auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
             fprintf(stderr, "[msl_peac] graph %ld us, cluster %ld us (%zu nodes), refine %ld us (queue %zu)\n", us(t0, t1), us(t1, t2), (size_t)nNodes_, us(t2, t3), growQ_.size());
         }
+        emit_planes();
         return (int)planes_.size();
     }
 
@@ -597,6 +603,18 @@ private:
     int nNodes_ = 0;
     std::vector<int> G_, u_, oldPlanes_, relabel_, edges_;
     bool recordEdges_ = false;
+    PlaneSink *sink_ = nullptr;
+    void emit_planes() {   // plane_filter.extractedPlanes as Frame::ExtractPlanes reads them (src/Frame.cc:626-632)
+        if (!sink_) return;
+        if ((int)planes_.size() > sink_->maxPlanes) { sink_->overflow = true; return; }
+        for (size_t j = 0; j < planes_.size(); j++) {
+            const Node &nd = nodes_[planes_[j]];
+            msl_peac_plane &o = sink_->planes[j];
+            for (int c = 0; c < 3; c++) { o.normal[c] = nd.normal[c]; o.center[c] = nd.center[c]; }
+            o.mse = nd.mse; o.N = nd.N; o._pad = 0;
+        }
+        if (sink_->offsets && !T.p.do_refine) for (size_t j = 0; j <= planes_.size(); j++) sink_->offsets[j] = 0;
+    }
     std::vector<char> validPlane_;
     std::vector<float> distMap_;
     int add_node(const Node &src) {
@@ -828,9 +846,23 @@ private:
             for (size_t j = 0; j < planes_.size(); ++j)
                 if (root == nodes_[planes_[j]].rid) { relabel[i] = (int)j; break; }
         }
+        const bool lists = sink_ && sink_->offsets && sink_->indices && (int)planes_.size() <= sink_->maxPlanes;
+        if (lists) {   // pMembership (:341-361): sizes first, so every plane's pixels land contiguously and in raster order
+            std::vector<int> &cur = u_;
+            cur.assign(planes_.size() + 1, 0);
+            for (size_t i = 0, nPx = (size_t)W * H; i < nPx; ++i) {
+                const int32_t plid = member_[i];
+                if (plid >= 0 && relabel[plid] >= 0) cur[relabel[plid] + 1]++;
+            }
+            for (size_t j = 0; j < planes_.size(); j++) cur[j + 1] += cur[j];
+            for (size_t j = 0; j <= planes_.size(); j++) sink_->offsets[j] = cur[j];
+        }
         for (size_t i = 0, nPx = (size_t)W * H; i < nPx; ++i) {
             int32_t &plid = member_[i];
-            if (plid >= 0 && relabel[plid] >= 0) plid = relabel[plid];   // anything else keeps its value (old id or visit counter), as in the reference
+            if (plid >= 0 && relabel[plid] >= 0) {   // anything else keeps its value (old id or visit counter), as in the reference
+                plid = relabel[plid];
+                if (lists) sink_->indices[u_[plid]++] = (int32_t)i;
+            }
         }
     }
 };
@@ -893,14 +925,16 @@ private:
 
 // graph initialisation + clustering + erosion + region growing of n_frames frames: blocks [frames][nBlocks], half [frames][ch][cw]
 void segment_frames(const msl_peac_params &prm, const msl_peac_block *blocks, size_t nBlocks, const uint16_t *half, int cw, int ch, int n_frames, float fx,
-                    float fy, float cx, float cy, float depth_map_factor, int32_t *membership_out, int32_t *n_planes_out) {
+                    float fy, float cx, float cy, float depth_map_factor, int32_t *membership_out, int32_t *n_planes_out, PlaneSink *sinks = nullptr) {
     const bool timing = getenv("MSL_PEAC_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<long> startUs(timing ? n_frames : 0), durUs(timing ? n_frames : 0);
     SegPool::get().run(n_frames, [&](int f, FrameSegmenter &seg) {
         const auto a = std::chrono::steady_clock::now();
         seg.configure(prm, half + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
+        seg.set_sink(sinks ? &sinks[f] : nullptr);
         const int n = seg.run(blocks + (size_t)f * nBlocks, membership_out + (size_t)f * cw * ch);
+        seg.set_sink(nullptr);
         if (n_planes_out) n_planes_out[f] = n;
         if (timing) {
             startUs[f] = (long)std::chrono::duration_cast<std::chrono::microseconds>(a - t0).count();
@@ -1064,10 +1098,39 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
     return MSL_OK;
 }
 
-int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
-                              msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
-                              int32_t *membership_out, int32_t *n_planes_out) {
-    if (!params || !membership_out || params->min_support < 1) { set_error("msl_peac_membership_batch: invalid argument"); return MSL_ERR_INVALID; }
+}  // extern "C"
+
+namespace {
+// per-frame sinks over the caller's arrays (nullptr when no plane output is wanted)
+std::vector<PlaneSink> make_sinks(int n_frames, int cw, int ch, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out) {
+    std::vector<PlaneSink> sinks;
+    if (!planes_out) return sinks;
+    sinks.resize(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        sinks[f].planes = planes_out + (size_t)f * max_planes;
+        sinks[f].offsets = vertex_offsets_out ? vertex_offsets_out + (size_t)f * (max_planes + 1) : nullptr;
+        sinks[f].indices = vertex_indices_out ? vertex_indices_out + (size_t)f * cw * ch : nullptr;
+        sinks[f].maxPlanes = max_planes; sinks[f].overflow = false;
+    }
+    return sinks;
+}
+int check_sinks(const std::vector<PlaneSink> &sinks, int max_planes) {
+    for (const PlaneSink &k : sinks)
+        if (k.overflow) { set_error("msl_peac: a frame has more than max_planes = %d planes", max_planes); return MSL_ERR_CAPACITY; }
+    return MSL_OK;
+}
+
+int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                    msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                    int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
+                    int32_t *vertex_indices_out) {
+    if (!params || !membership_out || params->min_support < 1 || (planes_out && max_planes < 1) || ((vertex_offsets_out || vertex_indices_out) && !planes_out) ||
+        ((vertex_offsets_out != nullptr) != (vertex_indices_out != nullptr)) || (vertex_indices_out && !params->do_refine)) {
+        set_error("msl_peac: invalid argument (plane outputs need max_planes >= 1; vertex lists need planes_out, both list arrays and do_refine)");
+        return MSL_ERR_INVALID;
+    }
+    std::vector<PlaneSink> sinks = make_sinks(n_frames, (width + 1) / 2, (height + 1) / 2, max_planes, planes_out, vertex_offsets_out, vertex_indices_out);
+    PlaneSink *sinkp = sinks.empty() ? nullptr : sinks.data();
     std::vector<msl_peac_block> hb;
     std::vector<uint16_t> half;       // raw depth of the cloud vertices, [frames][ch][cw]
     std::vector<int> hOutI;           // device clustering result: plane count per frame, disjoint-set parents and sizes
@@ -1148,12 +1211,14 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
         }
     }
     const auto tb1 = std::chrono::steady_clock::now();
-    if (!usedDevice) segment_frames(*params, hb.data(), nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
+    if (!usedDevice) segment_frames(*params, hb.data(), nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out, sinkp);
     else
         SegPool::get().run(n_frames, [&](int f, FrameSegmenter &seg) {
             seg.configure(*params, half.data() + (size_t)f * cw * ch, cw, ch, fx, fy, cx, cy, depth_map_factor);
+            seg.set_sink(sinkp ? &sinkp[f] : nullptr);
             const int n = seg.finish_from_device(hPlanes.data() + (size_t)f * maxPl, hOutI[f], hOutI.data() + n_frames + (size_t)f * nBlocks,
                                                  hOutI.data() + n_frames + (size_t)(n_frames + f) * nBlocks, membership_out + (size_t)f * cw * ch);
+            seg.set_sink(nullptr);
             if (n_planes_out) n_planes_out[f] = n;
         });
     if (timing) {
@@ -1162,15 +1227,35 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
         fprintf(stderr, "[msl_peac] batch of %d: device fit%s + copies %ld us, host stage %ld us\n", n_frames, usedDevice ? " + device clustering" : "", us(tb0, tb1),
                 us(tb1, tb2));
     }
-    return MSL_OK;
+    return check_sinks(sinks, max_planes);
+}
+}  // namespace
+
+extern "C" {
+
+int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                              msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                              int32_t *membership_out, int32_t *n_planes_out) {
+    return membership_impl(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, params,
+                           membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
+}
+int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
+                           msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                           int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
+                           int32_t *vertex_indices_out) {
+    if (!planes_out) { set_error("msl_peac_extract_batch: planes_out is NULL (use msl_peac_membership_batch for the image alone)"); return MSL_ERR_INVALID; }
+    return membership_impl(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, params,
+                           membership_out, n_planes_out, max_planes, planes_out, vertex_offsets_out, vertex_indices_out);
 }
 
-int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
-                                    int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
-                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
+int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
+                                 int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
+                                 int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
+                                 int32_t *vertex_indices_out) {
     if (!blocks || !depth || !params || !membership_out || params->min_support < 1 || params->window_w < 1 || params->window_h < 1 || width < 2 || height < 2 ||
-        n_frames < 0 || depth_stride_bytes < (size_t)width * 2) {
-        set_error("msl_peac_membership_from_blocks: invalid argument");
+        n_frames < 0 || depth_stride_bytes < (size_t)width * 2 || (planes_out && max_planes < 1) || ((vertex_offsets_out || vertex_indices_out) && !planes_out) ||
+        ((vertex_offsets_out != nullptr) != (vertex_indices_out != nullptr)) || (vertex_indices_out && !params->do_refine)) {
+        set_error("msl_peac_extract_from_blocks: invalid argument");
         return MSL_ERR_INVALID;
     }
     const int cw = (width + 1) / 2, ch = (height + 1) / 2;
@@ -1182,8 +1267,16 @@ int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t
             uint16_t *o = half.data() + ((size_t)f * ch + r) * cw;
             for (int c = 0; c < cw; c++) o[c] = row[2 * c];
         }
-    segment_frames(*params, blocks, nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out);
-    return MSL_OK;
+    std::vector<PlaneSink> sinks = make_sinks(n_frames, cw, ch, max_planes, planes_out, vertex_offsets_out, vertex_indices_out);
+    segment_frames(*params, blocks, nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out,
+                   sinks.empty() ? nullptr : sinks.data());
+    return check_sinks(sinks, max_planes);
+}
+int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
+                                    int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
+                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
+    return msl_peac_extract_from_blocks(blocks, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, fx, fy, cx, cy, depth_map_factor, params,
+                                        membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ ahc::PlaneFitter::initGraph (include/peac/AHCPlaneFitter.hpp:756-776, include/pe
 """
 import numpy as np
 
-from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, PEAC_PARAMS_DTYPE, PEAC_BLOCK_DTYPE, MSL_MEM_HOST, MSL_MEM_DEVICE
+from ._lib import lib, check, ptr, PEAC_STATS_DTYPE, PEAC_PARAMS_DTYPE, PEAC_BLOCK_DTYPE, PEAC_PLANE_DTYPE, MSL_MEM_HOST, MSL_MEM_DEVICE
 
 
 def block_stats(depth_u16, fx, fy, cx, cy, depth_map_factor, window=(10, 10), depth_alpha=0.04, depth_change_tol=0.02,
@@ -76,6 +76,42 @@ def plane_membership_from_blocks(blocks, depth_u16, fx, fy, cx, cy, depth_map_fa
     check(lib.msl_peac_membership_from_blocks(ptr(b), ptr(d), d.strides[1], d.strides[0], W, H, F, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(member),
                                               ptr(n)), "msl_peac_membership_from_blocks")
     return member, n
+
+
+def _split_planes(F, n, planes, offsets, indices):
+    out = []
+    for f in range(F):
+        k = int(n[f])
+        out.append((planes[f, :k].copy(), [indices[f, offsets[f, j]:offsets[f, j + 1]].copy() for j in range(k)]))
+    return out
+
+
+def extract(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, max_planes=64, device=0):
+    """Everything PlaneDetection hands on after runPlaneDetection: (membership [F, ch, cw], n_planes [F], per frame (planes PEAC_PLANE_DTYPE [n],
+    plane_vertices_: list of int32 vertex-index arrays))."""
+    d = _frames(depth_u16)
+    F, H, W = d.shape
+    prm = default_params() if params is None else params
+    ch, cw = (H + 1) // 2, (W + 1) // 2
+    member = np.zeros((F, ch, cw), np.int32); n = np.zeros(F, np.int32)
+    planes = np.zeros((F, max_planes), PEAC_PLANE_DTYPE); offsets = np.zeros((F, max_planes + 1), np.int32); indices = np.zeros((F, ch * cw), np.int32)
+    check(lib.msl_peac_extract_batch(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(member),
+                                     ptr(n), max_planes, ptr(planes), ptr(offsets), ptr(indices)), "msl_peac_extract_batch")
+    return member, n, _split_planes(F, n, planes, offsets, indices)
+
+
+def extract_from_blocks(blocks, depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, max_planes=64):
+    """extract() from block fits the caller already has: the host stage only, no device."""
+    d = _frames(depth_u16)
+    F, H, W = d.shape
+    prm = default_params() if params is None else params
+    b = np.ascontiguousarray(blocks, PEAC_BLOCK_DTYPE).reshape(F, -1)
+    ch, cw = (H + 1) // 2, (W + 1) // 2
+    member = np.zeros((F, ch, cw), np.int32); n = np.zeros(F, np.int32)
+    planes = np.zeros((F, max_planes), PEAC_PLANE_DTYPE); offsets = np.zeros((F, max_planes + 1), np.int32); indices = np.zeros((F, ch * cw), np.int32)
+    check(lib.msl_peac_extract_from_blocks(ptr(b), ptr(d), d.strides[1], d.strides[0], W, H, F, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(member), ptr(n),
+                                           max_planes, ptr(planes), ptr(offsets), ptr(indices)), "msl_peac_extract_from_blocks")
+    return member, n, _split_planes(F, n, planes, offsets, indices)
 
 
 def plane_membership_device(d_depth16, frame_step, n_frames, width, height, fx, fy, cx, cy, depth_map_factor, params, member_out, nplanes_out, device=0):

@@ -300,6 +300,7 @@ struct PlaneFitter {
     std::unique_ptr<DisjointSet> ds;
     std::vector<PlaneSeg::shared_ptr> extractedPlanes;
     std::vector<int> membershipImg;
+    std::vector<std::vector<int>> pMembership;   // run(points, pMembership, pSeg): vertex indices per plane (doRefine only)
     std::map<int, int> rid2plid;
     std::vector<int> blkMap;
     std::vector<std::pair<int, int>> rfQueue;
@@ -539,10 +540,12 @@ struct PlaneFitter {
             for (size_t j = 0; j < extractedPlanes.size(); ++j)
                 if (np_rid == extractedPlanes[j]->rid) { plidmap[i] = (int)j; break; }
         }
+        // pMembership (:341-361): the pixels of every final plane, in raster order -- what PlaneDetection keeps as plane_vertices_
+        pMembership.assign(extractedPlanes.size(), std::vector<int>());
         const int nPixels = width * height;
         for (int i = 0; i < nPixels; ++i) {
             int &plid = membershipImg[i];
-            if (plid >= 0 && plidmap[plid] >= 0) plid = plidmap[plid];   // every other value (incl. the negative visit counters) stays as it is
+            if (plid >= 0 && plidmap[plid] >= 0) { plid = plidmap[plid]; pMembership[plid].push_back(i); }   // every other value (incl. the negative visit counters) stays as it is
         }
     }
 
@@ -562,6 +565,8 @@ struct PlaneFitter {
 
 // Whole plane extractor for one depth image.  membershipOut: ceil(rows / 2) x ceil(cols / 2) ints = plane_filter.membershipImg after
 // runPlaneDetection(); *nPlanes = extractedPlanes.size(); blocksOut (may be NULL): the initial node of every block incl. its PCA.
+static thread_local std::vector<msl_peac_plane> g_lastPlanes;
+static thread_local std::vector<int32_t> g_lastOffsets, g_lastIndices;
 MSLO_API void mslo_peac_run(const uint16_t *depth, size_t strideBytes, int cols, int rows, float fx, float fy, float cx, float cy, float depthMapFactor,
                             const msl_peac_params *prm, int32_t *membershipOut, int32_t *nPlanes, msl_peac_block *blocksOut) {
     Cloud cloud;
@@ -581,6 +586,24 @@ MSLO_API void mslo_peac_run(const uint16_t *depth, size_t strideBytes, int cols,
     pf.run(&cloud, stats.data(), blocksOut);
     for (size_t i = 0; i < pf.membershipImg.size(); i++) membershipOut[i] = pf.membershipImg[i];
     *nPlanes = (int32_t)pf.extractedPlanes.size();
+    g_lastPlanes.clear(); g_lastOffsets.assign(1, 0); g_lastIndices.clear();
+    for (size_t j = 0; j < pf.extractedPlanes.size(); j++) {
+        const PlaneSeg &ps = *pf.extractedPlanes[j];
+        msl_peac_plane o;
+        for (int c = 0; c < 3; c++) { o.normal[c] = ps.normal[c]; o.center[c] = ps.center[c]; }
+        o.mse = ps.mse; o.N = ps.N; o._pad = 0;
+        g_lastPlanes.push_back(o);
+        if (j < pf.pMembership.size()) g_lastIndices.insert(g_lastIndices.end(), pf.pMembership[j].begin(), pf.pMembership[j].end());
+        g_lastOffsets.push_back((int32_t)g_lastIndices.size());
+    }
+}
+// What PlaneDetection exposes besides the membership image after the last mslo_peac_run of this thread: extractedPlanes (normal, centre, MSE, N:
+// src/Frame.cc:626-632) and plane_vertices_ (vertex indices per plane, concatenated; offsets has n_planes + 1 entries)
+MSLO_API int32_t mslo_peac_last_planes(msl_peac_plane *planes, int32_t *offsets, int32_t *indices) {
+    for (size_t j = 0; j < g_lastPlanes.size(); j++) planes[j] = g_lastPlanes[j];
+    for (size_t j = 0; j < g_lastOffsets.size(); j++) offsets[j] = g_lastOffsets[j];
+    for (size_t j = 0; j < g_lastIndices.size(); j++) indices[j] = g_lastIndices[j];
+    return (int32_t)g_lastPlanes.size();
 }
 
 // ahc::ParamSet / ahc::PlaneFitter defaults (include/peac/AHCParamSet.hpp:68-76, AHCPlaneFitter.hpp:157-161)

@@ -345,6 +345,19 @@ def peac_run(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None):
     return member, n.value, blocks
 
 
+PEAC_PLANE_DTYPE = np.dtype([("normal", "<f8", (3,)), ("center", "<f8", (3,)), ("mse", "<f8"), ("N", "<i4"), ("_pad", "<i4")])
+
+
+def peac_last_planes(n_vertices):
+    """extractedPlanes + plane_vertices_ of this thread's last peac_run: (planes PEAC_PLANE_DTYPE [n], list of int32 vertex-index arrays)."""
+    planes = np.zeros(1024, PEAC_PLANE_DTYPE); offsets = np.zeros(1025, np.int32); indices = np.zeros(n_vertices, np.int32)
+    f = load().dll.mslo_peac_last_planes
+    f.restype = C.c_int32
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    k = f(_p(planes), _p(offsets), _p(indices))
+    return planes[:k].copy(), [indices[offsets[j]:offsets[j + 1]].copy() for j in range(k)]
+
+
 def eig33sym(K):
     K = np.ascontiguousarray(K, np.float64)
     s = np.zeros(3); V = np.zeros((3, 3))

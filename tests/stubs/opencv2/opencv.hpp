@@ -6,16 +6,23 @@
 #define CV_8U 0
 #define CV_8UC1 0
 #define CV_32F 5
+#define CV_16U 2
+#define CV_8UC3 16
+#define CV_32SC1 4
 namespace cv {
 struct MatStep { size_t v; operator size_t() const; };
 class Mat {
 public:
     Mat();
+    Mat(int rows, int cols, int type);
     int rows, cols;
     unsigned char *data;
     MatStep step;
     int type() const;
+    int depth() const;
     bool empty() const;
+    void release();
+    Mat clone() const;
     unsigned char *ptr(int row = 0);
     const unsigned char *ptr(int row = 0) const;
     template <typename T> T *ptr(int row = 0);
@@ -26,6 +33,8 @@ public:
     template <typename T> const T &at(int i) const;
 };
 struct Point2f { float x, y; };
+struct Vec3b { unsigned char v[3]; unsigned char &operator[](int i); const unsigned char &operator[](int i) const; };
+struct Vec3d { Vec3d(); Vec3d(double a, double b, double c); double v[3]; double &operator[](int i); const double &operator[](int i) const; };
 class KeyPoint {
 public:
     Point2f pt; float size, angle, response; int octave, class_id;

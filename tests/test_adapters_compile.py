@@ -12,7 +12,7 @@ ADAPTER = os.path.join(ROOT, "manhattanslam_amd", "adapter")
 INC = ["-I", os.path.join(ROOT, "tests", "stubs"), "-I", os.path.join(ROOT, "include"), "-I", ADAPTER]
 
 
-@pytest.mark.parametrize("tu", ["ORBextractor.cc", "SurfelFusion.cpp", "SurfelMapping.cpp"])
+@pytest.mark.parametrize("tu", ["ORBextractor.cc", "SurfelFusion.cpp", "SurfelMapping.cpp", "PlaneExtractor.cpp"])
 def test_adapter_translation_unit_compiles(tu):
     assert shutil.which("g++")
     r = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", *INC, os.path.join(ADAPTER, tu)],

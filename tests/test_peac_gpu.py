@@ -114,3 +114,31 @@ def test_device_and_host_clustering_agree(oracle, monkeypatch):
         for f in (1, 4):
             want, nw, _ = oracle_lib.peac_run(frames[f], I["fx"], I["fy"], I["cx"], I["cy"], fac, params=po)
             assert nd[f] == nw and np.array_equal(dev[f], want), (kw, f)
+
+
+def test_extract_planes_and_vertex_lists(oracle, monkeypatch):
+    """msl_peac_extract_batch = everything PlaneDetection hands on: membership image, extractedPlanes (normal, centre, MSE, N) and plane_vertices_,
+    with the clustering on the device and on the host workers."""
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = synth.ICL
+    fac = np.float32(1 / 5000.0)
+    frames = []
+    for k, dr, box in ((0, 0.0, False), (100, 0.001, True), (170, 0.0, True), (250, 0.003, False), (300, 0.02, False)):
+        d = _depth(k, I, dr)
+        if box:
+            d[150:330, 260:470] = 5000
+        frames.append(d)
+    ref = []
+    for d in frames:
+        want, nw, _ = oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac)
+        ref.append((want, nw, oracle_lib.peac_last_planes(want.size)))
+    for mode in ("device", "host"):
+        monkeypatch.setenv("MSL_PEAC_CLUSTER", mode)
+        got, n, planes = peac.extract(np.stack(frames), I["fx"], I["fy"], I["cx"], I["cy"], fac)
+        for f, (want, nw, (wp, wv)) in enumerate(ref):
+            gp, gv = planes[f]
+            assert n[f] == nw and np.array_equal(got[f], want), (mode, f)
+            assert gp.tobytes() == wp.tobytes(), (mode, f)
+            assert len(gv) == len(wv) and all(np.array_equal(a, b) for a, b in zip(gv, wv)), (mode, f)
+    assert sum(r[1] for r in ref) >= 5

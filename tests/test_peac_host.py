@@ -83,3 +83,47 @@ def test_invalid_arguments_are_rejected():
     with pytest.raises(MslError):
         peac.plane_membership_from_blocks(np.zeros((1, 768), peac.PEAC_BLOCK_DTYPE), np.zeros((480, 640), np.uint16), I["fx"], I["fy"], I["cx"], I["cy"],
                                           np.float32(1 / 5000.0), params=p)
+
+
+def test_planes_and_vertex_lists_match_oracle(oracle):
+    """msl_peac_extract_from_blocks: plane_filter.extractedPlanes (normal, centre, MSE, N) and plane_vertices_ as PlaneDetection hands them on."""
+    from manhattanslam_amd import peac, synth
+    from tests import oracle_lib
+    I = synth.ICL
+    fac = np.float32(1 / 5000.0)
+    frames = _scenes(I)
+    total = 0
+    for kw in (dict(), dict(min_support=500, erode_type=0), dict(erode_type=1)):
+        p = peac.default_params(); po = oracle_lib.peac_default_params()
+        for k, v in kw.items():
+            p[k] = v; po[k] = v
+        ref = []
+        for d in frames:
+            want, nw, blocks = oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=po)
+            ref.append((want, nw, blocks, oracle_lib.peac_last_planes(want.size)))
+        got, n, planes = peac.extract_from_blocks(np.stack([r[2] for r in ref]), np.stack(frames), I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p, max_planes=64)
+        for f, (want, nw, _, (wp, wv)) in enumerate(ref):
+            gp, gv = planes[f]
+            assert n[f] == nw and np.array_equal(got[f], want), (kw, f)
+            assert gp.tobytes() == wp.tobytes(), (kw, f)
+            assert len(gv) == len(wv) and all(np.array_equal(a, b) for a, b in zip(gv, wv)), (kw, f)
+            # plane_vertices_ are the pixels that carry the plane's final id, minus stale ids of eroded planes: never more than the image shows
+            for j, v in enumerate(gv):
+                assert (got[f].ravel()[v] == j).all() and len(v) <= int((got[f] == j).sum())
+                total += len(v)
+    assert total > 100000
+
+
+def test_plane_capacity_and_argument_errors(oracle):
+    from manhattanslam_amd import peac, synth, MslError
+    from tests import oracle_lib
+    I = synth.ICL
+    fac = np.float32(1 / 5000.0)
+    d = _scenes(I)[2]
+    want, nw, blocks = oracle_lib.peac_run(d, I["fx"], I["fy"], I["cx"], I["cy"], fac)
+    assert nw >= 2
+    with pytest.raises(MslError):
+        peac.extract_from_blocks(blocks[None], d, I["fx"], I["fy"], I["cx"], I["cy"], fac, max_planes=1)
+    p = peac.default_params(); p["do_refine"] = 0
+    with pytest.raises(MslError):   # the vertex lists are refineDetails' pMembership
+        peac.extract_from_blocks(blocks[None], d, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
