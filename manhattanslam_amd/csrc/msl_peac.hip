@@ -282,6 +282,21 @@ __device__ __forceinline__ void st_ag(unsigned *p, unsigned v) { __hip_atomic_st
 __device__ __forceinline__ double ld_agd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agd(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Minimum of a double over the 64 lanes (DPP row shifts and row broadcasts, as msl::wave_incl_scan; lanes without a source see +inf); every lane gets it.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_min_step(double v) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWMASK, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)0x7FF00000, (int)(unsigned)(u >> 32), CTRL, ROWMASK, 0xF, false);
+    return fmin(v, __longlong_as_double(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+    v = dpp_min_step<0x111, 0xF>(v); v = dpp_min_step<0x112, 0xF>(v); v = dpp_min_step<0x114, 0xF>(v); v = dpp_min_step<0x118, 0xF>(v);
+    v = dpp_min_step<0x142, 0xA>(v);   // row_bcast:15 -> rows 1, 3
+    v = dpp_min_step<0x143, 0xC>(v);   // row_bcast:31 -> rows 2, 3
+    return __shfl(v, 63, 64);
+}
+
 __global__ __launch_bounds__(64) void k_peac_cluster(ClusterDev C) {
     extern __shared__ double s_mem[];
     const int f = blockIdx.x, lane = threadIdx.x, nB = C.nB, maxN = C.maxN, words = C.words;
@@ -415,10 +430,18 @@ __global__ __launch_bounds__(64) void k_peac_cluster(ClusterDev C) {
             const unsigned long long pm = __ballot(pass);
             const int lim = min(64, nc - c0);
             int jBest = -1;
-            for (int j = 0; j < lim; j++) {
-                if (!((pm >> j) & 1ull)) continue;
-                const double m = __shfl(mMse, j, 64);
-                if (!have || bMse > m || (bMse == m && (double)bN < m)) { have = true; bMse = m; bN = __shfl(mN, j, 64); jBest = j; }   // (sic: N against mse, :1005)
+            // The rule walks the candidates in order and keeps the first strict minimum.  Without NaNs and without ties that is the lane of the
+            // wave-wide minimum; anything else (never seen on real data) replays the walk literally.
+            const double minv = wave_min_d(pass ? mMse : __builtin_inf());
+            const unsigned long long eq = __ballot(pass && mMse == minv), nanm = __ballot(pass && mMse != mMse);
+            if (pm && !nanm && __popcll(eq) == 1 && !(have && (bMse == minv || bMse != bMse))) {
+                if (!have || bMse > minv) { jBest = __ffsll((long long)eq) - 1; have = true; bMse = minv; bN = __shfl(mN, jBest, 64); }
+            } else {
+                for (int j = 0; j < lim; j++) {
+                    if (!((pm >> j) & 1ull)) continue;
+                    const double m = __shfl(mMse, j, 64);
+                    if (!have || bMse > m || (bMse == m && (double)bN < m)) { have = true; bMse = m; bN = __shfl(mN, j, 64); jBest = j; }   // (sic: N against mse, :1005)
+                }
             }
             if (jBest >= 0) {   // the best so far lies in this chunk: fetch the rest of its fit
                 bNb = __shfl(nb, jBest, 64);
