@@ -56,7 +56,7 @@ for e in summary.values():
     e["pct"] = round(100.0 * e["total_ns"] / tot, 2)
 json.dump(dict(sorted(summary.items(), key=lambda kv: -kv[1]["total_ns"])), open(f"profiles/{tag}_summary.json", "w"), indent=1)
 with open(f"profiles/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary `{tag}` (bench.py --steps 4 --warmup 1 --cpu-frames 0 --no-breakdown)\n\n")
+    f.write(f"# rocprofv3 summary `{tag}` (bench.py --cpu-frames 0 --no-breakdown: the default 20 steps x 256 frames after 3 warm-up steps)\n\n")
     f.write("| kernel | calls | avg us | % GPU time | FETCH_SIZE KiB/launch (raw) | HBM read B/launch (x2 corrected) | WRITE_SIZE B/launch |\n|---|---|---|---|---|---|---|\n")
     for k, e in sorted(summary.items(), key=lambda kv: -kv[1]["total_ns"]):
         f.write(f"| {k} | {e['calls']} | {e['avg_us']} | {e['pct']} | {e.get('fetch_KiB_raw', '')} | {e.get('fetch_bytes_corrected', '')} | {e.get('write_bytes', '')} |\n")
