@@ -940,7 +940,8 @@ public:
     }
 
 private:
-    SegPool() : maxWorkers_(std::max(0, std::min(64, usable_cpus()) - 1)) {}
+    // MSL_PEAC_THREADS overrides the worker count (1 = everything on the calling thread)
+    SegPool() : maxWorkers_(std::max(0, std::min(64, getenv("MSL_PEAC_THREADS") ? atoi(getenv("MSL_PEAC_THREADS")) : usable_cpus()) - 1)) {}
     const int maxWorkers_;
     std::mutex callMutex_;
     std::vector<std::unique_ptr<FrameSegmenter>> ws_;

@@ -127,3 +127,32 @@ def test_plane_capacity_and_argument_errors(oracle):
     p = peac.default_params(); p["do_refine"] = 0
     with pytest.raises(MslError):   # the vertex lists are refineDetails' pMembership
         peac.extract_from_blocks(blocks[None], d, I["fx"], I["fy"], I["cx"], I["cy"], fac, params=p)
+
+
+def test_worker_count_does_not_change_the_result(oracle):
+    """MSL_PEAC_THREADS=1 (everything on the calling thread) and 5 workers give the images the default worker count gives."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, hashlib, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from manhattanslam_amd import peac, synth\n"
+        "from tests import oracle_lib\n"
+        "from tests.test_peac_host import _scenes\n"
+        "I = synth.ICL; fac = np.float32(1 / 5000.0)\n"
+        "frames = _scenes(I)\n"
+        "blocks = np.stack([oracle_lib.peac_run(d, I['fx'], I['fy'], I['cx'], I['cy'], fac)[2] for d in frames])\n"
+        "m, n = peac.plane_membership_from_blocks(blocks, np.stack(frames), I['fx'], I['fy'], I['cx'], I['cy'], fac)\n"
+        "print('digest', hashlib.sha256(m.tobytes() + n.tobytes()).hexdigest())\n" % root)
+    digests = set()
+    for threads in (None, "1", "5"):
+        env = dict(os.environ)
+        env.pop("MSL_PEAC_THREADS", None)
+        if threads:
+            env["MSL_PEAC_THREADS"] = threads
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout + r.stderr
+        digests.add(r.stdout.strip().split()[-1])
+    assert len(digests) == 1
