@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native RGB-D front end (ORB extractor + surfel fusion).
 
-    python bench.py --gpus N --steps K --warmup W [--config frontend|2|3|4|5]
+    python bench.py --gpus N --steps K --warmup W [--config frontend|2|3|4|5] [--io resident|host]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under
 torch.distributed.run (one rank per GPU, RCCL); the printed n_gpus always equals --gpus.
 
-One *step* = one batch of F synthetic RGB-D frames through the hot path on each GPU, inputs resident in HBM:
+One *step* = P passes over one stationary batch of F synthetic RGB-D frames through the hot path on each GPU, inputs resident in
+HBM.  A pass starts by putting the pre-seeded ~1 M-surfel map back (msl_sf_map_restore: a device-to-device copy INSIDE the timed
+region, ~0.2 % of a pass) and restarts the keyframe numbering, so every pass -- and therefore every step -- does identical work:
+N_live stays within ~1 % of --surfels and the surfels fused per keyframe stay constant whatever --steps is.  (The free-running
+synthetic sequence of rounds 1-2 grew by ~40 surfels per keyframe and `value` moved 10 % with the run length; --no-reseed still
+runs it.)
 
-  --config frontend (default, the BASELINE.json metric): ORB extraction of the F gray frames (one frame-batched launch
-        sequence) + surfel fusion of every frame (keyframe_every = 1, the most demanding cadence) into a device-resident
+  --config frontend (default, the BASELINE.json metric): ORB extraction of the F gray frames (frame-batched launch sequences of
+        --batch frames) + surfel fusion of every frame (keyframe_every = 1, the most demanding cadence) into a device-resident
         map of ~1 M live surfels, 640x480, TUM1 intrinsics.
   --config 2: ORBextractor only.                      --config 3: SurfelFusion only (~1 M live surfels).
   --config 4: ICL-NUIM intrinsics (fy = -480), ORB on every frame; on every k-th frame (--keyframe-every, default 4; the
@@ -19,10 +24,15 @@ One *step* = one batch of F synthetic RGB-D frames through the hot path on each 
         SurfelFusion with its membership image.
   --config 5: the frontend workload on 1280x960 frames (2x TUM1 intrinsics); meant for --gpus 8, one sequence per GPU.
 
+  --io host: the same passes with every frame coming from pinned HOST memory and every ORB result going back to pinned host memory
+        (keypoints, descriptors, counts), through the library's MSL_MEM_HOST paths; the line then carries `value_streaming` and the
+        PCIe rates next to the resident `value` (SURVEY.md 7 hard part 7: every ORB consumer in src/Frame.cc:103-153 is host code).
+
 Each rank owns an independent sequence (weak scaling); the only inter-GPU traffic is one RCCL all_gather of per-sequence
 counters after the timed loop.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -39,15 +49,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8
 SURFEL_BYTES = 56              # sizeof(Surfel), reference include/Surfel.h:28-37
 
 CONFIGS = {
-    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1,
+    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=12,
                      name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
-    "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 2: ORBextractor only"),
-    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, name="BASELINE config 3: SurfelFusion only"),
-    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_step=512,
+    "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, passes=48, name="BASELINE config 2: ORBextractor only"),
+    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=12, name="BASELINE config 3: SurfelFusion only"),
+    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_pass=512, passes=7,
               name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + PEAC plane extractor and SurfelFusion every k-th "
                    "frame (block fit and agglomerative clustering on the GPU, erosion / region growing on host threads; its membership "
                    "image feeds the fusion)"),
-    "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1,
+    "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1, passes=3,
               name="BASELINE config 5: ORB + SurfelFusion on every frame, 1280x960 sequences"),
 }
 
@@ -58,18 +68,22 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="frontend", choices=sorted(CONFIGS))
-    ap.add_argument("--size", default=None, help="WxH override (multiples of 8)")
+    ap.add_argument("--io", default="resident", choices=["resident", "host"], help="host: additionally time the passes with pinned host buffers in and out")
+    ap.add_argument("--size", default=None, help="WxH override")
     ap.add_argument("--keyframe-every", type=int, default=None, help="SurfelFusion on every k-th frame")
-    ap.add_argument("--frames-per-step", type=int, default=0, help="frames one step pushes through the hot path (each with its own input memory); "
-                    "0 = the configuration's default (256; config 4: 512, because the plane extractor clusters one keyframe per wave and is "
-                    "latency-bound per call, so its throughput grows with the keyframes handed over at once)")
-    ap.add_argument("--batch", type=int, default=32, help="frames per library call; a step issues frames-per-step / batch calls.  The scratch of "
+    ap.add_argument("--frames-per-pass", type=int, default=0, help="frames of one pass = the stationary batch (each frame with its own input memory); the map "
+                    "is put back at the start of every pass.  0 = the configuration's default (256; config 4: 512, because the plane extractor clusters "
+                    "one keyframe per wave and is latency-bound per call, so its throughput grows with the keyframes handed over at once)")
+    ap.add_argument("--passes-per-step", type=int, default=0, help="passes one step makes over the batch; 0 = the configuration's default, chosen so that "
+                    "the default 20 steps time about 3 s (frontend: 12 x 256 = 3072 frames per step)")
+    ap.add_argument("--no-reseed", action="store_true", help="free-running sequence of rounds 1-2: never put the map back (not stationary)")
+    ap.add_argument("--batch", type=int, default=32, help="frames per library call; a pass issues frames-per-pass / batch calls.  The scratch of "
                     "2 x batch keyframe slots plus the map should stay inside the 256 MB Infinity Cache: 128-frame batches measured 35 %% slower")
-    ap.add_argument("--distinct-frames", type=int, default=32, help="distinct synthetic frames generated per sequence (tiled to a step)")
+    ap.add_argument("--distinct-frames", type=int, default=64, help="distinct synthetic frames generated per sequence (SURVEY.md 8(d): 64), tiled to a pass")
     ap.add_argument("--surfels", type=int, default=1_000_000)
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the single-thread CPU-baseline sample (0 = no CPU baseline)")
     ap.add_argument("--no-breakdown", action="store_true")
-    ap.add_argument("--dry-run", action="store_true", help="launcher / aggregation check on CPU (gloo), no GPU work, fabricated timings")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / aggregation / device-binding check on CPU (gloo), no GPU work, fabricated timings")
     return ap.parse_args(argv)
 
 
@@ -90,35 +104,56 @@ def self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def sequence_seeds(rank):
+    """Seeds of rank r's independent sequence ('seeds offset by rank')."""
+    return {"frame": 7 + 1000 * rank, "orb": 20210530 + 1000 * rank, "map": 11 + rank}
+
+
 def build_inputs(rank, D, n_surfels, W, H, intr, variant, need_orb_texture=True, dropout=0.02):
     """D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host)."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
+    sd = sequence_seeds(rank)
     grays, depths, poses = [], [], []
     member = None
     for f in range(D):
-        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=7 + 1000 * rank, dropout=dropout)
+        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=sd["frame"], dropout=dropout)
         # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
-        grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f, W, H) if need_orb_texture else g)
+        grays.append(synth.orb_frame(sd["orb"] + f, W, H) if need_orb_texture else g)
         depths.append(depth)
         poses.append(pose)
-    smap = synth.surfel_map(n_surfels, ref=0, seed=11 + rank, min_update_times=5).astype(SURFEL_DTYPE)
+    smap = synth.surfel_map(n_surfels, ref=0, seed=sd["map"], min_update_times=5).astype(SURFEL_DTYPE)
     return np.stack(grays), np.stack(depths), member, poses, smap
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json."""
+def kernel_source_hash():
+    """Hash of the kernel sources: a committed PMC summary is quoted only for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "manhattanslam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel, config):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command on THESE kernel sources (separate
+    FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes for gfx950): profiles/<tag>_summary.json.
+    Returns (bytes, source) or (None, why)."""
     cur = os.path.join(ROOT, "profiles", "current.txt")   # tag of the profile that matches the committed kernels
     if not os.path.exists(cur):
-        return None
-    f = os.path.join(ROOT, "profiles", open(cur).read().strip() + "_summary.json")
+        return None, "no profiles/current.txt"
+    tag = open(cur).read().strip()
+    f = os.path.join(ROOT, "profiles", f"{tag}_summary.json" if config == "frontend" else f"{tag}_config{config}_summary.json")
     try:
-        e = json.load(open(f)).get(kernel)
+        doc = json.load(open(f))
     except Exception:  # noqa: BLE001
-        return None
+        return None, f"no committed PMC summary {os.path.basename(f)}"
+    if doc.get("_meta", {}).get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{os.path.basename(f)} was measured on other kernel sources (hash mismatch): not quoted"
+    e = doc.get(kernel)
     if e and "fetch_bytes_corrected" in e and "write_bytes" in e:
         return e["fetch_bytes_corrected"] + e["write_bytes"], os.path.basename(f)
-    return None
+    return None, f"{os.path.basename(f)} has no counters for {kernel}"
 
 
 def aggregate(local_ms, counters, world, device=None):
@@ -145,7 +180,7 @@ def cpu_baseline(args, cfg, W, H, kfe):
     if not cfg["sf"]:
         cmd.append("--no-surfel")
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
         res = json.loads(r.stdout.strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001
         return {"error": f"cpu baseline failed: {e!r}"}
@@ -158,23 +193,43 @@ def cpu_baseline(args, cfg, W, H, kfe):
     return out
 
 
-def dry_run(args, world, rank):
-    """Launcher / aggregation path without a GPU: gloo, fabricated per-rank timings and counters."""
+def geometry(args):
+    cfg = CONFIGS[args.config]
+    W, H = (int(v) for v in (args.size or cfg["size"]).lower().split("x"))
+    kfe = args.keyframe_every or cfg["kfe"]
+    F = args.frames_per_pass or cfg.get("frames_per_pass", 256)
+    P = args.passes_per_step or cfg["passes"]
+    B = min(args.batch, F)
+    D = min(args.distinct_frames, F)
+    if F % B or B % kfe or F % D:
+        raise SystemExit("--frames-per-pass must be a multiple of --batch and --distinct-frames, --batch a multiple of --keyframe-every")
+    return cfg, W, H, kfe, F, P, B, D
+
+
+def dry_run(args, world, rank, local_rank):
+    """Launcher / aggregation / binding path without a GPU: gloo, fabricated per-rank timings; every rank reports the device it
+    would bind (LOCAL_RANK -> hipSetDevice(local_rank) in both handles, independent of HIP_VISIBLE_DEVICES) and its sequence seeds."""
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("gloo")
         dist.barrier()
-    F = args.frames_per_step or CONFIGS[args.config].get("frames_per_step", 256)
+    cfg, W, H, kfe, F, P, B, D = geometry(args)
     local_ms = 10.0 + 5.0 * rank
-    counters = [args.steps * F, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
+    sd = sequence_seeds(rank)
+    counters = [args.steps * P * F, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
+    binding = [rank, local_rank, local_rank, sd["frame"], sd["orb"], sd["map"], int(os.environ.get("LOCAL_WORLD_SIZE", world)), 0]
     total_ms, gathered = aggregate(local_ms, counters, world, None)
+    _, bindings = aggregate(local_ms, binding, world, None)
     if rank == 0:
         frames = sum(g[0] for g in gathered)
-        print(json.dumps({"metric": "RGB-D frames/sec at 640x480 (ORB+surfel front end)", "value": round(frames / (total_ms * 1e-3), 1),
+        print(json.dumps({"metric": f"RGB-D frames/sec at {W}x{H} (ORB+surfel front end)", "value": round(frames / (total_ms * 1e-3), 1),
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(total_ms / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dry_run": True, "data": "none (fabricated timings: launcher / gloo aggregation check only)",
-                          "counters_per_rank": gathered}), flush=True)
+                          "dry_run": True, "data": "none (fabricated timings: launcher / gloo aggregation / binding check only)",
+                          "config": {"config": args.config, "frames_per_pass": F, "passes_per_step": P},
+                          "counters_per_rank": gathered,
+                          "binding_per_rank": [dict(zip(("rank", "local_rank", "device", "frame_seed", "orb_seed", "map_seed", "local_world_size"), b)) for b in bindings]}),
+              flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -190,7 +245,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line whose n_gpus differs from --gpus")
     if args.dry_run:
-        return dry_run(args, world, rank)
+        return dry_run(args, world, rank, local_rank)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -201,15 +256,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from manhattanslam_amd import ORBextractor, SurfelFusion, synth
-    cfg = CONFIGS[args.config]
-    W, H = (int(v) for v in (args.size or cfg["size"]).lower().split("x"))
-    kfe = args.keyframe_every or cfg["kfe"]
+    cfg, W, H, kfe, F, P, B, D = geometry(args)
     do_orb, do_sf = cfg["orb"], cfg["sf"]
-    F = args.frames_per_step or cfg.get("frames_per_step", 256)
-    B = min(args.batch, F)
-    D = min(args.distinct_frames, F)
-    if F % B or B % kfe or F % D:
-        raise SystemExit("--frames-per-step must be a multiple of --batch and --distinct-frames, --batch a multiple of --keyframe-every")
+    reseed = do_sf and not args.no_reseed
     nsub = F // B
     nkf = B // kfe if do_sf else 0   # keyframes per library call
     intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
@@ -229,6 +278,7 @@ def main():
         sf.set_batch_capacity(nkf)
         sf.map_reserve(2 * args.surfels + 65536)
         sf.map_upload(smap)
+        sf.map_snapshot()
         d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
         d_member = torch.from_numpy(member).to(dev)
         if use_peac:
@@ -236,9 +286,9 @@ def main():
             # raw 16-bit depth of the keyframes (5000 units per metre), resident in HBM like the other inputs
             d_depth16 = torch.from_numpy(np.stack([synth.depth_u16(d) for d in depths]).view(np.int16)).to(dev).repeat(F // D, 1, 1).contiguous()
             peac_prm = peac.default_params()
-            # The extractor of the NEXT step's keyframes runs on a host thread (block fit on the GPU, clustering on the library's worker
-            # threads) while this step's ORB / SurfelFusion calls are enqueued, the way the reference runs plane extraction in the tracking
-            # thread and surfel mapping in its own (src/Tracking.cc:228, src/SurfelMapping.cpp:46-60).  Every timed step still pays one full
+            # The extractor of the NEXT pass's keyframes runs on a host thread (block fit on the GPU, clustering on the library's worker
+            # threads) while this pass's ORB / SurfelFusion calls are enqueued, the way the reference runs plane extraction in the tracking
+            # thread and surfel mapping in its own (src/Tracking.cc:228, src/SurfelMapping.cpp:46-60).  Every timed pass still pays one full
             # extraction of its nkf * nsub keyframes: the one in flight at the end of the region is waited for inside it (sync_all).
             import concurrent.futures
             h_member = [np.zeros((nkf * nsub, H // 2, W // 2), np.int32) for _ in range(2)]
@@ -264,8 +314,8 @@ def main():
     def sub_sf(sb):
         if use_peac:
             if sb == 0:
-                # plane membership of this step's keyframes (one call: block fit on the GPU, clustering on one host thread per keyframe),
-                # computed while the previous step was enqueued; back to HBM, then start the next step's
+                # plane membership of this pass's keyframes (one call: block fit on the GPU, clustering on one host thread per keyframe),
+                # computed while the previous pass was enqueued; back to HBM, then start the next pass's
                 if peac_job[0] is None:
                     peac_submit()
                 peac_job[0].result()
@@ -280,20 +330,31 @@ def main():
                                member_shared=True, frame_step=kfe)
         kf_no[0] += nkf
 
-    def step_orb():
+    def begin_pass():
+        if reseed:           # the pre-seeded map again (device-to-device, asynchronous on the map stream), keyframe numbering from 0
+            sf.map_restore()
+            kf_no[0] = 0
+
+    def pass_orb():
         for sb in range(nsub):
             sub_orb(sb)
 
-    def step_sf():
+    def pass_sf():
+        begin_pass()
         for sb in range(nsub):
             sub_sf(sb)
 
-    def step():
+    def one_pass():
+        begin_pass()
         for sb in range(nsub):
             if do_orb:
                 sub_orb(sb)
             if do_sf:
                 sub_sf(sb)
+
+    def step():
+        for _ in range(P):
+            one_pass()
 
     def sync_all():
         if use_peac and peac_job[0] is not None:
@@ -307,7 +368,8 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    n_live_start = sf.counters()["n_live_after"] if do_sf else 0
+    n_live_start = int(len(smap)) if reseed else (sf.counters()["n_live_after"] if do_sf else 0)
+    tot0 = sf.debug_ctr() if do_sf else None
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize; only the roofline kernel carries HIP events ----
     sf_names = {v: k for k, v in enumerate(sf.kernel_names())} if do_sf else {}
@@ -335,8 +397,10 @@ def main():
         roof_ms, roof_launches = orb.profile_read()[roof_kernel]
         orb.profile_enable(0)
     ctr = sf.counters() if do_sf else dict(n_live_after=0, n_new=0, n_updated=0, n_deleted=0)
-    n_kp = int(d_n.sum().item()) if do_orb else 0
-    counters = [args.steps * F, n_kp, ctr["n_live_after"], ctr["n_new"], ctr["n_updated"], ctr["n_deleted"], int(local_ms * 1e6), n_live_start]
+    tot1 = sf.debug_ctr() if do_sf else None
+    n_kp_pass = int(d_n.sum().item()) if do_orb else 0
+    frames_rank = args.steps * P * F
+    counters = [frames_rank, n_kp_pass * args.steps * P, ctr["n_live_after"], ctr["n_new"], ctr["n_updated"], ctr["n_deleted"], int(local_ms * 1e6), n_live_start]
     total_ms, gathered = aggregate(local_ms, counters, world, dev)
 
     if rank != 0:
@@ -344,17 +408,29 @@ def main():
             dist.destroy_process_group()
         return
 
-    frames_total = args.steps * F * world
+    frames_total = frames_rank * world
     value = frames_total / (total_ms * 1e-3)
-    n_live_avg = 0.5 * (n_live_start + ctr["n_live_after"])
+    # per-keyframe averages over the timed region from the handle's running totals (new, deleted, updated, keyframes, live before)
+    if do_sf:
+        dk = max(int(tot1[11] - tot0[11]), 1)
+        avg_new, avg_del, avg_upd, n_live_avg = (float(tot1[i] - tot0[i]) / dk for i in (8, 9, 10, 12))
+    else:
+        dk, avg_new, avg_del, avg_upd, n_live_avg = 0, 0.0, 0.0, 0.0, 0.0
     sum_pl = sum(w * h for w, h in (orb.level_size(l) for l in range(8))) if do_orb else 0   # sum of the pyramid level areas
     launch_s = roof_ms * 1e-3 / max(roof_launches, 1)
     # algorithmic bytes per launch of the roofline kernel: k_fuse reads the live surfels (56 B each) once per
-    # keyframe; k_fast reads every pyramid level of the F frames of a step once
+    # keyframe; k_fast reads every pyramid level of the B frames of a call once
     alg_bytes = SURFEL_BYTES * n_live_avg if do_sf else float(sum_pl * B)
+    alg_write = SURFEL_BYTES * avg_upd if do_sf else 0.0
     achieved = alg_bytes / launch_s / 1e9 if roof_launches else 0.0
-    alg_frame = (2 * sum_pl if do_orb else 0) + ((SURFEL_BYTES * n_live_avg + 5 * W * H + W * H) / kfe if do_sf else 0)
-    traffic = pmc_traffic(roof_kernel) if args.config == "frontend" else None
+    achieved_rw = (alg_bytes + alg_write) / launch_s / 1e9 if roof_launches else 0.0
+    # R = 2 sum P_l per frame + (56 N_live + 5 W H + 4 (W/2)(H/2)) per keyframe; W = (sum_{l>=1} P_l + sum P_l + 60 N_kp)
+    # per frame + 56 (N_updated + N_new) per keyframe
+    n_kp_frame = n_kp_pass / F if do_orb else 0.0
+    r_frame = (2 * sum_pl if do_orb else 0) + ((SURFEL_BYTES * n_live_avg + 5 * W * H + W * H) / kfe if do_sf else 0)
+    w_frame = ((2 * sum_pl - W * H + 60 * n_kp_frame) if do_orb else 0) + (SURFEL_BYTES * (avg_upd + avg_new) / kfe if do_sf else 0)
+    traffic, traffic_src = pmc_traffic(roof_kernel, args.config)
+    fps_gpu = value / world
     out = {
         "metric": f"RGB-D frames/sec at {W}x{H} (ORB+surfel front end)" if do_orb and do_sf else
                   (f"frames/sec at {W}x{H} (ORBextractor only)" if do_orb else f"keyframes/sec at {W}x{H} (SurfelFusion only)"),
@@ -362,20 +438,29 @@ def main():
         "ms_per_step": round(total_ms / args.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "/".join((["u8/i32 (ORB)"] if do_orb else []) + (["f32+f64 (surfel)"] if do_sf else [])), "data": "synthetic",
         "config": {"workload": f"{cfg['name']} (keyframe_every={kfe}), {W}x{H}, one independent sequence per GPU",
-                   "config": args.config, "frames_per_step": F, "frames_per_call": B, "keyframes_per_step": nkf * nsub, "keyframe_every": kfe, "distinct_frames": D,
-                   "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg), "intrinsics": cfg["intr"],
-                   "membership": "PEAC plane extractor (msl_peac_membership_batch)" if use_peac else cfg["variant"], "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4)},
+                   "config": args.config, "frames_per_step": F * P, "frames_per_pass": F, "passes_per_step": P, "frames_per_call": B,
+                   "keyframes_per_pass": nkf * nsub, "keyframe_every": kfe, "distinct_frames": D,
+                   "stationary": bool(reseed) or not do_sf,
+                   "map_reseed": "msl_sf_map_restore (device-to-device, inside the timed region) at the start of every pass" if reseed else "none",
+                   "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg),
+                   "surfels_updated_per_keyframe": round(avg_upd, 1), "surfels_new_per_keyframe": round(avg_new, 2), "surfels_deleted_per_keyframe": round(avg_del, 2),
+                   "intrinsics": cfg["intr"], "membership": "PEAC plane extractor (msl_peac_membership_batch)" if use_peac else cfg["variant"],
+                   "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4), "timed_frames_per_gpu": frames_rank},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic[0] if traffic else None,
-                     "traffic_source": traffic[1] if traffic else "no committed PMC summary for this config",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
+                     "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic and roof_launches else None,
                      "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(launch_s * 1e6, 2),
+                     "read_write": {"algorithmic_bytes_per_launch": int(alg_bytes + alg_write), "achieved": round(achieved_rw, 1),
+                                    "frac": round(achieved_rw / HBM_PEAK_GBS, 4)},
                      "timer": f"HIP events carried by the {roof_kernel} dispatch (hipExtLaunchKernelGGL) on its own stream, timed region",
                      "launches": int(roof_launches)},
-        # whole-pipeline algorithmic HBM reads per frame (ORB 2 * sum P_l + surfel (56 N + 5 W H + 4 (W/2)(H/2)) per
-        # keyframe) times the per-GPU frame rate, against the same peak
-        "pipeline_roofline": {"algorithmic_read_bytes_per_frame": int(alg_frame),
-                              "achieved": round(alg_frame * value / world / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(alg_frame * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+        # whole-pipeline algorithmic HBM bytes per frame times the per-GPU frame rate, against the same peak
+        "pipeline_roofline": {"algorithmic_read_bytes_per_frame": int(r_frame), "algorithmic_write_bytes_per_frame": int(w_frame),
+                              "achieved": round(r_frame * fps_gpu / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(r_frame * fps_gpu / 1e9 / HBM_PEAK_GBS, 4),
+                              "read_write": {"achieved": round((r_frame + w_frame) * fps_gpu / 1e9, 1),
+                                             "frac": round((r_frame + w_frame) * fps_gpu / 1e9 / HBM_PEAK_GBS, 4)}},
         "counters_per_rank": gathered,
     }
 
@@ -385,46 +470,131 @@ def main():
             sf.profile_enable(-1)
         if do_orb:
             orb.profile_enable(-1)
-        step()
+        one_pass()
         sync_all()
-        nfr = F
         out["kernel_us_per_frame"] = {
-            **({k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in sf.profile_read().items() if c} if do_sf else {}),
-            **({"orb:" + k: round(ms * 1e3 / nfr, 2) for k, (ms, c) in orb.profile_read().items() if c} if do_orb else {})}
+            **({k: round(ms * 1e3 / F, 2) for k, (ms, c) in sf.profile_read().items() if c} if do_sf else {}),
+            **({"orb:" + k: round(ms * 1e3 / F, 2) for k, (ms, c) in orb.profile_read().items() if c} if do_orb else {})}
         if do_sf:
             sf.profile_enable(0)
         if do_orb:
             orb.profile_enable(0)
             t0 = time.perf_counter()
-            for _ in range(2):
-                step_orb()
+            for _ in range(4):
+                pass_orb()
             orb.sync()
-            out["orb_only_fps"] = round(2 * F / (time.perf_counter() - t0), 1)
+            out["orb_only_fps"] = round(4 * F / (time.perf_counter() - t0), 1)
         if do_sf:
             t0 = time.perf_counter()
-            step_sf()
+            for _ in range(2):
+                pass_sf()
             sf.sync()
-            out["surfel_only_keyframes_per_sec"] = round(nkf * nsub / (time.perf_counter() - t0), 1)
+            out["surfel_only_keyframes_per_sec"] = round(2 * nkf * nsub / (time.perf_counter() - t0), 1)
             # the same kernel without co-running work: the whole surfel pipeline on ONE stream (no overlap with the batched
             # superpixel stage or ORB), k_fuse timed again.  Reported next to, never instead of, the in-region roofline.
             sf.set_stream(torch.cuda.current_stream().cuda_stream)
+            begin_pass()
+            t_a = sf.debug_ctr()
             sf.profile_enable(1 << sf_names["k_fuse"])
             sub_sf(0)
             ms_iso, n_iso = sf.profile_read()["k_fuse"]
             sf.profile_enable(0)
-            n_now = sf.counters()["n_live_after"]
-            iso = SURFEL_BYTES * n_now / (ms_iso * 1e-3 / max(n_iso, 1)) / 1e9
+            t_b = sf.debug_ctr()
+            n_iso_live = float(t_b[12] - t_a[12]) / max(int(t_b[11] - t_a[11]), 1)
+            iso = SURFEL_BYTES * n_iso_live / (ms_iso * 1e-3 / max(n_iso, 1)) / 1e9
             out["roofline_isolated"] = {"kernel": "k_fuse", "achieved": round(iso, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(iso / HBM_PEAK_GBS, 4), "avg_launch_us": round(ms_iso * 1e3 / max(n_iso, 1), 2),
                                         "note": "single stream, no co-running kernels; HIP events carried by the dispatch"}
         if world == 1:
             out["dropin"] = dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf, local_rank)
 
+    if args.io == "host" and world == 1:
+        out["streaming"] = streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, local_rank, value)
+
     if args.cpu_frames > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, cfg, W, H, kfe)
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, device, resident_value):
+    """--io host: the same passes, but every call reads its frames from PINNED HOST memory (hipMemcpyAsync inside the library, on the
+    handles' own streams, double-buffered slot sets) and ORB writes keypoints / descriptors / counts back to pinned host memory, as the
+    reference's consumers need them (src/Frame.cc:103-153 are host code).  Two host threads feed the two handles so that their copies
+    and kernels overlap.  Reported next to `value`, never instead of it."""
+    import threading
+    import torch
+    from manhattanslam_amd import ORBextractor, SurfelFusion
+    from manhattanslam_amd._lib import KEYPOINT_DTYPE
+    do_orb, do_sf = cfg["orb"], cfg["sf"]
+    nsub = F // B
+    nkf = B // kfe if do_sf else 0
+    reps = F // D
+    # pinned host copies of the pass's frames (torch pinned memory = hipHostMalloc)
+    h_gray = torch.from_numpy(np.tile(grays, (reps, 1, 1))).pin_memory()
+    orb = sf = None
+    if do_orb:
+        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=device)
+        cap = orb.capacity
+        h_kps = torch.zeros(F * cap * 28, dtype=torch.uint8).pin_memory()
+        h_desc = torch.zeros(F * cap * 32, dtype=torch.uint8).pin_memory()
+        h_n = torch.zeros(F, dtype=torch.int32).pin_memory()
+    if do_sf:
+        sf = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=device)
+        sf.set_batch_capacity(nkf)
+        sf.map_reserve(2 * args.surfels + 65536)
+        sf.map_upload(smap)
+        sf.map_snapshot()
+        h_depth = torch.from_numpy(np.tile(depths, (reps, 1, 1))).pin_memory()
+        h_member = torch.from_numpy(member).pin_memory()
+        kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
+    g_np, = (h_gray.numpy(),)
+
+    def orb_pass():
+        for sb in range(nsub):
+            orb.extract_batch_host(g_np[sb * B:(sb + 1) * B], h_kps.numpy()[sb * B * cap * 28:], h_desc.numpy()[sb * B * cap * 32:], h_n.numpy()[sb * B:], B, W, H)
+
+    def sf_pass():
+        sf.map_restore()
+        d_np, m_np = h_depth.numpy(), h_member.numpy()
+        for sb in range(nsub):
+            sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], d_np[sb * B:], m_np, kf_poses[sb], device=False,
+                                   member_shared=True, frame_step=kfe)
+
+    def run(npass):
+        th = []
+        if do_orb:
+            th.append(threading.Thread(target=lambda: [orb_pass() for _ in range(npass)]))
+        if do_sf:
+            th.append(threading.Thread(target=lambda: [sf_pass() for _ in range(npass)]))
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if do_orb:
+            orb.sync()
+        if do_sf:
+            sf.sync()
+
+    run(2)
+    npass = max(2, min(P * args.steps, 24))
+    t0 = time.perf_counter()
+    run(npass)
+    dt = time.perf_counter() - t0
+    fps = npass * F / dt
+    n_kp = int(h_n.numpy().sum()) if do_orb else 0
+    h2d = (W * H * (1 if do_orb or do_sf else 0) * (2 if do_orb and do_sf else 1) + (4 * W * H + W * H) / kfe * (1 if do_sf else 0))   # bytes per frame
+    d2h = (60.0 * n_kp / F + 4) if do_orb else 0.0
+    res = {"value_streaming": round(fps, 1), "unit": "frames/s", "fraction_of_resident": round(fps / resident_value, 3), "passes": npass,
+           "h2d_bytes_per_frame": int(h2d), "d2h_bytes_per_frame": int(d2h), "h2d_gbs": round(h2d * fps / 1e9, 2), "d2h_gbs": round(d2h * fps / 1e9, 3),
+           "note": "pinned host buffers in (gray for ORB and again for SurfelFusion, f32 depth, membership) and out (keypoints, descriptors, counts); "
+                   "msl_orb_extract_batch / msl_sf_fuse_resident_batch with MSL_MEM_HOST, one feeding thread per handle"}
+    if do_orb:
+        orb.close()
+    if do_sf:
+        sf.close()
+    return res
 
 
 def dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf, device):

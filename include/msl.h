@@ -191,6 +191,12 @@ MSL_API int msl_sf_map_reserve(msl_sf *h, size_t capacity);
 MSL_API int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n);
 MSL_API int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out);
 MSL_API int msl_sf_map_size(msl_sf *h, size_t *n_out);
+/* Replay support (bench.py's stationary sequence, tests): msl_sf_map_snapshot keeps a device-side copy of the resident map and its
+ * live count (synchronous); msl_sf_map_restore puts that copy back, asynchronously on the map stream, ordered after every keyframe
+ * enqueued so far -- a device-to-device copy of the records, no host traffic.  (No reference counterpart: Tracking::Reset does not
+ * touch the surfel vectors, SURVEY.md App. D.) */
+MSL_API int msl_sf_map_snapshot(msl_sf *h);
+MSL_API int msl_sf_map_restore(msl_sf *h);
 
 /* fuseInitializeMap + the SurfelMapping::fuseMap slot refill / tail compaction
  * (src/SurfelMapping.cpp:353-392) on the resident map.  Image pointers may be host or device
@@ -366,7 +372,8 @@ MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
 MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
 /* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
- * 5: deferred error code; 8-15: spare, used by instrumented experiment builds for in-kernel time stamps). */
+ * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
+ * surfels before each keyframe; 13-15: spare). */
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "msl_sf_map_upload": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_download": (_i, [_vp, _vp, _sz, _vp]),
     "msl_sf_map_size": (_i, [_vp, _vp]),
+    "msl_sf_map_snapshot": (_i, [_vp]),
+    "msl_sf_map_restore": (_i, [_vp]),
     "msl_sf_map_detach": (_i, [_vp, _i, _vp, _sz, _vp]),
     "msl_sf_map_append": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_export": (_i, [_vp, _i, _vp, _sz, _vp]),

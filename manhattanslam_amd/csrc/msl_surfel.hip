@@ -101,6 +101,7 @@ struct SfDev {
     MapSoA map;
     unsigned long long cap;
     // ctr[0]=n_live  [1]=K new (last)  [2]=D deleted (last)  [3]=updated (last)  [4]=n before (last)  [5]=err  [6]=n after (last)  [7]=tail fallback flag
+    // ctr[8..12] = running totals: new, deleted, updated, keyframes, live-before
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
@@ -1421,6 +1422,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
     if (threadIdx.x == 0) {
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
+        // running totals over all keyframes of this handle (one writer per launch, launches are ordered): bench.py derives the
+        // per-keyframe averages of a timed region from their differences
+        P.ctr[8] += K; P.ctr[9] += D; P.ctr[10] += s_upd; P.ctr[11] += 1; P.ctr[12] += n;
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
     }
     if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }
@@ -1593,6 +1597,7 @@ struct msl_sf {
     unsigned long long kfEnq = 0; int snapNext = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
+    float *d_snapStore = nullptr; size_t snapCap = 0, snapN = 0; bool snapValid = false;   // msl_sf_map_snapshot / _restore
     KernelProfiler prof;
 };
 
@@ -1605,6 +1610,12 @@ void set_map_ptrs(msl_sf *h) {
     M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
+}
+
+// The asynchronous live-count snapshots only ever LOWER liveBound; whenever the map is replaced from outside the keyframe chain
+// (upload, restore) the ones still pending describe the old map and must be ignored.
+void drop_live_snapshots(msl_sf *h) {
+    for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;
 }
 
 int sync_all(msl_sf *h) {
@@ -1925,7 +1936,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos); F(h->d_snapStore);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_snap) (void)hipHostFree(h->h_snap);
     for (int i = 0; i < msl_sf::NSNAP; i++) if (h->snapEv[i]) (void)hipEventDestroy(h->snapEv[i]);
@@ -1999,6 +2010,52 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipStreamSynchronize(s));
     h->liveBound = n;
+    drop_live_snapshots(h);   // a count recorded before the upload would otherwise lower the bound below n
+    return MSL_OK;
+}
+
+int msl_sf_map_snapshot(msl_sf *h) {
+    if (!h) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = read_ctr(h);
+    if (rc != MSL_OK) return rc;
+    rc = check_err(h);
+    if (rc != MSL_OK) return rc;
+    const size_t n = (size_t)h->h_ctr[0];
+    if (n > h->snapCap) {
+        if (h->d_snapStore) (void)hipFree(h->d_snapStore);
+        h->d_snapStore = nullptr; h->snapCap = 0; h->snapValid = false;
+        const size_t c = (n + 4095) & ~(size_t)4095;
+        MSL_HIP_TRY(hipMalloc(&h->d_snapStore, sizeof(float) * 14 * c));
+        h->snapCap = c;
+    }
+    if (n) {
+        MSL_HIP_TRY(hipMemcpy(h->d_snapStore, h->dev.map.hot, sizeof(HotRec) * n, hipMemcpyDeviceToDevice));
+        MSL_HIP_TRY(hipMemcpy(h->d_snapStore + 5 * h->snapCap, h->dev.map.cold, sizeof(ColdRec) * n, hipMemcpyDeviceToDevice));
+    }
+    h->snapN = n; h->snapValid = true;
+    return MSL_OK;
+}
+
+int msl_sf_map_restore(msl_sf *h) {
+    if (!h || !h->snapValid) { set_error("msl_sf_map_restore: no snapshot"); return MSL_ERR_INVALID; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    const size_t n = h->snapN;
+    if (n + (size_t)h->dev.nseeds > h->mapCap) {   // the map was reallocated smaller than the snapshot (upload of a small map): grow again
+        int rc = read_ctr(h);
+        if (rc != MSL_OK) return rc;
+        rc = map_realloc(h, n + n / 4 + 4 * (size_t)h->dev.nseeds, 0);
+        if (rc != MSL_OK) return rc;
+    }
+    hipStream_t s = h->mapStream;   // ordered after every keyframe enqueued so far; the superpixel stream never touches the map
+    if (n) {
+        MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.hot, h->d_snapStore, sizeof(HotRec) * n, hipMemcpyDeviceToDevice, s));
+        MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.cold, h->d_snapStore + 5 * h->snapCap, sizeof(ColdRec) * n, hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
+    MSL_HIP_TRY(hipGetLastError());
+    h->liveBound = n;
+    drop_live_snapshots(h);
     return MSL_OK;
 }
 

@@ -119,6 +119,12 @@ class ORBextractor:
                                         MSL_MEM_DEVICE, ptr(d_kps), ptr(d_desc), self.capacity, ptr(d_n),
                                         MSL_MEM_DEVICE), "msl_orb_extract_batch")
 
+    def extract_batch_host(self, images, kps, desc, n_out, n_frames, width, height):
+        """Host buffers in and out (numpy views, ideally of pinned memory), no copies on the Python side; synchronous."""
+        check(lib.msl_orb_extract_batch(self._h, ptr(images), n_frames, width, height, width, width * height,
+                                        MSL_MEM_HOST, ptr(kps), ptr(desc), self.capacity, ptr(n_out),
+                                        MSL_MEM_HOST), "msl_orb_extract_batch")
+
     def sync(self):
         check(lib.msl_orb_sync(self._h), "msl_orb_sync")
 

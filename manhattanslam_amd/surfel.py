@@ -58,6 +58,13 @@ class SurfelFusion:
         surfels = np.ascontiguousarray(surfels, SURFEL_DTYPE)
         check(lib.msl_sf_map_upload(self._h, ptr(surfels) if len(surfels) else None, len(surfels)), "msl_sf_map_upload")
 
+    def map_snapshot(self):
+        """Device-side copy of the resident map (synchronous); map_restore() puts it back, asynchronously, device to device."""
+        check(lib.msl_sf_map_snapshot(self._h), "msl_sf_map_snapshot")
+
+    def map_restore(self):
+        check(lib.msl_sf_map_restore(self._h), "msl_sf_map_restore")
+
     def map_size(self):
         n = C.c_size_t(0)
         check(lib.msl_sf_map_size(self._h, C.byref(n)), "msl_sf_map_size")

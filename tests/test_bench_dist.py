@@ -63,7 +63,7 @@ def _run_bench(*argv, env=None):
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` with no rendezvous in the environment must start 2 ranks itself (torch.distributed.run) and
     report n_gpus = 2 with one counter record per rank; --dry-run swaps RCCL for gloo and skips the GPU work."""
-    rc, line, err = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--frames-per-step", "8")
+    rc, line, err = _run_bench("--gpus", "2", "--dry-run", "--steps", "2", "--frames-per-pass", "8", "--passes-per-step", "1")
     assert rc == 0, err[-2000:]
     assert line["n_gpus"] == 2 and line["dry_run"] is True
     assert len(line["counters_per_rank"]) == 2 and [c[1] for c in line["counters_per_rank"]] == [1000, 2000]
@@ -73,3 +73,21 @@ def test_bench_self_launches_its_ranks():
 def test_bench_refuses_gpus_world_mismatch():
     rc, line, err = _run_bench("--gpus", "2", "--dry-run", env={"WORLD_SIZE": "1", "RANK": "0"})
     assert rc != 0 and line is None and "refusing" in err
+
+
+def test_bench_eight_ranks_bind_distinct_devices_and_sequences():
+    """The 8-GPU shape of BASELINE config 5 without hardware: `bench.py --gpus 8 --config 5 --dry-run` starts 8 gloo ranks; every
+    rank reports the device it would bind (= its LOCAL_RANK, passed as `device` to both handles, which call hipSetDevice(device) at
+    every entry) and the seeds of its own sequence; one 8-record gather reaches rank 0."""
+    rc, line, err = _run_bench("--gpus", "8", "--config", "5", "--dry-run", "--steps", "2")
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and len(line["counters_per_rank"]) == 8
+    b = line["binding_per_rank"]
+    assert [x["rank"] for x in b] == list(range(8))
+    assert [x["device"] for x in b] == list(range(8)) and all(x["device"] == x["local_rank"] for x in b)
+    assert all(x["local_world_size"] == 8 for x in b)
+    for k in ("frame_seed", "orb_seed", "map_seed"):
+        assert len({x[k] for x in b}) == 8, k                      # independent sequences: seeds offset by rank
+    frames = sum(c[0] for c in line["counters_per_rank"])
+    assert frames == 8 * 2 * line["config"]["frames_per_pass"] * line["config"]["passes_per_step"]
+    assert line["value"] == round(frames / 0.045, 1)               # rank 7 is the slowest fabricated rank: 10 + 5 * 7 ms

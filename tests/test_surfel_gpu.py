@@ -467,3 +467,61 @@ def test_export_ply_matches_map_export(oracle, tmp_path):
     cam = lines[hdr + 1 + len(want)].split()
     assert len(cam) == 21 and int(cam[17]) == len(want) and len(lines) == hdr + 2 + len(want)
     g.close()
+
+
+def test_snapshot_restore_replays_identically(oracle):
+    """msl_sf_map_snapshot / msl_sf_map_restore (bench.py's stationary passes): after a restore the same keyframes give the same map,
+    and that map is the oracle's."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(30000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
+    g.map_upload(m)
+    g.map_snapshot()
+    o.map_set(m)
+    frames = [synth.surfel_frame(k) for k in range(3)]
+    g.set_batch_capacity(3)
+    args = (np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]), [f[3] for f in frames])
+    g.fuse_resident_batch([0, 1, 2], *args)
+    first = g.map_download()
+    for k, f in enumerate(frames):
+        o.fuse_map(k, f[0], f[1], f[2], f[3])
+    assert_surfels_close(first, o.map_get(), "first pass")
+    assert len(first) != len(m)
+    g.map_restore()                       # asynchronous: ordered behind the keyframes above on the map stream
+    assert g.map_size() == len(m)
+    assert g.map_download().tobytes() == m.tobytes()
+    g.map_restore()
+    g.fuse_resident_batch([0, 1, 2], *args)
+    assert g.map_download().tobytes() == first.tobytes()
+    # a snapshot larger than the current allocation (after an upload of a small map) is restored into a regrown map
+    g.map_upload(m[:10])
+    g.map_restore()
+    assert g.map_download().tobytes() == m.tobytes()
+    g.close()
+
+
+def test_upload_after_resident_batches_keeps_growing(oracle):
+    """a live-count snapshot recorded by an earlier resident batch must not lower the host-side bound below the size of a
+    map uploaded afterwards; otherwise the grow-before-overflow check is skipped and k_compact drops new surfels (deferred error 20)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    small = synth.surfel_map(2000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
+    g.map_upload(small)
+    gray, depth, member, pose = synth.surfel_frame(0)
+    g.set_batch_capacity(2)
+    g.fuse_resident_batch([0, 1], np.stack([gray, gray]), np.stack([depth, depth]), np.stack([member, member]), [pose, pose])   # leaves an async count snapshot behind
+    g.sync()
+    # a larger map whose size is just below the capacity upload() chooses; all of it far outside the fusion range, so it only grows
+    big = synth.surfel_map(60000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
+    big["px"] += 100.0; big["py"] += 100.0; big["pz"] += 100.0
+    g.map_upload(big)
+    o.map_set(big)
+    for k in range(4):
+        fr = [synth.surfel_frame(120 * k + 60 * j) for j in range(2)]
+        g.fuse_resident_batch([2 * k, 2 * k + 1], np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), np.stack([f[2] for f in fr]), [f[3] for f in fr])
+        for j, f in enumerate(fr):
+            o.fuse_map(2 * k + j, f[0], f[1], f[2], f[3])
+    mo = o.map_get()
+    assert len(mo) > 80000, len(mo)
+    assert_surfels_close(g.map_download(), mo, "map uploaded after resident batches, grown past the old capacity")
+    g.close()
