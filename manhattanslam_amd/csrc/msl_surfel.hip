@@ -46,26 +46,26 @@ constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-maintenance kernels (k_select_*)
-// Waves (= sub-blocks) per k_fuse workgroup.  Measured (1 M surfels, surfel-only): 4 -> k_fuse 20.8 us / k_compact 9.0 us in
-// region, 2 -> 16.7 / 9.9, 1 -> 16.3 / 11.8 (k_compact sums one blockUpd entry per workgroup); end-to-end the three are equal
-// (37.3-37.8 us per keyframe) because the superpixel chain then limits; with ORB running next to it (bench.py) 2 waves give
-// +3 % frames/s and k_fuse 19.8 instead of 26.4 us in region, hence the default.
-#ifndef MSL_FUSE_WAVES
-#define MSL_FUSE_WAVES 2
-#endif
-constexpr int FUSE_WAVES = MSL_FUSE_WAVES;
-constexpr int FUSE_NT = 64 * FUSE_WAVES;
-constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted-slot partials
+constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted / updated partials
 
 // Device-resident surfel map, split hot/cold: the fuse kernel streams only the 20-byte hot records (what decides a
 // surfel's fate for the ~90 % that leave early) and touches the 36-byte cold record of the few it updates; an update
 // writes two contiguous records (3-4 cache lines) instead of 14 scattered 4-byte fields.
 struct HotRec { float px, py, pz; int updateTimes, lastUpdate; };                       // 20 B
-struct ColdRec { float nx, ny, nz, size, color; int r, g, b; float weight; };           // 36 B
+// 32 bytes, 32-byte aligned: a fused surfel touches exactly one 32-byte sector of its cold record (the 36-byte record of round 2
+// straddled sectors and cache lines).  r, g, b always come from a cv::Vec3b (src/SurfelFusion.cpp:484, 551), so they travel as three
+// bytes; a record whose ints do not fit a byte (only possible for maps uploaded by the caller) sets COLD_WIDE and keeps the exact ints in
+// rgbWide[3 i ..] -- every accessor below honours it, so upload -> download stays the identity for arbitrary values.
+struct alignas(32) ColdRec { float nx, ny, nz, size, color, weight; unsigned rgbf; unsigned _spare; };
+constexpr unsigned COLD_WIDE = 1u << 24;
 struct MapSoA {
     HotRec *hot;
     ColdRec *cold;
+    int *rgbWide;          // [cap][3]
+    long long *wideFlag;   // ctr[13]: set once any COLD_WIDE record has been stored (the map copies then carry rgbWide along)
 };
+__host__ __device__ inline bool rgb_fits(int r, int g, int b) { return ((unsigned)r | (unsigned)g | (unsigned)b) < 256u; }
+__host__ __device__ inline unsigned rgb_pack(int r, int g, int b) { return (unsigned)r | ((unsigned)g << 8) | ((unsigned)b << 16); }
 
 // Per-keyframe parameters of one slot (device memory, uploaded per batch).
 // Image pointers travel through memory, so the compiler only knows them as generic pointers and would emit FLAT loads
@@ -89,7 +89,9 @@ struct SfDev {
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
     uint8_t *candOk;             // [slots][nseeds]
-    uint8_t *fused;              // [slots][nseeds] seed consumed by a fusion (written write-through, read at agent scope)
+    uint8_t *fused;              // [slots][nseeds] seed consumed by a fusion
+    uint2 *tex;                  // [slots][npx] {depth bits, final superpixel index} of every pixel: k_fuse's ONE gather per in-view surfel
+    float4 *fuseRec;             // [slots][nseeds][3] what k_fuse needs of a seed, per-seed terms of :236-277 evaluated once (FuseRec below)
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
     double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
@@ -709,6 +711,13 @@ __device__ __forceinline__ double group_sum_d(double v) {
     return v;
 }
 
+// FuseRec: the 48 bytes of a seed that fuseSurfelsKernel reads (three 16-byte loads instead of the 64-byte msl_seed), with the terms
+// that depend on the seed alone evaluated once per seed instead of once per fused surfel -- same expressions, same operands:
+//   [0] normX, normY, normZ (camera frame), meanDepth
+//   [1] pose * (posX, posY, posZ, 1) (:240-245), getWeight(meanDepth) (:236)
+//   [2] size * fabs(meanDepth / (cameraF * viewCos)) (:270-271), meanIntensity, r | g << 8 | b << 16, valid
+// valid = !(norm == 0) && !(viewCos < MAX_ANGLE_COS), the two seed tests of :214-219.
+//
 // LDS: one pool per wave.  The four seeds of a wave form a 2x2 block of the seed lattice, so their 16x16 windows cover
 // 24x24 = 576 distinct pixels; every pixel belongs to one seed, hence the four ordered lists hold <= 576 entries in total
 // (+ 3 x 3 for 16-byte alignment of each list) instead of 4 x 256.  14 KB per wave: 11 waves per CU instead of 5.
@@ -751,6 +760,18 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             dq[m] = load_quad(F.depthG() + (size_t)row * P.dstride + wcol0);
             ddq[m] = load_quad(F.depthG() + (size_t)min(row + 1, P.H - 1) * P.dstride + wcol0);
             dr3[m] = F.depthG()[(size_t)row * P.dstride + min(wcol0 + 4, P.W - 1)];
+        }
+        // Texel map for k_fuse: every pixel's {depth, final index} as one 8-byte word.  The seed's own 8x8 cell is rows / columns
+        // [4, 12) of its window (iterations 1, 2; column quads 1, 2), and the cells tile the image, so each pixel is written exactly
+        // once from values this lane holds anyway: two 16-byte stores per iteration for half of the lanes.
+        if (inRange && (cq == 1 || cq == 2)) {
+            uint2 *tex = P.tex + (size_t)slot * P.npx;
+#pragma unroll
+            for (int m = 1; m <= 2; m++) {
+                uint4 *t4 = reinterpret_cast<uint4 *>(tex + (size_t)(yb + 4 * m + rq) * P.W + cx0);
+                t4[0] = make_uint4(__float_as_uint(dq[m].v[0]), idq[m].v[0], __float_as_uint(dq[m].v[1]), idq[m].v[1]);
+                t4[1] = make_uint4(__float_as_uint(dq[m].v[2]), idq[m].v[2], __float_as_uint(dq[m].v[3]), idq[m].v[3]);
+            }
         }
         unsigned vm = 0;   // bit 4 m + e: pixel e of the quad in iteration m is a valid-depth pixel of the seed
 #pragma unroll
@@ -972,21 +993,35 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         S.meanDepth = meanDepth; S.viewCos = viewCos; S.size = sqrtf(maxDist);
         P.seeds[(size_t)slot * P.nseeds + seedI] = S;
     }
-    // candidate new surfel (:291-329, everything except the `fused` test, which needs the map stage)
-    const bool ok = !(S.meanDepth == 0) && !(S.viewCos < MAX_ANGLE_COS) && !(S.normX == 0 && S.normY == 0 && S.normZ == 0);
+    // what the map stage reads of this seed (FuseRec) and the candidate new surfel (:291-329, everything except the `fused` test,
+    // which needs the map stage); both use the same per-seed terms
+    const bool valid = !(S.viewCos < MAX_ANGLE_COS) && !(S.normX == 0 && S.normY == 0 && S.normZ == 0);
+    const bool ok = valid && !(S.meanDepth == 0);
     P.candOk[(size_t)slot * P.nseeds + seedI] = ok ? 1 : 0;
-    if (ok) {
-        float pw[4], nw[3];
+    float pw[4] = {0, 0, 0, 0};
+    float seedWeight = 0, seedSize = 0;
+    if (valid) {
         mul4(F.pose, S.posX, S.posY, S.posZ, 1.0f, pw);
+        const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
+        seedSize = S.size * fabsf(S.meanDepth / (cameraF * S.viewCos));
+        seedWeight = get_weight(S.meanDepth);
+    }
+    {
+        float4 *fr = P.fuseRec + ((size_t)slot * P.nseeds + seedI) * 3;
+        fr[0] = make_float4(S.normX, S.normY, S.normZ, S.meanDepth);
+        fr[1] = make_float4(pw[0], pw[1], pw[2], seedWeight);
+        fr[2] = make_float4(seedSize, S.meanIntensity, __uint_as_float(rgb_pack(S.r, S.g, S.b)), __uint_as_float(valid ? 1u : 0u));
+    }
+    if (ok) {
+        float nw[3];
         mul3(F.pose, S.normX, S.normY, S.normZ, nw);
         msl_surfel e;
         e.px = pw[0]; e.py = pw[1]; e.pz = pw[2];
         e.r = S.r; e.g = S.g; e.b = S.b;
         e.nx = nw[0]; e.ny = nw[1]; e.nz = nw[2];
-        const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
-        e.size = S.size * fabsf(S.meanDepth / (cameraF * S.viewCos));
+        e.size = seedSize;
         e.color = S.meanIntensity;
-        e.weight = get_weight(S.meanDepth);
+        e.weight = seedWeight;
         e.updateTimes = 1;
         e.lastUpdate = F.ref;
         P.cand[(size_t)slot * P.nseeds + seedI] = e;
@@ -1016,191 +1051,215 @@ __device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_fla
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// k_fuse (:167-283): workgroup b owns surfels [b*1024, (b+1)*1024) (loop over chunks).
-//   Phase A (streaming): each thread owns 4 CONSECUTIVE surfels, i.e. five 16-byte loads of the 20-byte hot records
-//   per lane.  The ~80 % that fail the cheap tests (stale, deleted, out of range, out of image) finish here.
-//   Survivors are compacted into an LDS list (slot by LDS atomic; per-surfel work is order independent).
-//   Phase B (gathers): one survivor per thread runs the rest of the reference's chain -- depth/index lookup, seed,
-//   cold record, weighted fusion -- so a wave pays each dependent memory round trip once instead of once per lane slot.
-// Also counts the deleted / updated surfels of each chunk so the compaction needs no extra pass over the map.
+// k_fuse (:167-283): ONE WAVE per sub-block of 256 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever a
+// SIMD has a free slot and registers -- next to the LDS-heavy frame-batched kernels the former 2 KB workgroups waited for LDS
+// (kb_seed_plane leaves 4 KB of a CU's 160 KB free) and k_fuse took 20 us in the timed region against 16 us alone.
+//   Phase A (streaming): a lane owns 4 CONSECUTIVE surfels = five 16-byte loads of the 20-byte hot records.  Stale / deleted / out of
+//     range / out of image surfels (~75 %) finish here; the in-view ones need ONE 8-byte gather each ({depth, superpixel index} texel
+//     written by kb_seed_plane) for the occlusion test.  The four gathers of a lane leave together (branch-free, clamped addresses).
+//   Hand-over inside the wave: survivor number s (rank by (k, lane)) goes to lane s % 64, round s / 64, with one ds_permute_b32 per k --
+//     a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining lanes, so every k is a
+//     permutation of the 64 lanes and no two lanes ever target the same destination.
+//   Phase B (gathers): rounds are processed in pairs; the hot record (just streamed: cache hit), the 32-byte cold record and the 48-byte
+//     FuseRec of both rounds' survivors are requested before the first use, so <= 128 survivors per sub-block cost one round trip.
+// Deleted slots are handed to k_compact in delU (one atomic per wave that deleted something -- a handful per keyframe); per-sub-block
+// deleted / updated counts go to blockSums / blockUpd with plain stores.
+// The sub-block -> wave mapping uses the HOST's upper bound of the live count (nSubGrid), so the first loads do not wait for ctr[0].
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m) {   // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
-__global__ __launch_bounds__(FUSE_NT) void k_fuse(SfDev P, int slot, FrameDev F) {   // F by value: kernarg -> SGPRs
-    // One small list per workgroup (4 entries per thread) keeps the kernel co-resident with the LDS-heavy batched kernels: survivors (local index |
-    // superpixel << 16) grow from the front, slots found deleted in phase A from the back; a survivor deleted in phase B
-    // is flagged in place (superpixel field 0xFFFF), so the two ends never meet (each surfel owns at most one entry).
-    // Each wave owns one sub-block of 256 consecutive surfels, and the FUSE_WAVES waves of a workgroup take theirs from
-    // different parts of the array (sub-block w * nW + b): the recently created surfels at the end of the array are
-    // nearly all in view, and this spreads them over many workgroups instead of giving a few four times the phase-B work.
-    __shared__ unsigned s_cnt[5], s_delSub[4];
-    constexpr int LISTN = 4 * FUSE_NT;
-    __shared__ unsigned s_surv[LISTN];
-    __shared__ unsigned s_delBase;
+__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int nSubGrid) {   // F by value: kernarg -> SGPRs
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
-    const long long n = P.ctr[0];
-    const long long nSub = (n + SUB_ITEMS - 1) / SUB_ITEMS, nW = (nSub + FUSE_WAVES - 1) / FUSE_WAVES;   // sub-blocks, workgroups with work
     const MapSoA &M = P.map;
-    const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
-    const unsigned short *index = P.index + (size_t)slot * P.npx;
+    const unsigned lane = threadIdx.x;
+    const long long sb = (long long)nSubGrid - 1 - (long long)blockIdx.x;   // the newest surfels (most phase-B work) are dispatched first
+    const long long c0 = sb * SUB_ITEMS, i0 = c0 + 4 * lane;
+    // map capacity is a multiple of 4096 and nSubGrid * 256 <= capacity: the 16-byte loads stay in bounds
+    uint4 q[5];
+    {
+        const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
+#pragma unroll
+        for (int j = 0; j < 5; j++) q[j] = hp[j];
+    }
+    const long long n = P.ctr[0];
+    const uint2 *tex = P.tex + (size_t)slot * P.npx;
+    const float4 *fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
-    const int wv = threadIdx.x >> 6;
-    for (long long bq = blockIdx.x; bq < nW; bq += gridDim.x) {
-        const long long b = nW - 1 - bq;   // the newest surfels (most phase-B work) are dispatched first
-        if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
-        if (threadIdx.x < FUSE_WAVES) s_delSub[threadIdx.x] = 0;
-        __syncthreads();
-        unsigned nupd = 0;
-        // local index (10 bits) = wave << 8 | offset in the wave's sub-block
-        auto sub_base = [&](unsigned w) -> long long { return ((long long)w * nW + b) * SUB_ITEMS; };
-        auto global_of = [&](unsigned local) -> long long { return sub_base(local >> 8) + (local & 0xFFu); };
-        const long long c0 = sub_base(wv);
-        auto mark_deleted = [&](long long i) {
-            s_surv[LISTN - 1 - atomicAdd(&s_cnt[0], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0);
-            atomicAdd(&s_delSub[wv], 1u);
-        };
-        const bool hasSub = (long long)wv * nW + b < nSub;   // the last workgroups may own fewer than four sub-blocks
-        // map capacity is a multiple of 4096: the 16-byte loads of an existing sub-block stay in bounds
-        const long long i0 = (hasSub ? c0 : 0) + 4 * (threadIdx.x & 63);
-        {
-            const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
-            uint4 q[5];
+    const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
+                            q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+    int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
+    float pzv[4];
+    unsigned offT[4];
 #pragma unroll
-            for (int j = 0; j < 5; j++) q[j] = hp[j];
-            const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
-                                    q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
-            // Branch-free up to the loads: the eight depth / superpixel lookups of the lane's (up to four) in-view surfels
-            // leave together (lanes without an in-view surfel read some valid pixel), so the lane pays ONE dependent round trip.
-            int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
-            float pzv[4], dep[4];
-            unsigned spi[4];   // 32-bit on purpose: packing two 16-bit results into one register would wait for each load
-            unsigned offD[4], offI[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const long long i = i0 + k;
-                const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
-                const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
-                float pc[4];
-                mul4(F.invPose, x, y, z, 1.0f, pc);
-                const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
-                const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
-                const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
-                const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
-                // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of
-                // the image either way
-                const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
-                const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
-                int st = 0;
-                if (hasSub && i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
-                state[k] = st; pzv[k] = pc[2];
-                const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
-                offD[k] = (unsigned)pVc * (unsigned)P.dstride + (unsigned)pUc;   // images are far below 2^32 elements
-                offI[k] = (unsigned)(pVc * P.W + pUc);
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) { dep[k] = F.depthG()[offD[k]]; spi[k] = index[offI[k]]; }
-            // a common use of all eight results: keeps the compiler from sinking each load into its (conditional) consumer,
-            // which would turn one round trip back into up to eight dependent ones
-            asm volatile("" ::"v"(dep[0]), "v"(dep[1]), "v"(dep[2]), "v"(dep[3]), "v"(spi[0]), "v"(spi[1]), "v"(spi[2]), "v"(spi[3]));
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const long long i = i0 + k;
-                if (state[k] == 0) continue;
-                if (state[k] == 1) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                if (state[k] == 2) { mark_deleted(i); continue; }
-                if ((double)pzv[k] < (double)dep[k] - 1.0) { M.hot[i].updateTimes = 0; mark_deleted(i); continue; }
-                s_surv[atomicAdd(&s_cnt[2], 1u)] = ((unsigned)wv << 8) | (unsigned)(i - c0) | (spi[k] << 16);
-            }
-        }
-        __syncthreads();
-        const unsigned nsurv = s_cnt[2];
-        unsigned ndelB = 0;
-        for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
-            const unsigned sv = s_surv[sidx];
-            const long long i = global_of(sv & 0xFFFFu);
-            const int spIndex = (int)(sv >> 16);
-            // seed, hot record (just streamed by this workgroup: cache hit) and cold record in ONE round trip; the cold
-            // record of a surfel that fails the seed tests below is read for nothing (36 B), which is cheaper than a
-            // fourth dependent round trip on this latency-bound chain
-            const msl_seed S = seeds[spIndex];
-            const HotRec hr = M.hot[i];
-            ColdRec C = M.cold[i];
-            // common use of one field per load instruction (see phase A): all three records are in flight together
-            asm volatile("" ::"v"(S.size), "v"(S.normY), "v"(S.posZ), "v"(S.b), "v"(hr.px), "v"(hr.lastUpdate), "v"(C.nx), "v"(C.color), "v"(C.weight));
-            const float pz = ((F.invPose[2] * hr.px + F.invPose[6] * hr.py) + F.invPose[10] * hr.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
-            if (S.normX == 0 && S.normY == 0 && S.normZ == 0) continue;
-            if (S.viewCos < MAX_ANGLE_COS) continue;
-            float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
-            tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
-            if (pz < S.meanDepth - tolerateDiff) continue;
-            if (pz > S.meanDepth + tolerateDiff) continue;
-            float nc[3];
-            mul3(F.invPose, C.nx, C.ny, C.nz, nc);
-            const float normDiffCos = nc[0] * S.normX + nc[1] * S.normY + nc[2] * S.normZ;
-            if (normDiffCos < MAX_ANGLE_COS) { M.hot[i].updateTimes = 0; s_surv[sidx] = sv | 0xFFFF0000u; atomicAdd(&s_delSub[(sv >> 8) & 3u], 1u); ndelB++; continue; }
-            const float Lpx = hr.px, Lpy = hr.py, Lpz = hr.pz;
-            const float oldWeight = C.weight;
-            const float newWeight = get_weight(S.meanDepth);
-            const float sumWeight = oldWeight + newWeight;
-            float spPW[4];
-            mul4(F.pose, S.posX, S.posY, S.posZ, 1.0f, spPW);
-            const float fusedPx = (Lpx * oldWeight + newWeight * spPW[0]) / sumWeight;
-            const float fusedPy = (Lpy * oldWeight + newWeight * spPW[1]) / sumWeight;
-            const float fusedPz = (Lpz * oldWeight + newWeight * spPW[2]) / sumWeight;
-            float fusedNx = nc[0] * oldWeight + newWeight * S.normX;
-            float fusedNy = nc[1] * oldWeight + newWeight * S.normY;
-            float fusedNz = nc[2] * oldWeight + newWeight * S.normZ;
-            const double newNormLength = (double)sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
-            fusedNx = (float)((double)fusedNx / newNormLength); fusedNy = (float)((double)fusedNy / newNormLength);
-            fusedNz = (float)((double)fusedNz / newNormLength);
-            float newNormW[3];
-            mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
-            HotRec Hn;
-            Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = hr.updateTimes + 1; Hn.lastUpdate = ref;
-            C.r = S.r; C.g = S.g; C.b = S.b;
-            C.nx = newNormW[0]; C.ny = newNormW[1]; C.nz = newNormW[2];
-            C.weight = sumWeight;
-            C.color = S.meanIntensity;
-            const float newSize = S.size * fabsf(S.meanDepth / (cameraF * S.viewCos));
-            if (newSize < C.size) C.size = newSize;
-            M.hot[i] = Hn;
-            M.cold[i] = C;
-            fused[spIndex] = 1;
-            nupd++;
-        }
-        if (nupd) atomicAdd(&s_cnt[1], nupd);
-        if (ndelB) atomicAdd(&s_cnt[3], ndelB);
-        __syncthreads();
-        const unsigned ndelA = s_cnt[0], ndelBlk = ndelA + s_cnt[3];
-        if (threadIdx.x < FUSE_WAVES && (long long)threadIdx.x * nW + b < nSub) P.blockSums[(long long)threadIdx.x * nW + b] = s_delSub[threadIdx.x];
-        if (threadIdx.x == 0) {
-            P.blockUpd[b] = s_cnt[1];
-            if (ndelBlk) s_delBase = atomicAdd(P.delUCount, ndelBlk);   // one global atomic per workgroup that deleted something
-        }
-        __syncthreads();
-        if (ndelBlk) {
-            const unsigned base = s_delBase;
-            for (unsigned j = threadIdx.x; j < ndelA; j += FUSE_NT)
-                if (base + j < LIST_D) P.delU[base + j] = (unsigned)global_of(s_surv[LISTN - 1 - j]);
-            if (ndelBlk != ndelA)
-                for (unsigned sidx = threadIdx.x; sidx < nsurv; sidx += FUSE_NT) {
-                    const unsigned sv = s_surv[sidx];
-                    if ((sv >> 16) != 0xFFFFu) continue;
-                    const unsigned j = base + ndelA + atomicAdd(&s_cnt[4], 1u);
-                    if (j < LIST_D) P.delU[j] = (unsigned)global_of(sv & 0xFFFFu);
-                }
-        }
-        __syncthreads();
+    for (int k = 0; k < 4; k++) {
+        const long long i = i0 + k;
+        const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
+        const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
+        float pc[4];
+        mul4(F.invPose, x, y, z, 1.0f, pc);
+        const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
+        const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+        const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+        const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
+        // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of the image either way
+        const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
+        const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+        int st = 0;
+        if (i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+        state[k] = st; pzv[k] = pc[2];
+        const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+        offT[k] = (unsigned)(pVc * P.W + pUc);
     }
+    uint2 tx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tx[k] = tex[offT[k]];
+    // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
+    // round trip back into up to four dependent ones
+    asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+    // ---- classification: deletions of phase A, survivors ----
+    bool del[4], surv[4];
+    unsigned long long mdel[4];
+    unsigned cntDel = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
+        if (state[k] == 1 || occluded) M.hot[i0 + k].updateTimes = 0;
+        del[k] = state[k] == 1 || state[k] == 2 || occluded;
+        surv[k] = state[k] == 3 && !occluded;
+        mdel[k] = __ballot(del[k]);
+        cntDel += (unsigned)__popcll(mdel[k]);
+    }
+    auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {   // append this lane's deleted slot to delU
+        if (d) { const unsigned j = base + lane_rank(m); if (j < LIST_D) P.delU[j] = (unsigned)i; }
+    };
+    if (cntDel) {   // rare: a handful of slots per keyframe
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(P.delUCount, cntDel);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, i0 + k); base += (unsigned)__popcll(mdel[k]); }
+    }
+    // ---- survivors -> (round, lane): one push per k ----
+    unsigned rcv[4], bk[4];
+    unsigned total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(surv[k]);
+        const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
+        const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
+        const unsigned payload = surv[k] ? ((4u * lane + (unsigned)k) | 0x100u | (tx[k].y << 16)) : 0u;   // local index, valid, superpixel
+        rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
+        bk[k] = total;
+        total += c;
+    }
+    const unsigned rounds = (total + 63u) >> 6;
+    unsigned nupd = 0, cntDelB = 0;
+    for (unsigned r = 0; r < rounds; r += 2) {
+        unsigned item[2] = {0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned rk = (bk[k] + ((lane - bk[k]) & 63u)) >> 6;   // round of the survivor this lane received from k (if any)
+            if ((rcv[k] & 0x100u) && rk == r) item[0] = rcv[k];
+            if ((rcv[k] & 0x100u) && rk == r + 1) item[1] = rcv[k];
+        }
+        HotRec hr[2]; ColdRec C[2]; float4 f0[2], f1[2], f2[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            // branch-free: a lane without a survivor in this round reads record c0 / seed 0 (valid addresses, one line for all such
+            // lanes) -- conditional loads made the compiler sink the first uses into the load block and wait there
+            const long long i = c0 + (item[t] & 0xFFu);
+            const unsigned sp = item[t] >> 16;
+            hr[t] = M.hot[i];
+            C[t] = M.cold[i];
+            f0[t] = fuseRec[3 * sp]; f1[t] = fuseRec[3 * sp + 1]; f2[t] = fuseRec[3 * sp + 2];
+        }
+        // common use of one field per load instruction: both rounds' records are in flight together
+        asm volatile("" ::"v"(hr[0].px), "v"(hr[0].lastUpdate), "v"(C[0].nx), "v"(C[0].color), "v"(f0[0].x), "v"(f1[0].x), "v"(f2[0].x),
+                     "v"(hr[1].px), "v"(hr[1].lastUpdate), "v"(C[1].nx), "v"(C[1].color), "v"(f0[1].x), "v"(f1[1].x), "v"(f2[1].x));
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            bool upd = false, delB = false;
+            const long long i = c0 + (item[t] & 0xFFu);
+            if (item[t] && __float_as_uint(f2[t].w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
+                const HotRec &h = hr[t];
+                ColdRec c = C[t];
+                const float seedDepth = f0[t].w;
+                const float pz = ((F.invPose[2] * h.px + F.invPose[6] * h.py) + F.invPose[10] * h.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
+                float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
+                tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
+                if (!(pz < seedDepth - tolerateDiff) && !(pz > seedDepth + tolerateDiff)) {
+                    float nc[3];
+                    mul3(F.invPose, c.nx, c.ny, c.nz, nc);
+                    const float normDiffCos = nc[0] * f0[t].x + nc[1] * f0[t].y + nc[2] * f0[t].z;
+                    if (normDiffCos < MAX_ANGLE_COS) {
+                        M.hot[i].updateTimes = 0;
+                        delB = true;
+                    } else {
+                        const float oldWeight = c.weight;
+                        const float newWeight = f1[t].w;                      // getWeight(seed.meanDepth)
+                        const float sumWeight = oldWeight + newWeight;
+                        const float fusedPx = (h.px * oldWeight + newWeight * f1[t].x) / sumWeight;   // f1.xyz = pose * seed.pos
+                        const float fusedPy = (h.py * oldWeight + newWeight * f1[t].y) / sumWeight;
+                        const float fusedPz = (h.pz * oldWeight + newWeight * f1[t].z) / sumWeight;
+                        float fusedNx = nc[0] * oldWeight + newWeight * f0[t].x;
+                        float fusedNy = nc[1] * oldWeight + newWeight * f0[t].y;
+                        float fusedNz = nc[2] * oldWeight + newWeight * f0[t].z;
+                        const double newNormLength = (double)sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
+                        fusedNx = (float)((double)fusedNx / newNormLength); fusedNy = (float)((double)fusedNy / newNormLength);
+                        fusedNz = (float)((double)fusedNz / newNormLength);
+                        float newNormW[3];
+                        mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
+                        HotRec Hn;
+                        Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = h.updateTimes + 1; Hn.lastUpdate = ref;
+                        c.rgbf = __float_as_uint(f2[t].z);                    // r, g, b of the seed (bytes: never COLD_WIDE)
+                        c.nx = newNormW[0]; c.ny = newNormW[1]; c.nz = newNormW[2];
+                        c.weight = sumWeight;
+                        c.color = f2[t].y;                                    // seed.meanIntensity
+                        const float newSize = f2[t].x;                        // seed.size * fabs(meanDepth / (cameraF * viewCos))
+                        if (newSize < c.size) c.size = newSize;
+                        M.hot[i] = Hn;
+                        M.cold[i] = c;
+                        fused[item[t] >> 16] = 1;
+                        upd = true;
+                    }
+                }
+            }
+            nupd += (unsigned)__popcll(__ballot(upd));
+            const unsigned long long mb = __ballot(delB);
+            if (mb) {   // rare
+                const unsigned cb = (unsigned)__popcll(mb);
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(P.delUCount, cb);
+                base = __builtin_amdgcn_readfirstlane(base);
+                hand_over(delB, mb, base, i);
+                cntDelB += cb;
+            }
+        }
+    }
+    if (lane == 0) { P.blockSums[sb] = cntDel + cntDelB; P.blockUpd[sb] = nupd; }
 }
 
 __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
     HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
-    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.r = e.r; c.g = e.g; c.b = e.b; c.weight = e.weight;
+    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.weight = e.weight; c._spare = 0;
+    if (rgb_fits(e.r, e.g, e.b)) c.rgbf = rgb_pack(e.r, e.g, e.b);
+    else { c.rgbf = COLD_WIDE; *M.wideFlag = 1; M.rgbWide[3 * i] = e.r; M.rgbWide[3 * i + 1] = e.g; M.rgbWide[3 * i + 2] = e.b; }
     M.hot[i] = h; M.cold[i] = c;
 }
+__device__ __forceinline__ void load_surfel(const MapSoA &M, long long i, const HotRec &h, msl_surfel &e) {
+    const ColdRec c = M.cold[i];
+    e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz; e.size = c.size; e.color = c.color;
+    if (c.rgbf & COLD_WIDE) { e.r = M.rgbWide[3 * i]; e.g = M.rgbWide[3 * i + 1]; e.b = M.rgbWide[3 * i + 2]; }
+    else { e.r = (int)(c.rgbf & 255u); e.g = (int)((c.rgbf >> 8) & 255u); e.b = (int)((c.rgbf >> 16) & 255u); }
+    e.weight = c.weight; e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
+}
 __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
-    M.hot[dst] = M.hot[src]; M.cold[dst] = M.cold[src];
+    const ColdRec c = M.cold[src];
+    M.hot[dst] = M.hot[src]; M.cold[dst] = c;
+    if (c.rgbf & COLD_WIDE) { M.rgbWide[3 * dst] = M.rgbWide[3 * src]; M.rgbWide[3 * dst + 1] = M.rgbWide[3 * src + 1]; M.rgbWide[3 * dst + 2] = M.rgbWide[3 * src + 2]; }
 }
 
 // Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
@@ -1294,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
     }
     const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
-    const long long nWg = (nblk + FUSE_WAVES - 1) / FUSE_WAVES;   // k_fuse workgroups (blockUpd entries)
+    const long long nWg = nblk;   // k_fuse waves (blockUpd entries): one per sub-block
     s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
@@ -1513,10 +1572,8 @@ __global__ __launch_bounds__(256) void k_select_write(SfDev P, int mode, int arg
             unsigned tot;
             const unsigned pos = base + block_excl_scan(sel ? 1u : 0u, s_wave, &tot);
             if (sel) {
-                const ColdRec c = P.map.cold[i];
                 msl_surfel e;
-                e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz; e.size = c.size; e.color = c.color;
-                e.r = c.r; e.g = c.g; e.b = c.b; e.weight = c.weight; e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
+                load_surfel(P.map, i, h, e);
                 out[pos] = e;
                 if (markDeleted) P.map.hot[i].updateTimes = 0;   // "Delete the surfel from the local point" (:224)
             }
@@ -1541,11 +1598,8 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const HotRec h = M.hot[i];
-    const ColdRec c = M.cold[i];
     msl_surfel e;
-    e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz;
-    e.size = c.size; e.color = c.color; e.r = c.r; e.g = c.g; e.b = c.b; e.weight = c.weight;
-    e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
+    load_surfel(M, i, h, e);
     dst[i] = e;
 }
 __global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
@@ -1575,7 +1629,7 @@ struct msl_sf {
     int lastSlot = 0;
     // per-slot device buffers
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
-    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr;
+    msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr; uint2 *d_tex = nullptr; float4 *d_fuseRec = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
     double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
     float *d_pxInv = nullptr;
@@ -1597,7 +1651,7 @@ struct msl_sf {
     unsigned long long kfEnq = 0; int snapNext = 0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
-    float *d_snapStore = nullptr; size_t snapCap = 0, snapN = 0; bool snapValid = false;   // msl_sf_map_snapshot / _restore
+    float *d_snapStore = nullptr; size_t snapCap = 0, snapN = 0; bool snapValid = false, snapWide = false;   // msl_sf_map_snapshot / _restore
     KernelProfiler prof;
 };
 
@@ -1607,7 +1661,9 @@ void set_map_ptrs(msl_sf *h) {
     const size_t c = h->mapCap;
     MapSoA &M = h->dev.map;
     M.hot = reinterpret_cast<HotRec *>(h->d_mapStore);                  // [cap] 20-byte records
-    M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 36-byte records
+    M.cold = reinterpret_cast<ColdRec *>(h->d_mapStore + 5 * c);        // [cap] 32-byte records (cap is a multiple of 4096: 32-byte aligned)
+    M.rgbWide = reinterpret_cast<int *>(h->d_mapStore + 13 * c);        // [cap][3] exact ints of the COLD_WIDE records (untouched otherwise)
+    M.wideFlag = h->d_ctr + 13;
     h->dev.cap = c;
     h->dev.blockSums = h->d_blockSums; h->dev.blockUpd = h->d_blockUpd; h->dev.delList = h->d_delList; h->dev.srcOf = h->d_srcOf;
 }
@@ -1629,7 +1685,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     auto attempt = [&]() -> int {
-        MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 14 * cap));
+        MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 16 * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
         MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
         MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
@@ -1641,6 +1697,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
             if (rc != MSL_OK) return rc;
             MSL_HIP_TRY(hipMemcpy(nstore, h->d_mapStore, sizeof(HotRec) * keep, hipMemcpyDeviceToDevice));
             MSL_HIP_TRY(hipMemcpy(nstore + 5 * cap, h->d_mapStore + 5 * h->mapCap, sizeof(ColdRec) * keep, hipMemcpyDeviceToDevice));
+            MSL_HIP_TRY(hipMemcpy(nstore + 13 * cap, h->d_mapStore + 13 * h->mapCap, sizeof(int) * 3 * keep, hipMemcpyDeviceToDevice));   // (rare path: no need to know whether any record is wide)
         }
         return MSL_OK;
     };
@@ -1663,7 +1720,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_index); F(h->d_amap); F(h->d_tmin);
+    F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_tex); F(h->d_fuseRec); F(h->d_index); F(h->d_amap); F(h->d_tmin);
     F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
     h->grayCap = h->depthCap = h->memberCap = 0;
@@ -1680,6 +1737,10 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_cand, sizeof(msl_surfel) * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_candOk, ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_fused, ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_tex, sizeof(uint2) * npx * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_fuseRec, sizeof(float4) * 3 * ns * slots));
+    MSL_HIP_TRY(hipMemset(h->d_tex, 0, sizeof(uint2) * npx * slots));
+    MSL_HIP_TRY(hipMemset(h->d_fuseRec, 0, sizeof(float4) * 3 * ns * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_index, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
@@ -1694,7 +1755,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMemset(h->d_index, 0, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMemset(h->d_fused, 0, ns * slots));
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
-    D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused;
+    D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused; D.tex = h->d_tex; D.fuseRec = h->d_fuseRec;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
     D.invDepth = h->d_invDepth; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
     h->maxBatch = maxBatch;
@@ -1821,6 +1882,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // shift every per-slot base so that blockIdx.y/z == 0 addresses slot0
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
+    P.tex = D.tex + (size_t)slot0 * D.npx; P.fuseRec = D.fuseRec + (size_t)slot0 * D.nseeds * 3;
     P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
     P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.npx; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
@@ -1852,12 +1914,11 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
-    // k_fuse's grid covers the host-side upper bound of the live count (the kernel loops if the map is larger): at 1 M surfels half
-    // of the former fixed 4096 workgroups had nothing to do
+    // k_fuse's grid covers the host-side upper bound of the live count, one wave per 256 surfels
     const size_t boundLive = compact ? h->liveBound : h->mapCap;
-    const unsigned fuseGrid = (unsigned)std::min<size_t>(65536, (boundLive / SUB_ITEMS + FUSE_WAVES) / FUSE_WAVES + 1);
+    const int nSubGrid = (int)std::max<size_t>(1, (boundLive + SUB_ITEMS - 1) / SUB_ITEMS);   // one wave per sub-block (boundLive <= capacity)
     for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3(fuseGrid), dim3(FUSE_NT), P, f, h->h_frames[slot0 + f]);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubGrid);
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
@@ -2001,6 +2062,7 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
         if (rc != MSL_OK) return rc;
     }
     hipStream_t s = h->mapStream;
+    MSL_HIP_TRY(hipMemsetAsync(h->d_ctr + 13, 0, sizeof(long long), s));   // a fresh map: no wide r, g, b records yet
     if (n) {
         rc = ensure_aos(h, n);
         if (rc != MSL_OK) return rc;
@@ -2026,14 +2088,15 @@ int msl_sf_map_snapshot(msl_sf *h) {
         if (h->d_snapStore) (void)hipFree(h->d_snapStore);
         h->d_snapStore = nullptr; h->snapCap = 0; h->snapValid = false;
         const size_t c = (n + 4095) & ~(size_t)4095;
-        MSL_HIP_TRY(hipMalloc(&h->d_snapStore, sizeof(float) * 14 * c));
+        MSL_HIP_TRY(hipMalloc(&h->d_snapStore, sizeof(float) * 16 * c));
         h->snapCap = c;
     }
     if (n) {
         MSL_HIP_TRY(hipMemcpy(h->d_snapStore, h->dev.map.hot, sizeof(HotRec) * n, hipMemcpyDeviceToDevice));
         MSL_HIP_TRY(hipMemcpy(h->d_snapStore + 5 * h->snapCap, h->dev.map.cold, sizeof(ColdRec) * n, hipMemcpyDeviceToDevice));
+        if (h->h_ctr[13]) MSL_HIP_TRY(hipMemcpy(h->d_snapStore + 13 * h->snapCap, h->dev.map.rgbWide, sizeof(int) * 3 * n, hipMemcpyDeviceToDevice));
     }
-    h->snapN = n; h->snapValid = true;
+    h->snapN = n; h->snapValid = true; h->snapWide = h->h_ctr[13] != 0;
     return MSL_OK;
 }
 
@@ -2051,6 +2114,9 @@ int msl_sf_map_restore(msl_sf *h) {
     if (n) {
         MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.hot, h->d_snapStore, sizeof(HotRec) * n, hipMemcpyDeviceToDevice, s));
         MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.cold, h->d_snapStore + 5 * h->snapCap, sizeof(ColdRec) * n, hipMemcpyDeviceToDevice, s));
+        if (h->snapWide) {
+            MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.rgbWide, h->d_snapStore + 13 * h->snapCap, sizeof(int) * 3 * n, hipMemcpyDeviceToDevice, s));
+        }
     }
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipGetLastError());

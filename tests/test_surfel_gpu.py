@@ -524,3 +524,33 @@ def test_upload_after_resident_batches_keeps_growing(oracle):
     assert len(mo) > 65536 + 2000, len(mo)      # past the 65 536-slot capacity the upload kept
     assert_surfels_close(g.map_download(), mo, "map uploaded after resident batches, grown past the old capacity")
     g.close()
+
+
+def test_wide_rgb_values_survive_the_byte_packed_cold_record(oracle):
+    """The resident map stores r, g, b as three bytes (they come from a cv::Vec3b, src/SurfelFusion.cpp:484, 551); an uploaded surfel
+    whose ints do not fit a byte keeps them exactly (side array), through upload / fuse / compaction moves / detach / append / snapshot."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(30000, ref=2, min_update_times=1).astype(SURFEL_DTYPE)
+    rng = np.random.default_rng(5)
+    wide = rng.choice(len(m), 3000, replace=False)
+    m["r"][wide] = rng.integers(-2**31, 2**31 - 1, len(wide)); m["g"][wide[::2]] = 256; m["b"][wide[::3]] = -1
+    g.map_upload(m)
+    assert g.map_download().tobytes() == m.tobytes()
+    g.map_snapshot()
+    o.map_set(m)
+    for k in (2, 9):      # keyframe 9 deletes stale surfels: tail moves carry wide records along
+        gray, depth, member, pose = synth.surfel_frame(k)
+        g.fuse_resident(k, gray, depth, member, pose)
+        o.fuse_map(k, gray, depth, member, pose)
+    mo = o.map_get()
+    mg = g.map_download()
+    assert_surfels_close(mg, mo, "map with wide r, g, b")
+    assert ((mo["r"] < 0) | (mo["r"] > 255)).sum() > 100
+    det = g.map_detach(9)
+    assert len(det) and np.array_equal(det["r"], mo["r"][(mo["lastUpdate"] == 9) & (mo["updateTimes"] > 0)])
+    g.map_append(m[wide[:50]])
+    assert np.array_equal(g.map_download()["r"][-50:], m["r"][wide[:50]])
+    g.map_restore()
+    assert g.map_download().tobytes() == m.tobytes()
+    g.close()
