@@ -373,8 +373,11 @@ MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
 MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
 /* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
  * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
- * surfels before each keyframe; 13-15: spare). */
+ * surfels before each keyframe; 13: some record keeps wide r, g, b; 14-15: spare). */
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
+/* The first n_words 32-bit words of the compaction's tail-move scratch array (host output, synchronous).  Instrumented experiment builds
+ * (-DMSL_FUSE_STAMPS, tools/fuse_stamps.py) park per-wave device-clock stamps of k_fuse there; otherwise the content is meaningless. */
+MSL_API int msl_sf_debug_scratch(msl_sf *h, uint32_t *out, size_t n_words);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);

@@ -1060,169 +1060,182 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 //   Hand-over inside the wave: survivor number s (rank by (k, lane)) goes to lane s % 64, round s / 64, with one ds_permute_b32 per k --
 //     a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining lanes, so every k is a
 //     permutation of the 64 lanes and no two lanes ever target the same destination.
-//   Phase B (gathers): rounds are processed in pairs; the hot record (just streamed: cache hit), the 32-byte cold record and the 48-byte
-//     FuseRec of both rounds' survivors are requested before the first use, so <= 128 survivors per sub-block cost one round trip.
+//   Phase B (gathers): per round one survivor per lane; its hot record (just streamed: cache hit), 32-byte cold record and 48-byte
+//     FuseRec are requested together, so <= 64 survivors per sub-block cost one round trip.
 // Deleted slots are handed to k_compact in delU (one atomic per wave that deleted something -- a handful per keyframe); per-sub-block
 // deleted / updated counts go to blockSums / blockUpd with plain stores.
 // The sub-block -> wave mapping uses the HOST's upper bound of the live count (nSubGrid), so the first loads do not wait for ctr[0].
+// int(projectU + 0.5) of :204-205 (a double addition, truncation towards zero) without double arithmetic: for u >= 1/2 it equals
+// floor(u) + (u - floor(u) >= 1/2) -- floor and the difference are exact in float --, and for smaller u (or NaN) both expressions are
+// <= 0, which the image test (pUInt < 1) rejects whatever the exact value is; the clamp keeps the conversion defined for huge / infinite u.
+__device__ __forceinline__ int round_half_up_pixel(float u) {
+    const float c = fminf(fmaxf(u, -4.0f), 1.0e6f);   // NaN -> -4
+    const float f = floorf(c);
+    return (int)f + ((c - f) >= 0.5f ? 1 : 0);
+}
 __device__ __forceinline__ unsigned lane_rank(unsigned long long m) {   // number of set bits of m below this lane
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int nSubGrid) {   // F by value: kernarg -> SGPRs
+__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int nSubHint) {   // F by value: kernarg -> SGPRs
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const MapSoA &M = P.map;
     const unsigned lane = threadIdx.x;
-    const long long sb = (long long)nSubGrid - 1 - (long long)blockIdx.x;   // the newest surfels (most phase-B work) are dispatched first
-    const long long c0 = sb * SUB_ITEMS, i0 = c0 + 4 * lane;
-    // map capacity is a multiple of 4096 and nSubGrid * 256 <= capacity: the 16-byte loads stay in bounds
-    uint4 q[5];
-    {
-        const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
-#pragma unroll
-        for (int j = 0; j < 5; j++) q[j] = hp[j];
-    }
-    const long long n = P.ctr[0];
     const uint2 *tex = P.tex + (size_t)slot * P.npx;
     const float4 *fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
-    const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
-                            q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
-    int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
-    float pzv[4];
-    unsigned offT[4];
+    const float halfF = 0.5f * cameraF;   // BASELINE * cameraF (:220), exact
+    const int G = (int)gridDim.x;
+    // Wave g owns sub-block G - 1 - g (the newest surfels -- nearly all in view: most phase-B work -- are dispatched first) and, should the
+    // map have outgrown the grid, G - 1 - g + G, ... (grid-stride; normally one iteration).  The grid covers the host's last KNOWN live count
+    // plus a margin, not its upper bound (which runs up to 1.5 x ahead between count snapshots).  Sub-blocks below nSubHint load at once; above
+    // it the wave reads the live count first and leaves if there is nothing for it.  Capacity is a multiple of 4096 and every sub-block that
+    // loads speculatively lies below it, so the 16-byte loads stay in bounds.
+    for (long long sb = (long long)G - 1 - (long long)blockIdx.x;; sb += G) {
+#ifdef MSL_FUSE_STAMPS   // instrumented experiment builds (tools/fuse_stamps.py): 100 MHz device-clock stamps of every wave in srcOf[]
+        const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        if (sb >= nSubHint && sb * SUB_ITEMS >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const long long c0 = sb * SUB_ITEMS, i0 = c0 + 4 * lane;
+        uint4 q[5];
+        {
+            const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const long long i = i0 + k;
-        const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
-        const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
-        float pc[4];
-        mul4(F.invPose, x, y, z, 1.0f, pc);
-        const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
-        const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
-        const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
-        const double du = (double)projectU + 0.5, dv = (double)projectV + 0.5;
-        // (int) of a double in [-1, 1e6] is exact truncation as in the reference; anything outside (or NaN) is out of the image either way
-        const int pUInt = (int)fmin(fmax(du, -1.0), 1.0e6), pVInt = (int)fmin(fmax(dv, -1.0), 1.0e6);
-        const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
-        int st = 0;
-        if (i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
-        state[k] = st; pzv[k] = pc[2];
-        const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
-        offT[k] = (unsigned)(pVc * P.W + pUc);
-    }
-    uint2 tx[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) tx[k] = tex[offT[k]];
-    // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
-    // round trip back into up to four dependent ones
-    asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
-    // ---- classification: deletions of phase A, survivors ----
-    bool del[4], surv[4];
-    unsigned long long mdel[4];
-    unsigned cntDel = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
-        if (state[k] == 1 || occluded) M.hot[i0 + k].updateTimes = 0;
-        del[k] = state[k] == 1 || state[k] == 2 || occluded;
-        surv[k] = state[k] == 3 && !occluded;
-        mdel[k] = __ballot(del[k]);
-        cntDel += (unsigned)__popcll(mdel[k]);
-    }
-    auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {   // append this lane's deleted slot to delU
-        if (d) { const unsigned j = base + lane_rank(m); if (j < LIST_D) P.delU[j] = (unsigned)i; }
-    };
-    if (cntDel) {   // rare: a handful of slots per keyframe
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(P.delUCount, cntDel);
-        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, i0 + k); base += (unsigned)__popcll(mdel[k]); }
-    }
-    // ---- survivors -> (round, lane): one push per k ----
-    unsigned rcv[4], bk[4];
-    unsigned total = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const unsigned long long m = __ballot(surv[k]);
-        const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
-        const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
-        const unsigned payload = surv[k] ? ((4u * lane + (unsigned)k) | 0x100u | (tx[k].y << 16)) : 0u;   // local index, valid, superpixel
-        rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
-        bk[k] = total;
-        total += c;
-    }
-    const unsigned rounds = (total + 63u) >> 6;
-    unsigned nupd = 0, cntDelB = 0;
-    for (unsigned r = 0; r < rounds; r += 2) {
-        unsigned item[2] = {0u, 0u};
+            for (int e = 0; e < 5; e++) q[e] = hp[e];
+        }
+        const long long n = P.ctr[0];
+        const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
+                                q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+        int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
+        float pzv[4];
+        unsigned offT[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned rk = (bk[k] + ((lane - bk[k]) & 63u)) >> 6;   // round of the survivor this lane received from k (if any)
-            if ((rcv[k] & 0x100u) && rk == r) item[0] = rcv[k];
-            if ((rcv[k] & 0x100u) && rk == r + 1) item[1] = rcv[k];
+            const long long i = i0 + k;
+            const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
+            const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
+            float pc[4];
+            mul4(F.invPose, x, y, z, 1.0f, pc);
+            const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
+            const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+            const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+            const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
+            const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+            int st = 0;
+            if (i < n) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+            state[k] = st; pzv[k] = pc[2];
+            const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+            offT[k] = (unsigned)(pVc * P.W + pUc);
         }
-        HotRec hr[2]; ColdRec C[2]; float4 f0[2], f1[2], f2[2];
+        uint2 tx[4];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            // branch-free: a lane without a survivor in this round reads record c0 / seed 0 (valid addresses, one line for all such
+        for (int k = 0; k < 4; k++) tx[k] = tex[offT[k]];
+        // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
+        // round trip back into up to four dependent ones
+        asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+#ifdef MSL_FUSE_STAMPS
+        const unsigned long long stamp1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        // ---- classification: deletions of phase A, survivors ----
+        bool del[4], surv[4];
+        unsigned long long mdel[4];
+        unsigned cntDel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
+            if (state[k] == 1 || occluded) M.hot[i0 + k].updateTimes = 0;
+            del[k] = state[k] == 1 || state[k] == 2 || occluded;
+            surv[k] = state[k] == 3 && !occluded;
+            mdel[k] = __ballot(del[k]);
+            cntDel += (unsigned)__popcll(mdel[k]);
+        }
+        auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {   // append this lane's deleted slot to delU
+            if (d) { const unsigned j = base + lane_rank(m); if (j < LIST_D) P.delU[j] = (unsigned)i; }
+        };
+        if (cntDel) {   // rare: a handful of slots per keyframe
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(P.delUCount, cntDel);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, i0 + k); base += (unsigned)__popcll(mdel[k]); }
+        }
+        // ---- survivors -> (round, lane): one push per k.  word = local index (4 lane + k), valid bit, superpixel << 16 ----
+        unsigned rcv[4], bk[4];
+        unsigned total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(surv[k]);
+            const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
+            const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
+            const unsigned payload = surv[k] ? ((4u * lane + (unsigned)k) | 0x100u | (tx[k].y << 16)) : 0u;
+            rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
+            bk[k] = total;
+            total += c;
+        }
+        const unsigned rounds = (total + 63u) >> 6;
+        unsigned nupd = 0, cntDelB = 0;
+        for (unsigned r = 0; r < rounds; r++) {   // one round for <= 64 survivors (a few per cent of the map are in view; the median sub-block has 14)
+            unsigned item = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned rk = (bk[k] + ((lane - bk[k]) & 63u)) >> 6;   // round of the survivor this lane received from k (if any)
+                if ((rcv[k] & 0x100u) && rk == r) item = rcv[k];
+            }
+            // branch-free loads: a lane without a survivor in this round reads record c0 / seed 0 (valid addresses, one line for all such
             // lanes) -- conditional loads made the compiler sink the first uses into the load block and wait there
-            const long long i = c0 + (item[t] & 0xFFu);
-            const unsigned sp = item[t] >> 16;
-            hr[t] = M.hot[i];
-            C[t] = M.cold[i];
-            f0[t] = fuseRec[3 * sp]; f1[t] = fuseRec[3 * sp + 1]; f2[t] = fuseRec[3 * sp + 2];
-        }
-        // common use of one field per load instruction: both rounds' records are in flight together
-        asm volatile("" ::"v"(hr[0].px), "v"(hr[0].lastUpdate), "v"(C[0].nx), "v"(C[0].color), "v"(f0[0].x), "v"(f1[0].x), "v"(f2[0].x),
-                     "v"(hr[1].px), "v"(hr[1].lastUpdate), "v"(C[1].nx), "v"(C[1].color), "v"(f0[1].x), "v"(f1[1].x), "v"(f2[1].x));
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
+            const long long i = c0 + (item & 0xFFu);
+            const unsigned sp = item >> 16;
+            const HotRec h = M.hot[i];
+            ColdRec c = M.cold[i];
+            const float4 f0 = fuseRec[3 * sp], f1 = fuseRec[3 * sp + 1], f2 = fuseRec[3 * sp + 2];
+            // common use of one field per load instruction: all records are in flight together
+            asm volatile("" ::"v"(h.px), "v"(h.lastUpdate), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x));
             bool upd = false, delB = false;
-            const long long i = c0 + (item[t] & 0xFFu);
-            if (item[t] && __float_as_uint(f2[t].w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
-                const HotRec &h = hr[t];
-                ColdRec c = C[t];
-                const float seedDepth = f0[t].w;
+            if (item && __float_as_uint(f2.w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
+                const float seedDepth = f0.w;
                 const float pz = ((F.invPose[2] * h.px + F.invPose[6] * h.py) + F.invPose[10] * h.pz) + F.invPose[14] * 1.0f;   // row 2 of mul4: as in phase A
-                float tolerateDiff = (float)((double)(pz * pz) / (BASELINE_D * (double)cameraF) * DISPARITY_ERROR);
+                // :220-221 is (float)((double)(pz pz) / (0.5 (double)cameraF) * 4.0).  Both operands of the division are float values (0.5 cameraF
+                // exactly), the multiplication by 4 is exact, and rounding a correctly rounded binary64 quotient of two binary32 numbers to
+                // binary32 gives the correctly rounded binary32 quotient (53 >= 2 * 24 + 2: double rounding is innocuous for division), so one
+                // IEEE float division yields the same bits as the double expression at a third of the instructions.
+                float tolerateDiff = (pz * pz) / halfF * 4.0f;
                 tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
                 if (!(pz < seedDepth - tolerateDiff) && !(pz > seedDepth + tolerateDiff)) {
                     float nc[3];
                     mul3(F.invPose, c.nx, c.ny, c.nz, nc);
-                    const float normDiffCos = nc[0] * f0[t].x + nc[1] * f0[t].y + nc[2] * f0[t].z;
+                    const float normDiffCos = nc[0] * f0.x + nc[1] * f0.y + nc[2] * f0.z;
                     if (normDiffCos < MAX_ANGLE_COS) {
                         M.hot[i].updateTimes = 0;
                         delB = true;
                     } else {
                         const float oldWeight = c.weight;
-                        const float newWeight = f1[t].w;                      // getWeight(seed.meanDepth)
+                        const float newWeight = f1.w;                      // getWeight(seed.meanDepth)
                         const float sumWeight = oldWeight + newWeight;
-                        const float fusedPx = (h.px * oldWeight + newWeight * f1[t].x) / sumWeight;   // f1.xyz = pose * seed.pos
-                        const float fusedPy = (h.py * oldWeight + newWeight * f1[t].y) / sumWeight;
-                        const float fusedPz = (h.pz * oldWeight + newWeight * f1[t].z) / sumWeight;
-                        float fusedNx = nc[0] * oldWeight + newWeight * f0[t].x;
-                        float fusedNy = nc[1] * oldWeight + newWeight * f0[t].y;
-                        float fusedNz = nc[2] * oldWeight + newWeight * f0[t].z;
-                        const double newNormLength = (double)sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
-                        fusedNx = (float)((double)fusedNx / newNormLength); fusedNy = (float)((double)fusedNy / newNormLength);
-                        fusedNz = (float)((double)fusedNz / newNormLength);
+                        const float fusedPx = (h.px * oldWeight + newWeight * f1.x) / sumWeight;   // f1.xyz = pose * seed.pos
+                        const float fusedPy = (h.py * oldWeight + newWeight * f1.y) / sumWeight;
+                        const float fusedPz = (h.pz * oldWeight + newWeight * f1.z) / sumWeight;
+                        float fusedNx = nc[0] * oldWeight + newWeight * f0.x;
+                        float fusedNy = nc[1] * oldWeight + newWeight * f0.y;
+                        float fusedNz = nc[2] * oldWeight + newWeight * f0.z;
+                        // :254-257: newNormLength is a double that holds a float (std::sqrt(float)); float /= double is a binary64 division
+                        // of two float values rounded to float = the IEEE float division (same argument as above)
+                        const float newNormLength = sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
+                        fusedNx = fusedNx / newNormLength; fusedNy = fusedNy / newNormLength; fusedNz = fusedNz / newNormLength;
                         float newNormW[3];
                         mul3(F.pose, fusedNx, fusedNy, fusedNz, newNormW);
                         HotRec Hn;
                         Hn.px = fusedPx; Hn.py = fusedPy; Hn.pz = fusedPz; Hn.updateTimes = h.updateTimes + 1; Hn.lastUpdate = ref;
-                        c.rgbf = __float_as_uint(f2[t].z);                    // r, g, b of the seed (bytes: never COLD_WIDE)
+                        c.rgbf = __float_as_uint(f2.z);                    // r, g, b of the seed (bytes: never COLD_WIDE)
                         c.nx = newNormW[0]; c.ny = newNormW[1]; c.nz = newNormW[2];
                         c.weight = sumWeight;
-                        c.color = f2[t].y;                                    // seed.meanIntensity
-                        const float newSize = f2[t].x;                        // seed.size * fabs(meanDepth / (cameraF * viewCos))
+                        c.color = f2.y;                                    // seed.meanIntensity
+                        const float newSize = f2.x;                        // seed.size * fabs(meanDepth / (cameraF * viewCos))
                         if (newSize < c.size) c.size = newSize;
                         M.hot[i] = Hn;
                         M.cold[i] = c;
-                        fused[item[t] >> 16] = 1;
+                        fused[sp] = 1;
                         upd = true;
                     }
                 }
@@ -1238,8 +1251,21 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
                 cntDelB += cb;
             }
         }
+        if (lane == 0) { P.blockSums[sb] = cntDel + cntDelB; P.blockUpd[sb] = nupd; }
+#ifdef MSL_FUSE_STAMPS
+        if (lane == 0 && ref == MSL_FUSE_STAMPS) {   // the keyframe with this number only: one in the middle of a batch, co-running kernels and all
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            const unsigned long long stamp2 = __builtin_amdgcn_s_memrealtime();
+            uint4 *o = reinterpret_cast<uint4 *>(P.srcOf) + 2 * sb;
+            o[0] = make_uint4((unsigned)stamp0, (unsigned)stamp1, (unsigned)stamp2, total);
+            o[1] = make_uint4(hwid, xcc, nupd, 0u);
+        }
+#endif
+        if ((sb + G) * SUB_ITEMS >= n) return;   // (normally) nothing beyond the grid
     }
-    if (lane == 0) { P.blockSums[sb] = cntDel + cntDelB; P.blockUpd[sb] = nupd; }
 }
 
 __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
@@ -1288,6 +1314,10 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     __shared__ unsigned s_nzIdx[SMALL_CHUNKS], s_nzCnt[SMALL_CHUNKS], s_nzSortIdx[SMALL_CHUNKS], s_nzSortCnt[SMALL_CHUNKS];   // sub-blocks with deletions
     __shared__ int s_fallback;
     __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
+#ifdef MSL_FUSE_STAMPS
+    unsigned long long cst[6];
+    cst[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
@@ -1357,6 +1387,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
+#ifdef MSL_FUSE_STAMPS
+    cst[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     // k_fuse already counted the deleted slots; when they all fit its hand-over list (the steady state) the per-sub-block
     // counts are not needed at all.  Otherwise one pass over them (4 consecutive per thread and tile) lists the sub-blocks
     // that contain deletions.
@@ -1377,6 +1410,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         }
     unsigned Dtot, Ku, exUnused, pos;
     block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
+#ifdef MSL_FUSE_STAMPS
+    cst[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     const long long D = fastest ? (long long)dHand : (long long)Dtot;
     // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
     const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
@@ -1479,6 +1515,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             if (candOk[i] && !fused[i]) emit_one(cand[i]);
     }
     __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
+#ifdef MSL_FUSE_STAMPS
+    cst[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) {
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
         // running totals over all keyframes of this handle (one writer per launch, launches are ordered): bench.py derives the
@@ -1519,6 +1558,13 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         }
     }
     if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
+#ifdef MSL_FUSE_STAMPS
+    if (threadIdx.x == 0 && (P.ctr[11] & 255) == MSL_FUSE_STAMPS + 1) {
+        cst[4] = __builtin_amdgcn_s_memrealtime();
+        for (int q = 0; q < 5; q++) P.delList[q] = (unsigned)cst[q];
+        P.delList[5] = (unsigned)K; P.delList[6] = (unsigned)D;
+    }
+#endif
 }
 
 // ---- map maintenance: ordered selection of surfels by a predicate -------------------------------
@@ -1643,6 +1689,7 @@ struct msl_sf {
     msl_surfel *d_new = nullptr;
     float *d_mapStore = nullptr; size_t mapCap = 0;
     size_t liveBound = 0;        // host-side upper bound of the live count: last known count + nseeds per keyframe enqueued since
+    size_t liveKnown = 0;        // the most recent live count the host has seen (exact at that time; only a hint for k_fuse's speculative loads)
     // asynchronous refresh of that bound: after every batch the live count is copied to pinned memory behind an event; a later call picks
     // up whatever has arrived, so the bound follows the real count a couple of batches late instead of forcing a pipeline drain
     // every capacity / nseeds keyframes
@@ -1771,6 +1818,7 @@ int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
     h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
+    h->liveKnown = h->liveBound;
     for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;   // (their events have fired: the stream is idle)
     return MSL_OK;
 }
@@ -1819,6 +1867,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
                 h->snapBusy[i] = false;
                 const size_t cand = (size_t)h->h_snap[i] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
                 if (cand < h->liveBound) h->liveBound = cand;
+                h->liveKnown = (size_t)h->h_snap[i];
             }
         if (h->liveBound + need > h->mapCap) {
             int rc = read_ctr(h);
@@ -1914,11 +1963,14 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
-    // k_fuse's grid covers the host-side upper bound of the live count, one wave per 256 surfels
     const size_t boundLive = compact ? h->liveBound : h->mapCap;
-    const int nSubGrid = (int)std::max<size_t>(1, (boundLive + SUB_ITEMS - 1) / SUB_ITEMS);   // one wave per sub-block (boundLive <= capacity)
+    // grid: the last known live count plus a margin (k_fuse is grid-stride, so a map that outgrew it is still covered), never beyond the upper
+    // bound; hint: the sub-blocks that were full at the last known count load without waiting for the live count
+    const size_t known = std::min(h->liveKnown, boundLive);
+    const int nSubGrid = (int)std::max<size_t>(1, (std::min(known + 8 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS);
+    const int nSubHint = (int)(known / SUB_ITEMS);
     for (int f = 0; f < n; f++) {
-        LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubGrid);
+        LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubHint);
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
@@ -2071,7 +2123,7 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     }
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipStreamSynchronize(s));
-    h->liveBound = n;
+    h->liveBound = n; h->liveKnown = n;
     drop_live_snapshots(h);   // a count recorded before the upload would otherwise lower the bound below n
     return MSL_OK;
 }
@@ -2120,7 +2172,7 @@ int msl_sf_map_restore(msl_sf *h) {
     }
     hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
     MSL_HIP_TRY(hipGetLastError());
-    h->liveBound = n;
+    h->liveBound = n; h->liveKnown = n;
     drop_live_snapshots(h);
     return MSL_OK;
 }
@@ -2240,7 +2292,7 @@ int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     hipLaunchKernelGGL(k_aos_to_soa_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev.map, h->d_aos, (long long)n, h->d_ctr);
     hipLaunchKernelGGL(k_add_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n);
     MSL_HIP_TRY(hipStreamSynchronize(s));
-    h->liveBound = cur + n;
+    h->liveBound = cur + n; h->liveKnown = cur + n;
     return MSL_OK;
 }
 
@@ -2316,6 +2368,15 @@ int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     for (int i = 0; i < 16; i++) out[i] = h->h_ctr[i];
+    return MSL_OK;
+}
+int msl_sf_debug_scratch(msl_sf *h, uint32_t *out, size_t n_words) {
+    if (!h || !out || n_words > h->mapCap || n_words < 16) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = sync_all(h);
+    if (rc != MSL_OK) return rc;
+    MSL_HIP_TRY(hipMemcpy(out, h->d_srcOf, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
+    MSL_HIP_TRY(hipMemcpy(out, h->d_delList, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost));   // words 0-7: k_compact's stamps (sub-block 0 has no k_fuse stamps then)
     return MSL_OK;
 }
 int msl_sf_debug_index(msl_sf *h, int32_t *out) {

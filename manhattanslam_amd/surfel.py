@@ -155,6 +155,11 @@ class SurfelFusion:
         check(lib.msl_sf_debug_ctr(self._h, ptr(out)))
         return out
 
+    def debug_scratch(self, n_words):
+        out = np.zeros(n_words, np.uint32)
+        check(lib.msl_sf_debug_scratch(self._h, ptr(out), n_words))
+        return out
+
     def debug_index(self):
         out = np.zeros((self.height, self.width), np.int32)
         check(lib.msl_sf_debug_index(self._h, ptr(out)))
