@@ -375,9 +375,10 @@ MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
  * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
  * surfels before each keyframe; 13: some record keeps wide r, g, b; 14-15: spare). */
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
-/* The first n_words 32-bit words of the compaction's tail-move scratch array (host output, synchronous).  Instrumented experiment builds
- * (-DMSL_FUSE_STAMPS, tools/fuse_stamps.py) park per-wave device-clock stamps of k_fuse there; otherwise the content is meaningless. */
-MSL_API int msl_sf_debug_scratch(msl_sf *h, uint32_t *out, size_t n_words);
+/* n_words 32-bit words from offset_words of one of the compaction's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list;
+ * host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
+ * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
+MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);

@@ -728,6 +728,13 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     int slot, blk;
     const int bW = (P.spW + 1) / 2, bH = (P.spH + 1) / 2;
     if (!xcd_slot(bW * bH, nSlots, slot, blk)) return;
+#ifdef MSL_FUSE_STAMPS   // section cycle counts of the waves of slot 0, summed into delList[64 ..] (tools/fuse_stamps.py)
+    unsigned long long sst[12]; int ssn = 0;
+#define SECTION_STAMP() sst[ssn++] = __builtin_amdgcn_s_memtime()
+#else
+#define SECTION_STAMP()
+#endif
+    SECTION_STAMP();
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15, lane = threadIdx.x;
     const int spX = (blk % bW) * 2 + (g & 1), spY = (blk / bW) * 2 + (g >> 1);
     const bool inRange = spX < P.spW && spY < P.spH;
@@ -814,6 +821,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             run += __shfl(incl, g15, 64);
         }
     }
+    SECTION_STAMP();   // 1: gather + ordered lists
     float *const pX = s_pool[0] + base, *const pY = s_pool[1] + base, *const pZ = s_pool[2] + base;
     float *const qX = s_pool[3] + base, *const qY = s_pool[4] + base, *const qZ = s_pool[5] + base;
 #pragma unroll
@@ -832,6 +840,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         qX[e] = nX; qY[e] = nY; qZ[e] = nZ;
     }
     __builtin_amdgcn_wave_barrier();
+    SECTION_STAMP();   // 2: positions + pixel normals
     bool active = inRange && nvalid >= 16;   // validDepthNum < 16 -> continue (:702)
     float meanDepth = S.meanDepth;
     // ---- inliers, kept in order (:707-720).  Count first: when every valid pixel is an inlier (the common case)
@@ -872,6 +881,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    SECTION_STAMP();   // 3: inlier count / compaction
     if (active && (float)ninl / (float)nvalid < 0.8) active = false;
     // Six strictly sequential f32 sums (inlier normals x,y,z and positions x,y,z, :709-713 and :95-99) run side by side:
     // lane q < 6 of the group walks array q in list order, so the serial latency is one chain instead of six.
@@ -886,6 +896,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         normX = normX / normLength; normY = normY / normLength; normZ = normZ / normLength;
         sumX /= ninl; sumY /= ninl; sumZ /= ninl;
     }
+    SECTION_STAMP();   // 4: six sequential sums
     // ---- getHuberNorm (:91-165): 5 Gauss-Newton steps, FP64 normal equations reduced over the 16 lanes ----
     float nx = normX, ny = normY, nz = normZ, nb = 0.0f;
     // The Hessian depends only on WHICH points lie inside the Huber band; while that set is unchanged between
@@ -968,7 +979,14 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         const double u0 = __shfl(updr, gbase + 0, 64), u1 = __shfl(updr, gbase + 1, 64), u2 = __shfl(updr, gbase + 2, 64),
                      u3 = __shfl(updr, gbase + 3, 64);
         nx = (float)((double)nx - u0); ny = (float)((double)ny - u1); nz = (float)((double)nz - u2); nb = (float)((double)nb - u3);
+        SECTION_STAMP();   // 5-9: Gauss-Newton steps
     }
+#ifdef MSL_FUSE_STAMPS
+    if (slot == 0 && lane == 0) {
+        for (int q = 1; q < ssn; q++) atomicAdd(&P.delList[64 + q], (unsigned)(sst[q] - sst[q - 1]));
+        atomicAdd(&P.delList[64], 1u);
+    }
+#endif
     if (!inRange || l != 0) return;
     if (active) {
         nb = nb - (nx * sumX + ny * sumY + nz * sumZ);
@@ -1318,6 +1336,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     unsigned long long cst[6];
     cst[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // Steady state (k_fuse handed over <= LIST_D deleted slots): workgroup 0 does everything alone; the others leave after one load
+    // instead of fetching the partials and flags as well.
+    if (mode == 0 && blockIdx.x != 0 && *P.delUCount <= LIST_D) return;
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
@@ -1738,6 +1759,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
         MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
+        MSL_HIP_TRY(hipMemset(ndl, 0, sizeof(unsigned) * 256));   // (instrumented builds accumulate section counters in its first words)
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
         if (keep && h->d_mapStore) {
             int rc = sync_all(h);
@@ -2370,13 +2392,12 @@ int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {
     for (int i = 0; i < 16; i++) out[i] = h->h_ctr[i];
     return MSL_OK;
 }
-int msl_sf_debug_scratch(msl_sf *h, uint32_t *out, size_t n_words) {
-    if (!h || !out || n_words > h->mapCap || n_words < 16) return MSL_ERR_INVALID;
+int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words) {
+    if (!h || !out || which < 0 || which > 1 || offset_words + n_words > h->mapCap) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
-    MSL_HIP_TRY(hipMemcpy(out, h->d_srcOf, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
-    MSL_HIP_TRY(hipMemcpy(out, h->d_delList, sizeof(uint32_t) * 8, hipMemcpyDeviceToHost));   // words 0-7: k_compact's stamps (sub-block 0 has no k_fuse stamps then)
+    MSL_HIP_TRY(hipMemcpy(out, (which == 0 ? h->d_srcOf : h->d_delList) + offset_words, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
     return MSL_OK;
 }
 int msl_sf_debug_index(msl_sf *h, int32_t *out) {

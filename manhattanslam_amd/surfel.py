@@ -155,9 +155,9 @@ class SurfelFusion:
         check(lib.msl_sf_debug_ctr(self._h, ptr(out)))
         return out
 
-    def debug_scratch(self, n_words):
+    def debug_scratch(self, n_words, which=0, offset=0):
         out = np.zeros(n_words, np.uint32)
-        check(lib.msl_sf_debug_scratch(self._h, ptr(out), n_words))
+        check(lib.msl_sf_debug_scratch(self._h, int(which), int(offset), ptr(out), n_words))
         return out
 
     def debug_index(self):

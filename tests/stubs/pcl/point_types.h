@@ -1,4 +1,4 @@
-// TEST-ONLY declarations (see tests/stubs/README.md): the slice of PCL the SurfelMapping adapter uses.  No implementation.
+// TEST-ONLY stand-in (see tests/stubs/README.md): the slice of PCL the SurfelMapping adapter uses (a point cloud is a vector of points).
 #pragma once
 #include <cstdint>
 #include <memory>
@@ -10,6 +10,6 @@ template <typename T> class PointCloud {
 public:
     typedef std::shared_ptr<PointCloud<T>> Ptr;
     std::vector<T> points;
-    void push_back(const T &p);
+    void push_back(const T &p) { points.push_back(p); }
 };
 }  // namespace pcl
