@@ -655,6 +655,9 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 
 // kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
 // although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
+// For image sizes this library accepts (multiples of 8) the rule can never fire: a used seed always owns the pixel at its lattice
+// centre -- a free pixel whose only updatePixels candidate is that seed (see the proof next to the `break` in oracle/surfel_oracle.cpp
+// and tests/test_oracle_surfel.py::test_used_seed_always_owns_its_centre_pixel) -- so the restore path is kept for fidelity only.
 __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;

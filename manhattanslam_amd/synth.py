@@ -34,7 +34,7 @@ def orb_frame(seed=ORB_SEED, w=640, h=480):
     for x, y, rw, rh, g in zip(xs, ys, ws, hs, gs):
         img[y:y + rh, x:x + rw] = g
     # fine structure: many small high-contrast blocks so that level 0 yields thousands of FAST corners
-    n_small = int(7000 * s * s)
+    n_small = int(9500 * s * s)
     xs = rng.integers(0, w, n_small); ys = rng.integers(0, h, n_small)
     ws = rng.integers(2, 10, n_small); hs = rng.integers(2, 10, n_small)
     gs = rng.integers(0, 256, n_small)
@@ -47,6 +47,16 @@ def orb_frame(seed=ORB_SEED, w=640, h=480):
         x = lx + int(rng.integers(0, lw - 8)); y = ly + int(rng.integers(0, lh - 8))
         rw = int(rng.integers(4, int(30 * s))); rh = int(rng.integers(4, int(30 * s)))
         img[y:min(y + rh, ly + lh), x:min(x + rw, lx + lw)] = 110 + int(rng.integers(-12, 13))
+    # ... whose top-left 64 x 64 corner holds contrasts of at most 9 + 9 < 20 only: at least one FAST cell lies inside it and is
+    # guaranteed to need the 20 -> 7 fallback (the +-12 rectangles above usually produce such cells, but not for every seed)
+    ss = int(64 * s)
+    img[ly:ly + ss, lx:lx + ss] = 110
+    for iy, gy in enumerate(range(ly + 4, ly + ss - 12, 16)):      # isolated 8 x 8 squares, +-9 against the base
+        for ix, gx in enumerate(range(lx + 4, lx + ss - 12, 16)):
+            sg = 1 if (ix + iy) & 1 else -1
+            img[gy:gy + 8, gx:gx + 8] = 110 + 9 * sg
+            for cy, cx in ((gy, gx), (gy, gx + 7), (gy + 7, gx), (gy + 7, gx + 7)):   # a stronger corner pixel: on a perfectly uniform square
+                img[cy, cx] = 110 + 10 * sg                                        # all scores tie and the strict 3x3 NMS removes every corner
     # flat patch
     fx0, fy0, fs = int(420 * s), int(60 * s), int(96 * s)
     img[fy0:fy0 + fs, fx0:fx0 + fs] = 128

@@ -251,3 +251,43 @@ def test_second_gaussian_generation_variant(tmp_path):
     assert np.array_equal(out[7:14, 7:14], want) and out.sum() == want.sum()
     # the default library keeps the 3.x kernel
     assert list(oracle_lib.load().gaussian_kernel()) == [18, 34, 49, 55, 49, 34, 18]
+
+
+def _cell_counts(o, img):
+    """Keypoints per FAST cell at thresholds 20 and 7 (the 20 -> 7 rule of src/ORBextractor.cc:723-780) on one level image."""
+    import math
+    h, w = img.shape
+    minB, maxBX, maxBY = 16, w - 16, h - 16
+    width, height = float(maxBX - minB), float(maxBY - minB)
+    nCols, nRows = int(width / 30), int(height / 30)
+    wCell, hCell = math.ceil(width / nCols), math.ceil(height / nRows)
+    n20, n7 = [], []
+    for i in range(nRows):
+        iniY = minB + i * hCell
+        maxY = min(iniY + hCell + 6, maxBY)
+        if iniY >= maxBY - 3:
+            continue
+        for j in range(nCols):
+            iniX = minB + j * wCell
+            maxX = min(iniX + wCell + 6, maxBX)
+            if iniX >= maxBX - 6:
+                continue
+            a = len(o.fast(img[iniY:maxY, iniX:maxX], 20))
+            n20.append(a)
+            n7.append(len(o.fast(img[iniY:maxY, iniX:maxX], 7)) if a == 0 else -1)
+    return np.array(n20), np.array(n7)
+
+
+@pytest.mark.parametrize("seed_off", [0, 7, 63])
+def test_synthetic_orb_frame_meets_the_survey_acceptance(oracle, seed_off):
+    """SURVEY.md 8(d), config 2 generator acceptance: >= 3 000 FAST candidates at level 0, every level reaches its quota, at least one cell
+    takes the 20 -> 7 fallback and at least one cell is empty at both thresholds (level 0 had 2 697 and nothing asserted it)."""
+    from manhattanslam_amd import synth
+    img = synth.orb_frame(synth.ORB_SEED + seed_off)
+    ex = oracle.orb_create()
+    k, _ = ex.extract(img)
+    assert len(ex.candidates(0)) >= 3000
+    quotas = [217, 181, 151, 126, 105, 87, 73, 60]
+    assert all(int((k["octave"] == l).sum()) >= q for l, q in enumerate(quotas))
+    n20, n7 = _cell_counts(oracle, img)
+    assert ((n20 == 0) & (n7 > 0)).sum() >= 1 and ((n20 == 0) & (n7 == 0)).sum() >= 1

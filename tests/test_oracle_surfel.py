@@ -3,6 +3,7 @@ import hashlib
 import os
 
 import numpy as np
+import pytest
 
 from manhattanslam_amd import synth
 from tests.oracle_lib import OracleSurfel, SURFEL_DTYPE, fuse_map_compact, load
@@ -162,3 +163,33 @@ def test_fabs_pin_known_answer():
     assert f32(f(float(a), 0.0, float(b), 0.0, float(c), 0.0, 0)) == chain        # pinned: std::fabs(float)
     assert f32(f(float(a), 0.0, float(b), 0.0, float(c), 0.0, 1)) == once         # alternative: ::fabs(double)
     assert abs(float(chain) - float(once)) <= float(np.spacing(chain)) and z == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_used_seed_always_owns_its_centre_pixel(seed):
+    """The chunk-abort `return` of src/SurfelFusion.cpp:473-474 needs a used seed that owns no pixel.  It cannot happen for image sizes that
+    are multiples of 8: the pixel at the lattice centre of a used seed is free and has that seed as its only candidate (x mod 8 == 4), so
+    it is assigned in pass 0 and never moves.  Checked on adversarial inputs: white noise, stripes that pull every other pixel away, NaN /
+    zero / huge depth, random membership holes."""
+    rng = np.random.default_rng(seed)
+    w, h = 160, 120
+    gray = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    if seed == 1:
+        gray[:, ::2] = 0; gray[:, 1::2] = 255
+    if seed == 2:
+        gray[:] = np.where((np.arange(w)[None, :] // 4 + np.arange(h)[:, None] // 4) & 1, 255, 0)
+        gray[4::8, 4::8] = 128                                    # centre pixels unlike everything around them
+    depth = rng.uniform(0.3, 5.0, (h, w)).astype(np.float32)
+    depth[rng.random((h, w)) < 0.2] = 0.0
+    depth[rng.random((h, w)) < 0.02] = np.nan
+    depth[rng.random((h, w)) < 0.02] = 1e30
+    member = np.full((h // 2, w // 2), -1, np.int32)
+    member[rng.random(member.shape) < 0.15] = 3
+    sf = OracleSurfel(w, h, 130.0, 130.0, 80.0, 60.0, 30.0, 0.5)
+    pose = np.eye(4, dtype=np.float32).T.reshape(16).copy()
+    sf.fuse(0, gray, depth, member, pose, np.zeros(0, SURFEL_DTYPE))
+    seeds, index = sf.seeds(), sf.index()
+    used = np.flatnonzero(seeds["use"])
+    assert len(used) > 100
+    cy, cx = (used // (w // 8)) * 8 + 4, (used % (w // 8)) * 8 + 4
+    assert np.array_equal(index[cy, cx], used)
