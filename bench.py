@@ -519,63 +519,59 @@ def main():
 
 
 def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, device, resident_value):
-    """--io host: the same passes, but every call reads its frames from PINNED HOST memory (hipMemcpyAsync inside the library, on the
-    handles' own streams, double-buffered slot sets) and ORB writes keypoints / descriptors / counts back to pinned host memory, as the
-    reference's consumers need them (src/Frame.cc:103-153 are host code).  Two host threads feed the two handles so that their copies
-    and kernels overlap.  Reported next to `value`, never instead of it."""
+    """--io host: the same passes, but every call reads its frames from PINNED HOST memory and ORB writes keypoints / descriptors / counts
+    back to pinned host memory, as the reference's consumers need them (src/Frame.cc:103-153 are host code), through the library's
+    MSL_MEM_HOST paths.  Overlap of copies and kernels across calls comes from handles and threads, not from a new entry point: two ORB
+    handles (own stream and staging each) are fed by two host threads with alternating calls -- a synchronous host-to-host call blocks
+    only its thread --, and one thread feeds the surfel handle, whose host-image batches are asynchronous already (double-buffered slot
+    sets, copies on the superpixel stream).  Reported next to `value`, never instead of it."""
     import threading
     import torch
     from manhattanslam_amd import ORBextractor, SurfelFusion
-    from manhattanslam_amd._lib import KEYPOINT_DTYPE
     do_orb, do_sf = cfg["orb"], cfg["sf"]
     nsub = F // B
     nkf = B // kfe if do_sf else 0
     reps = F // D
-    # pinned host copies of the pass's frames (torch pinned memory = hipHostMalloc)
-    h_gray = torch.from_numpy(np.tile(grays, (reps, 1, 1))).pin_memory()
-    orb = sf = None
+    g_np = torch.from_numpy(np.tile(grays, (reps, 1, 1))).pin_memory().numpy()     # torch pinned memory = hipHostMalloc
+    orbs, sf = [], None
     if do_orb:
-        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=device)
-        cap = orb.capacity
-        h_kps = torch.zeros(F * cap * 28, dtype=torch.uint8).pin_memory()
-        h_desc = torch.zeros(F * cap * 32, dtype=torch.uint8).pin_memory()
-        h_n = torch.zeros(F, dtype=torch.int32).pin_memory()
+        orbs = [ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=B, device=device) for _ in range(2)]
+        cap = orbs[0].capacity
+        h_kps = torch.zeros(F * cap * 28, dtype=torch.uint8).pin_memory().numpy()
+        h_desc = torch.zeros(F * cap * 32, dtype=torch.uint8).pin_memory().numpy()
+        h_n = torch.zeros(F, dtype=torch.int32).pin_memory().numpy()
     if do_sf:
         sf = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=device)
         sf.set_batch_capacity(nkf)
         sf.map_reserve(2 * args.surfels + 65536)
         sf.map_upload(smap)
         sf.map_snapshot()
-        h_depth = torch.from_numpy(np.tile(depths, (reps, 1, 1))).pin_memory()
-        h_member = torch.from_numpy(member).pin_memory()
+        d_np = torch.from_numpy(np.tile(depths, (reps, 1, 1))).pin_memory().numpy()
+        m_np = torch.from_numpy(member).pin_memory().numpy()
         kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
-    g_np, = (h_gray.numpy(),)
 
-    def orb_pass():
-        for sb in range(nsub):
-            orb.extract_batch_host(g_np[sb * B:(sb + 1) * B], h_kps.numpy()[sb * B * cap * 28:], h_desc.numpy()[sb * B * cap * 32:], h_n.numpy()[sb * B:], B, W, H)
+    def orb_worker(which, npass):
+        ex = orbs[which]
+        for _ in range(npass):
+            for sb in range(which, nsub, 2):
+                ex.extract_batch_host(g_np[sb * B:(sb + 1) * B], h_kps[sb * B * cap * 28:], h_desc[sb * B * cap * 32:], h_n[sb * B:], B, W, H)
 
-    def sf_pass():
-        sf.map_restore()
-        d_np, m_np = h_depth.numpy(), h_member.numpy()
-        for sb in range(nsub):
-            sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], d_np[sb * B:], m_np, kf_poses[sb], device=False,
-                                   member_shared=True, frame_step=kfe)
+    def sf_worker(npass):
+        for _ in range(npass):
+            sf.map_restore()
+            for sb in range(nsub):
+                sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], d_np[sb * B:], m_np, kf_poses[sb], device=False,
+                                       member_shared=True, frame_step=kfe)
+        sf.sync()
 
     def run(npass):
-        th = []
-        if do_orb:
-            th.append(threading.Thread(target=lambda: [orb_pass() for _ in range(npass)]))
+        th = [threading.Thread(target=orb_worker, args=(i, npass)) for i in range(len(orbs))]
         if do_sf:
-            th.append(threading.Thread(target=lambda: [sf_pass() for _ in range(npass)]))
+            th.append(threading.Thread(target=sf_worker, args=(npass,)))
         for t in th:
             t.start()
         for t in th:
             t.join()
-        if do_orb:
-            orb.sync()
-        if do_sf:
-            sf.sync()
 
     run(2)
     npass = max(2, min(P * args.steps, 24))
@@ -583,15 +579,17 @@ def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F,
     run(npass)
     dt = time.perf_counter() - t0
     fps = npass * F / dt
-    n_kp = int(h_n.numpy().sum()) if do_orb else 0
-    h2d = (W * H * (1 if do_orb or do_sf else 0) * (2 if do_orb and do_sf else 1) + (4 * W * H + W * H) / kfe * (1 if do_sf else 0))   # bytes per frame
-    d2h = (60.0 * n_kp / F + 4) if do_orb else 0.0
+    n_kp = int(h_n.sum()) if do_orb else 0
+    h2d = (W * H if do_orb else 0) + ((W * H + 4 * W * H) / kfe if do_sf else 0)        # bytes per frame (gray for ORB; gray + f32 depth per keyframe)
+    d2h = (60.0 * cap + 4) if do_orb else 0.0                                            # the library copies the full-capacity keypoint / descriptor rows
     res = {"value_streaming": round(fps, 1), "unit": "frames/s", "fraction_of_resident": round(fps / resident_value, 3), "passes": npass,
+           "keypoints_per_frame": round(n_kp / F, 1) if do_orb else 0,
            "h2d_bytes_per_frame": int(h2d), "d2h_bytes_per_frame": int(d2h), "h2d_gbs": round(h2d * fps / 1e9, 2), "d2h_gbs": round(d2h * fps / 1e9, 3),
-           "note": "pinned host buffers in (gray for ORB and again for SurfelFusion, f32 depth, membership) and out (keypoints, descriptors, counts); "
-                   "msl_orb_extract_batch / msl_sf_fuse_resident_batch with MSL_MEM_HOST, one feeding thread per handle"}
-    if do_orb:
-        orb.close()
+           "note": "pinned host buffers in (gray for ORB and again for SurfelFusion, f32 depth; the shared membership image once per call) and out "
+                   "(keypoints, descriptors, counts); msl_orb_extract_batch / msl_sf_fuse_resident_batch with MSL_MEM_HOST; 2 ORB handles on 2 host "
+                   "threads + 1 thread for the surfel handle"}
+    for ex in orbs:
+        ex.close()
     if do_sf:
         sf.close()
     return res

@@ -1253,9 +1253,14 @@ int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int wid
     const uint8_t *d_gray = gray; size_t rs = row_stride, fs = frame_stride;
     if (in_mem == MSL_MEM_HOST) {
         h->prof.begin(KID_COPY, h->stream);
-        for (int f = 0; f < n_frames; f++)
-            MSL_HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * h->inPitch * height, h->inPitch, gray + (size_t)f * frame_stride,
-                                         row_stride, width, height, hipMemcpyHostToDevice, h->stream));
+        if (row_stride == (size_t)width && h->inPitch == (size_t)width && frame_stride == (size_t)width * height) {
+            // tightly packed frames (the streaming case): one copy for the whole batch
+            MSL_HIP_TRY(hipMemcpyAsync(h->d_in, gray, (size_t)width * height * n_frames, hipMemcpyHostToDevice, h->stream));
+        } else {
+            for (int f = 0; f < n_frames; f++)
+                MSL_HIP_TRY(hipMemcpy2DAsync(h->d_in + (size_t)f * h->inPitch * height, h->inPitch, gray + (size_t)f * frame_stride,
+                                             row_stride, width, height, hipMemcpyHostToDevice, h->stream));
+        }
         h->prof.end(h->stream);
         d_gray = h->d_in; rs = h->inPitch; fs = h->inPitch * height;
     }

@@ -1693,6 +1693,8 @@ struct msl_sf {
     SfDev dev{};
     int maxBatch = 1;              // keyframes per batch; slots = 2 * maxBatch (double-buffered sets)
     hipStream_t preStream = nullptr, mapStream = nullptr; bool ownStreams = true;
+    hipStream_t copyStream = nullptr;   // host-image mode: the H2D copies of slot set i + 1 run beside the superpixel kernels of set i
+    hipEvent_t evH2D[2] = {nullptr, nullptr};
     hipEvent_t evPre[2] = {nullptr, nullptr}, evMap[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
     bool evMapValid[2] = {false, false}, evCopyValid[2] = {false, false};
     unsigned long long batchNo = 0;
@@ -1746,6 +1748,7 @@ void drop_live_snapshots(msl_sf *h) {
 }
 
 int sync_all(msl_sf *h) {
+    if (h->ownStreams && h->copyStream) MSL_HIP_TRY(hipStreamSynchronize(h->copyStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     return MSL_OK;
@@ -1838,6 +1841,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
 }
 
 int read_ctr(msl_sf *h) {
+    if (h->ownStreams && h->copyStream) MSL_HIP_TRY(hipStreamSynchronize(h->copyStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 16, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
@@ -1925,14 +1929,30 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             MSL_HIP_TRY(hipMalloc(&h->d_gray, gb * slots)); MSL_HIP_TRY(hipMalloc(&h->d_depth, db * slots)); MSL_HIP_TRY(hipMalloc(&h->d_member, mb * slots));
             h->grayCap = gb; h->depthCap = db; h->memberCap = mb;
         }
-        h->prof.begin(SK_COPY, sp);
+        // The images travel on their own stream so that they overlap the superpixel kernels of the previous call (the other slot set);
+        // with caller-provided streams (msl_sf_set_stream) everything stays on that one stream.
+        hipStream_t sc = (h->ownStreams && h->copyStream) ? h->copyStream : sp;
+        if (sc != sp && h->evMapValid[set]) MSL_HIP_TRY(hipStreamWaitEvent(sc, h->evMap[set], 0));   // the set's previous user is done
+        h->prof.begin(SK_COPY, sc);
+        // Tightly packed frame arrays (the streaming case) travel as ONE copy per image kind instead of one per frame; a membership image
+        // shared by all keyframes of the call (member_frame_stride == 0) is staged once.
+        const bool packedG = n > 1 && gfs == gb && h->grayCap == gb, packedD = n > 1 && dfs == db && h->depthCap == db;
+        const bool packedM = n > 1 && mfs == mb && h->memberCap == mb;
+        if (packedG) MSL_HIP_TRY(hipMemcpyAsync(h->d_gray + (size_t)slot0 * h->grayCap, gray, gb * (size_t)n, hipMemcpyHostToDevice, sc));
+        if (packedD) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + (size_t)slot0 * h->depthCap, depth, db * (size_t)n, hipMemcpyHostToDevice, sc));
+        if (packedM) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + (size_t)slot0 * h->memberCap, member, mb * (size_t)n, hipMemcpyHostToDevice, sc));
+        if (mfs == 0) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + (size_t)slot0 * h->memberCap, member, mb, hipMemcpyHostToDevice, sc));
         for (int f = 0; f < n; f++) {
             const size_t s = slot0 + f;
-            MSL_HIP_TRY(hipMemcpyAsync(h->d_gray + s * h->grayCap, gray + f * gfs, gb, hipMemcpyHostToDevice, sp));
-            MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + s * h->depthCap, (const uint8_t *)depth + f * dfs, db, hipMemcpyHostToDevice, sp));
-            MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + s * h->memberCap, (const uint8_t *)member + f * mfs, mb, hipMemcpyHostToDevice, sp));
+            if (!packedG) MSL_HIP_TRY(hipMemcpyAsync(h->d_gray + s * h->grayCap, gray + f * gfs, gb, hipMemcpyHostToDevice, sc));
+            if (!packedD) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + s * h->depthCap, (const uint8_t *)depth + f * dfs, db, hipMemcpyHostToDevice, sc));
+            if (!packedM && mfs != 0) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + s * h->memberCap, (const uint8_t *)member + f * mfs, mb, hipMemcpyHostToDevice, sc));
         }
-        h->prof.end(sp);
+        h->prof.end(sc);
+        if (sc != sp) {
+            MSL_HIP_TRY(hipEventRecord(h->evH2D[set], sc));
+            MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evH2D[set], 0));
+        }
     }
     if (h->evCopyValid[set]) MSL_HIP_TRY(hipEventSynchronize(h->evCopy[set]));   // pinned staging of this set is free again
     for (int f = 0; f < n; f++) {
@@ -1940,7 +1960,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         if (mem == MSL_MEM_HOST) {
             const size_t s = slot0 + f;
             F.gray = h->d_gray + s * h->grayCap; F.depth = (const float *)((uint8_t *)h->d_depth + s * h->depthCap);
-            F.member = (const int32_t *)((uint8_t *)h->d_member + s * h->memberCap);
+            F.member = (const int32_t *)((uint8_t *)h->d_member + (mfs == 0 ? (size_t)slot0 : s) * h->memberCap);
         } else {
             F.gray = gray + f * gfs; F.depth = (const float *)((const uint8_t *)depth + f * dfs); F.member = (const int32_t *)((const uint8_t *)member + f * mfs);
         }
@@ -2035,10 +2055,12 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         ok = ok && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&h->preStream, hipStreamNonBlocking, lo) == hipSuccess;
         ok = ok && hipStreamCreateWithPriority(&h->mapStream, hipStreamNonBlocking, hi) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking) == hipSuccess;
     }
     for (int i = 0; i < 2 && ok; i++)
         ok = hipEventCreateWithFlags(&h->evPre[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->evMap[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&h->evCopy[i], hipEventDisableTiming) == hipSuccess;
+             hipEventCreateWithFlags(&h->evCopy[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&h->evH2D[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
@@ -2069,6 +2091,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
 void msl_sf_destroy(msl_sf *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
     if (h->preStream) (void)hipStreamSynchronize(h->preStream);
     if (h->mapStream) (void)hipStreamSynchronize(h->mapStream);
     h->prof.destroy();
@@ -2078,7 +2101,8 @@ void msl_sf_destroy(msl_sf *h) {
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_snap) (void)hipHostFree(h->h_snap);
     for (int i = 0; i < msl_sf::NSNAP; i++) if (h->snapEv[i]) (void)hipEventDestroy(h->snapEv[i]);
-    for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); }
+    for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); if (h->evH2D[i]) (void)hipEventDestroy(h->evH2D[i]); }
+    if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
     delete h;
 }

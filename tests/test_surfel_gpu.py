@@ -554,3 +554,22 @@ def test_wide_rgb_values_survive_the_byte_packed_cold_record(oracle):
     g.map_restore()
     assert g.map_download().tobytes() == m.tobytes()
     g.close()
+
+
+def test_host_image_batches_with_shared_membership_and_strided_frames(oracle):
+    """The streaming shapes of msl_sf_fuse_resident_batch with MSL_MEM_HOST: tightly packed frame arrays (one copy per image kind on the
+    copy stream), one membership image shared by the call (staged once), and a frame step > 1 (per-frame copies) -- all equal the oracle."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(20000, ref=0, min_update_times=5).astype(SURFEL_DTYPE)
+    g.map_upload(m); o.map_set(m)
+    frames = [synth.surfel_frame(k, variant="B") for k in range(8)]
+    grays = np.stack([f[0] for f in frames]); depths = np.stack([f[1] for f in frames]); member = frames[0][2]
+    g.set_batch_capacity(4)
+    g.fuse_resident_batch([0, 1, 2, 3], grays, depths, member, [frames[j][3] for j in range(4)], member_shared=True)                 # packed
+    g.fuse_resident_batch([4, 5, 6, 7], grays[4:], depths[4:], member, [frames[j][3] for j in range(4, 8)], member_shared=True)       # other slot set
+    g.fuse_resident_batch([8, 9, 10, 11], grays, depths, member, [frames[j][3] for j in (0, 2, 4, 6)], member_shared=True, frame_step=2)   # strided
+    for r, j in enumerate(list(range(8)) + [0, 2, 4, 6]):
+        o.fuse_map(r, frames[j][0], frames[j][1], member, frames[j][3])
+    assert_surfels_close(g.map_download(), o.map_get(), "host-image batches")
+    g.close()
