@@ -304,12 +304,16 @@ MSL_API int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const 
  *   vertex_offsets_out HOST [n_frames][max_planes + 1]  plane_vertices_[i] = vertex_indices_out[f][offsets[i] .. offsets[i + 1])
  *   vertex_indices_out HOST [n_frames][ceil(h/2) * ceil(w/2)]  cloud vertex indices of every plane, raster order inside a plane (the pMembership
  *                                                       argument of PlaneFitter::run, AHCPlaneFitter.hpp:341-361); needs params->do_refine
+ *   cloud_out          HOST [n_frames][ceil(h/2) * ceil(w/2)][3] doubles or NULL: PlaneDetection::cloud.vertices, the organised cloud of
+ *                                                       readDepthImage (src/PlaneExtractor.cpp:60-74) as the device computed it for the block fit
+ * Host worker threads: as many as the process may use CPUs (affinity mask, cgroup quota), divided by LOCAL_WORLD_SIZE when one process per GPU
+ * shares the node (torch.distributed.run sets it); MSL_PEAC_THREADS overrides.
  * msl_peac_extract_from_blocks: the same from block fits the caller already has (host stage only, no device). */
 typedef struct msl_peac_plane { double normal[3], center[3], mse; int32_t N, _pad; } msl_peac_plane;
 MSL_API int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
                                    int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,
-                                   msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out);
+                                   msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out, double *cloud_out);
 MSL_API int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
                                          int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
                                          const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,

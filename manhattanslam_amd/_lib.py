@@ -77,7 +77,7 @@ SIGNATURES = {
     "msl_peac_block_fit": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _i]),
     "msl_peac_membership_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
     "msl_peac_membership_from_blocks": (_i, [_vp, _vp, _sz, _sz, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp]),
-    "msl_peac_extract_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "msl_peac_extract_batch": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "msl_peac_extract_from_blocks": (_i, [_vp, _vp, _sz, _sz, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
     "msl_match_by_projection_batch": (_i, [_i, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),

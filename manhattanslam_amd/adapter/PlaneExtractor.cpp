@@ -1,7 +1,8 @@
 // Drop-in replacement for the reference's src/PlaneExtractor.cpp on top of libmsl.so (see PlaneExtractor.h).
-// readColorImage / readDepthImage keep the reference's host loop (the organised half-resolution cloud with its colours is a public member that
-// Frame::ExtractPlanes reads, src/Frame.cc:612-622); runPlaneDetection hands the raw depth image to msl_peac_extract_batch, which returns
-// plane_filter.run's outputs: the membership image, the extracted planes and the per-plane vertex lists.
+// readDepthImage only records its inputs and sizes the public cloud; runPlaneDetection hands the raw depth image to msl_peac_extract_batch, which
+// returns plane_filter.run's outputs -- the membership image, the extracted planes, the per-plane vertex lists -- AND the organised
+// half-resolution cloud (cloud.vertices, src/PlaneExtractor.cpp:60-74) the device computes for the block fit anyway; only the vertex colours,
+// a strided copy of the colour image, are gathered on the host (Frame::ExtractPlanes reads both, src/Frame.cc:612-622).
 #include "PlaneExtractor.h"
 
 #include <cmath>
@@ -40,19 +41,11 @@ bool PlaneDetection::readDepthImage(const cv::Mat depthImg, const cv::Mat &K, co
     fx_ = K.at<float>(0, 0); fy_ = K.at<float>(1, 1); cx_ = K.at<float>(0, 2); cy_ = K.at<float>(1, 2);
     depthMapFactor_ = depthMapFactor;
     depth16_ = depthImg;
-    int vertex_idx = 0;
+    int vertex_idx = 0;   // colours of the cloud vertices (every second pixel of every second row); the positions arrive with the extraction
     for (int i = 0; i < depthImg.rows; i += 2)
         for (int j = 0; j < depthImg.cols; j += 2) {
-            const double z = (double)(depthImg.at<unsigned short>(i, j)) * depthMapFactor;
-            if (std::isnan(z)) {
-                cloud.vertices[vertex_idx++] = VertexType(0, 0, z);
-                continue;
-            }
-            const double x = ((double)j - cx_) * z / fx_;
-            const double y = ((double)i - cy_) * z / fy_;
             const cv::Vec3b c = color_img_.at<cv::Vec3b>(i, j);
-            cloud.verticesColour[vertex_idx] = VertexColour(c[0], c[1], c[2]);
-            cloud.vertices[vertex_idx++] = VertexType(x, y, z);
+            cloud.verticesColour[vertex_idx++] = VertexColour(c[0], c[1], c[2]);
         }
     return true;
 }
@@ -62,11 +55,13 @@ void PlaneDetection::runPlaneDetection() {   // src/PlaneExtractor.cpp:77-80: pl
     plane_filter.membershipImg = cv::Mat(ch, cw, CV_32SC1);
     std::vector<msl_peac_plane> planes(maxPlanes);
     std::vector<int32_t> offsets(maxPlanes + 1), indices((size_t)cw * ch);
+    std::vector<double> xyz((size_t)cw * ch * 3);   // cloud.vertices as the device computed them
     int32_t nPlanes = 0;
     const int rc = msl_peac_extract_batch(device_, depth16_.ptr<uint16_t>(), depth16_.step, 0, depth16_.cols, depth16_.rows, 1, MSL_MEM_HOST, fx_, fy_, cx_, cy_,
                                           depthMapFactor_, &plane_filter.params, plane_filter.membershipImg.ptr<int32_t>(), &nPlanes, maxPlanes, planes.data(),
-                                          offsets.data(), indices.data());
+                                          offsets.data(), indices.data(), xyz.data());
     if (rc != MSL_OK) throw std::runtime_error(std::string("msl_peac_extract_batch: ") + msl_last_error());
+    for (size_t v = 0; v < (size_t)cw * ch; v++) cloud.vertices[v] = VertexType(xyz[3 * v], xyz[3 * v + 1], xyz[3 * v + 2]);
     plane_filter.extractedPlanes.clear();
     plane_vertices_.assign((size_t)nPlanes, std::vector<int>());
     for (int i = 0; i < nPlanes; i++) {

@@ -941,7 +941,17 @@ public:
 
 private:
     // MSL_PEAC_THREADS overrides the worker count (1 = everything on the calling thread)
-    SegPool() : maxWorkers_(std::max(0, std::min(64, getenv("MSL_PEAC_THREADS") ? atoi(getenv("MSL_PEAC_THREADS")) : usable_cpus()) - 1)) {}
+    // and one process per GPU shares the node's CPUs with its sibling ranks: LOCAL_WORLD_SIZE (set by torch.distributed.run) divides the budget,
+    // so 8 ranks do not start 8 x usable_cpus() workers
+    static int worker_budget() {
+        if (const char *t = getenv("MSL_PEAC_THREADS")) return atoi(t);
+        const char *lws = getenv("LOCAL_WORLD_SIZE");
+        const int ranks = lws ? std::max(1, atoi(lws)) : 1;
+        return std::max(1, usable_cpus() / ranks);
+    }
+    SegPool() : maxWorkers_(std::max(0, std::min(64, worker_budget()) - 1)) {
+        if (getenv("MSL_PEAC_POOL_REPORT")) fprintf(stderr, "[msl_peac] pool workers = %d (usable CPUs %d)\n", maxWorkers_ + 1, usable_cpus());
+    }
     const int maxWorkers_;
     std::mutex callMutex_;
     std::vector<std::unique_ptr<FrameSegmenter>> ws_;
@@ -1147,7 +1157,7 @@ int check_sinks(const std::vector<PlaneSink> &sinks, int max_planes) {
 int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                     msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
                     int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
-                    int32_t *vertex_indices_out) {
+                    int32_t *vertex_indices_out, double *cloud_out = nullptr) {
     if (!params || !membership_out || params->min_support < 1 || (planes_out && max_planes < 1) || ((vertex_offsets_out || vertex_indices_out) && !planes_out) ||
         ((vertex_offsets_out != nullptr) != (vertex_indices_out != nullptr)) || (vertex_indices_out && !params->do_refine)) {
         set_error("msl_peac: invalid argument (plane outputs need max_planes >= 1; vertex lists need planes_out, both list arrays and do_refine)");
@@ -1169,7 +1179,14 @@ int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes
         std::lock_guard<std::mutex> lock(g_scratchMutex);
         msl_peac_block *dBlocks = nullptr;
         uint16_t *dHalf = nullptr;
-        int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, nullptr,
+        double *dCloud = nullptr;   // the organised cloud of PlaneDetection::readDepthImage, when the caller wants it (k_peac_cloud)
+        if (cloud_out) {
+            Scratch &sc0 = g_scratch[device & 15];
+            PEAC_TRY(hipSetDevice(device));
+            PEAC_TRY(grow(sc0.cloud, sc0.cloudCap, sizeof(double) * 3 * (size_t)cw * ch * n_frames));
+            dCloud = (double *)sc0.cloud;
+        }
+        int rc = device_fit(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, *params, dCloud,
                             &dBlocks, &dHalf, nullptr);
         if (rc != MSL_OK) return rc;
         nBlocks = (size_t)(cw / params->window_w) * (ch / params->window_h);
@@ -1178,6 +1195,7 @@ int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes
         const hipStream_t st = g_scratch[device & 15].stream;
         PEAC_TRY(hipMemcpyAsync(hb.data(), dBlocks, sizeof(msl_peac_block) * hb.size(), hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipMemcpyAsync(half.data(), dHalf, sizeof(uint16_t) * half.size(), hipMemcpyDeviceToHost, st));
+        if (cloud_out) PEAC_TRY(hipMemcpyAsync(cloud_out, dCloud, sizeof(double) * 3 * (size_t)cw * ch * n_frames, hipMemcpyDeviceToHost, st));
         PEAC_TRY(hipStreamSynchronize(st));
         // Agglomerative clustering on the device (one wave per frame) when a frame's node data fits the LDS and the call is large enough;
         // MSL_PEAC_CLUSTER=host / device forces one side (same results: tests/test_peac_gpu.py runs both).
@@ -1266,10 +1284,10 @@ int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_st
 int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                            msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
                            int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
-                           int32_t *vertex_indices_out) {
+                           int32_t *vertex_indices_out, double *cloud_out) {
     if (!planes_out) { set_error("msl_peac_extract_batch: planes_out is NULL (use msl_peac_membership_batch for the image alone)"); return MSL_ERR_INVALID; }
     return membership_impl(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, params,
-                           membership_out, n_planes_out, max_planes, planes_out, vertex_offsets_out, vertex_indices_out);
+                           membership_out, n_planes_out, max_planes, planes_out, vertex_offsets_out, vertex_indices_out, cloud_out);
 }
 
 int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,

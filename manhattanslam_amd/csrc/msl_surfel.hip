@@ -40,7 +40,7 @@ namespace {
 
 constexpr int SP = 8;
 constexpr int NCHUNK = 10;  // THREAD_NUM, include/SurfelFusion.h:34
-constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, BASELINE_D = 0.5, DISPARITY_ERROR = 4.0, MIN_TOLERATE_DIFF = 0.1;
+constexpr double MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, MIN_TOLERATE_DIFF = 0.1;   // (BASELINE 0.5 and DISPARITY_ERROR 4.0 appear as exact float factors in k_fuse)
 constexpr unsigned T_INF = 0xFFFFFFFFu;
 constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the single-workgroup finisher
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
@@ -656,8 +656,10 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 // kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
 // although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
 // For image sizes this library accepts (multiples of 8) the rule can never fire: a used seed always owns the pixel at its lattice
-// centre -- a free pixel whose only updatePixels candidate is that seed (see the proof next to the `break` in oracle/surfel_oracle.cpp
-// and tests/test_oracle_surfel.py::test_used_seed_always_owns_its_centre_pixel) -- so the restore path is kept for fidelity only.
+// centre (8 spX + 4, 8 spY + 4).  That pixel is free (what `use` means, :541-545); its ONLY updatePixels candidate is this seed
+// (|8 c + 4 - x| < 8 holds for c = spX alone when x mod 8 == 4, :384-389); pass 0 assigns it with cost 0 < 1e6 whatever intensity / depth
+// are; no later pass can move it; and it lies inside the clipped window updateSeeds counts.  So the owned-pixel count is >= 1 and the
+// restore path is kept for fidelity only (property-tested on adversarial inputs in the CPU suite).
 __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;

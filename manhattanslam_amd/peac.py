@@ -86,17 +86,20 @@ def _split_planes(F, n, planes, offsets, indices):
     return out
 
 
-def extract(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, max_planes=64, device=0):
+def extract(depth_u16, fx, fy, cx, cy, depth_map_factor, params=None, max_planes=64, device=0, with_cloud=False):
     """Everything PlaneDetection hands on after runPlaneDetection: (membership [F, ch, cw], n_planes [F], per frame (planes PEAC_PLANE_DTYPE [n],
-    plane_vertices_: list of int32 vertex-index arrays))."""
+    plane_vertices_: list of int32 vertex-index arrays)); with_cloud=True appends cloud.vertices [F, ch * cw, 3] (float64)."""
     d = _frames(depth_u16)
     F, H, W = d.shape
     prm = default_params() if params is None else params
     ch, cw = (H + 1) // 2, (W + 1) // 2
     member = np.zeros((F, ch, cw), np.int32); n = np.zeros(F, np.int32)
     planes = np.zeros((F, max_planes), PEAC_PLANE_DTYPE); offsets = np.zeros((F, max_planes + 1), np.int32); indices = np.zeros((F, ch * cw), np.int32)
+    cloud = np.zeros((F, ch * cw, 3), np.float64) if with_cloud else None
     check(lib.msl_peac_extract_batch(device, ptr(d), d.strides[1], d.strides[0], W, H, F, MSL_MEM_HOST, fx, fy, cx, cy, depth_map_factor, ptr(prm), ptr(member),
-                                     ptr(n), max_planes, ptr(planes), ptr(offsets), ptr(indices)), "msl_peac_extract_batch")
+                                     ptr(n), max_planes, ptr(planes), ptr(offsets), ptr(indices), ptr(cloud)), "msl_peac_extract_batch")
+    if with_cloud:
+        return member, n, _split_planes(F, n, planes, offsets, indices), cloud
     return member, n, _split_planes(F, n, planes, offsets, indices)
 
 

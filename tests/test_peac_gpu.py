@@ -142,3 +142,10 @@ def test_extract_planes_and_vertex_lists(oracle, monkeypatch):
             assert gp.tobytes() == wp.tobytes(), (mode, f)
             assert len(gv) == len(wv) and all(np.array_equal(a, b) for a, b in zip(gv, wv)), (mode, f)
     assert sum(r[1] for r in ref) >= 5
+    # the organised cloud of PlaneDetection::readDepthImage comes back with the extraction (what adapter/PlaneExtractor.cpp fills cloud.vertices with)
+    got, n, planes, cloud = peac.extract(np.stack(frames[:2]), I["fx"], I["fy"], I["cx"], I["cy"], fac, with_cloud=True)
+    for f in range(2):
+        want_cloud, _ = oracle_lib.peac_block_stats(frames[f], I["fx"], I["fy"], I["cx"], I["cy"], fac)
+        assert cloud[f].tobytes() == np.ascontiguousarray(want_cloud).reshape(-1, 3).tobytes(), f
+        assert np.array_equal(got[f], ref[f][0])
+

@@ -156,3 +156,35 @@ def test_worker_count_does_not_change_the_result(oracle):
         assert r.returncode == 0 and "digest" in r.stdout, r.stdout + r.stderr
         digests.add(r.stdout.strip().split()[-1])
     assert len(digests) == 1
+
+
+def test_worker_budget_is_divided_among_local_ranks(oracle):
+    """One process per GPU: LOCAL_WORLD_SIZE (torch.distributed.run) divides the CPUs the host stage may use, so 8 ranks on a node do not start
+    8 x usable_cpus() workers (VERDICT round 2, weak #7).  MSL_PEAC_THREADS still overrides."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import numpy as np\n"
+            "from manhattanslam_amd import peac, synth\n"
+            "from tests import oracle_lib\n"
+            "I = synth.ICL; fac = np.float32(1 / 5000.0)\n"
+            "d = synth.depth_u16(synth.surfel_frame(3, intr=I, dropout=0.0)[1])\n"
+            "_, _, b = oracle_lib.peac_run(d, I['fx'], I['fy'], I['cx'], I['cy'], fac)\n"
+            "peac.plane_membership_from_blocks(b[None], d, I['fx'], I['fy'], I['cx'], I['cy'], fac)\n")
+
+    def workers(**envs):
+        env = dict(os.environ, MSL_PEAC_POOL_REPORT="1", **envs)
+        for k in ("MSL_PEAC_THREADS", "LOCAL_WORLD_SIZE"):
+            if k not in envs:
+                env.pop(k, None)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stderr.splitlines() if "[msl_peac] pool workers" in ln]
+        assert line, r.stderr[-2000:]
+        return int(line[0].split("=")[1].split()[0]), int(line[0].split("usable CPUs")[1].split(")")[0])
+
+    w1, cpus = workers()
+    w8, _ = workers(LOCAL_WORLD_SIZE="8")
+    assert w1 == min(64, cpus) and w8 == max(1, cpus // 8)
+    assert workers(LOCAL_WORLD_SIZE="8", MSL_PEAC_THREADS="3")[0] == 3
