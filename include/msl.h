@@ -382,6 +382,9 @@ MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
 /* n_words 32-bit words from offset_words of one of the compaction's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list;
  * host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
  * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
+/* Mean time (us) an event pair carried by a dispatch reports for an EMPTY kernel of `grid` single-wave workgroups on the map stream (n launches):
+ * the measurement overhead contained in msl_sf_profile_read's per-kernel times (rocprofv3's kernel durations do not contain it). */
+MSL_API int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us);
 MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words);
 
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */

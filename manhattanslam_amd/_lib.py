@@ -92,6 +92,7 @@ SIGNATURES = {
     "msl_sf_debug_index": (_i, [_vp, _vp]),
     "msl_sf_debug_ctr": (_i, [_vp, _vp]),
     "msl_sf_debug_scratch": (_i, [_vp, _i, _sz, _vp, _sz]),
+    "msl_sf_debug_event_overhead": (_i, [_vp, _i, _i, _vp]),
     "msl_debug_div100": (_i, [_vp, _vp, _sz]),
     "msl_sf_profile_enable": (_i, [_vp, _i]),
     "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),

@@ -1678,6 +1678,7 @@ __global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
     if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
 }
 
+__global__ void k_empty(int grid_dummy) { (void)grid_dummy; }
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = div100_exact((double)(x[i] * x[i]));
@@ -1686,7 +1687,7 @@ __global__ void k_debug_div100(const float *x, double *out, long long n) {
 enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_COMMIT_SEEDS, SK_SEED_PLANE, SK_FUSE, SK_NEW, SK_COMPACT,
        SK_CONVERT, SK_COPY };
 const char *kSfNames[MSL_SF_NKERNELS] = {"kb_seed_init", "kb_assign", "kb_prop", "kb_commit_px", "kb_update_seeds", "kb_commit_seeds",
-                                         "kb_seed_plane", "k_fuse", "(unused)", "k_compact", "k_convert", "copy"};
+                                         "kb_seed_plane", "k_fuse", "k_empty", "k_compact", "k_convert", "copy"};
 
 }  // namespace
 
@@ -2019,6 +2020,10 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     for (int f = 0; f < n; f++) {
         LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubHint);
         LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
+        if (f == n / 2) {   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
+            hipEvent_t ea, eb;   // (the pair's first event completes with the previous command, so every event time contains the dependent-launch gap)
+            if (h->prof.kernel_pair(SK_NEW, &ea, &eb)) hipExtLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, sm, ea, eb, 0, 0);
+        }
     }
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     if (compact && h->h_snap) {   // snapshot of the live count after this batch (picked up by a later call, never waited for)
@@ -2427,6 +2432,24 @@ int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *ou
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
     MSL_HIP_TRY(hipMemcpy(out, (which == 0 ? h->d_srcOf : h->d_delList) + offset_words, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
+    return MSL_OK;
+}
+// What an event pair carried by a dispatch (hipExtLaunchKernelGGL) reports for a kernel that does nothing: n launches of an empty kernel with
+// `grid` single-wave workgroups on the map stream.  bench.py quotes it next to the roofline kernel's event time: rocprofv3's kernel duration
+// (first wave start to last wave end) is shorter than the event time by about this much.
+int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us) {
+    if (!h || !mean_us || n < 1 || grid < 1) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = sync_all(h);
+    if (rc != MSL_OK) return rc;
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto &e : ev) MSL_HIP_TRY(hipEventCreate(&e));
+    for (int i = 0; i < n; i++) hipExtLaunchKernelGGL(k_empty, dim3((unsigned)grid), dim3(64), 0, h->mapStream, ev[2 * i], ev[2 * i + 1], 0, grid);
+    MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
+    double tot = 0;
+    for (int i = 0; i < n; i++) { float ms = 0; MSL_HIP_TRY(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    *mean_us = (float)(tot * 1e3 / n);
     return MSL_OK;
 }
 int msl_sf_debug_index(msl_sf *h, int32_t *out) {

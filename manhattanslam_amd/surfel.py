@@ -160,6 +160,11 @@ class SurfelFusion:
         check(lib.msl_sf_debug_scratch(self._h, int(which), int(offset), ptr(out), n_words))
         return out
 
+    def debug_event_overhead(self, grid=1, n=200):
+        us = C.c_float(0)
+        check(lib.msl_sf_debug_event_overhead(self._h, int(grid), int(n), C.byref(us)))
+        return float(us.value)
+
     def debug_index(self):
         out = np.zeros((self.height, self.width), np.int32)
         check(lib.msl_sf_debug_index(self._h, ptr(out)))

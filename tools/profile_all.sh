@@ -1,12 +1,21 @@
 #!/bin/bash
-# All rocprofv3 evidence of one round (run on the GPU box through gpurun): kernel trace + stats, FETCH_SIZE / WRITE_SIZE passes (separate
-# --pmc runs, never combined with the sys / hip trace domains), two SQ counter groups, and the bench line of the same build.
+# All rocprofv3 evidence of one round (run on the GPU box through gpurun, ~10 min): the default command (kernel trace + statistics, FETCH_SIZE /
+# WRITE_SIZE passes), kernel statistics of configurations 2-5, the SQ counter groups, and the bench lines of the same build (default with its
+# CPU baseline, configurations 2-5 with theirs, the 8 M-surfel run whose map exceeds the 256 MB Infinity Cache).
 # Usage: tools/profile_all.sh <tag>
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 tools/profile.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
-tools/pmc.sh $TAG bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-breakdown > gpurun_out/pmc_$TAG.log 2>&1
-cd $R && python bench.py --cpu-frames 0 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+for c in 2 3 4 5; do
+  O=$R/gpurun_out/prof_${TAG}_config$c; mkdir -p $O
+  (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --config $c --cpu-frames 0 --no-breakdown --steps 2 --warmup 1 > $O/trace.log 2>&1; rm -f $O/trace/*kernel_trace.csv)
+done
+tools/pmc.sh $TAG bench.py --steps 1 --warmup 1 --passes-per-step 2 --cpu-frames 0 --no-breakdown > gpurun_out/pmc_$TAG.log 2>&1
+python tools/summarize_pmc.py $TAG > gpurun_out/pmc_$TAG/sq_counters.txt 2>&1
+find gpurun_out/pmc_$TAG -name "*.csv" -delete
+python bench.py --io host > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+for c in 2 3 4 5; do python bench.py --config $c > gpurun_out/bench_${TAG}_config$c.json 2> gpurun_out/bench_${TAG}_config$c.err; done
+python bench.py --surfels 8000000 --cpu-frames 0 --steps 5 --passes-per-step 3 > gpurun_out/bench_${TAG}_8M.json 2> gpurun_out/bench_${TAG}_8M.err
 ls gpurun_out/prof_$TAG gpurun_out/pmc_$TAG | head -20
-tail -c 600 gpurun_out/bench_$TAG.json
+for f in gpurun_out/bench_$TAG*.json; do echo $f; tail -c 300 $f; echo; done
