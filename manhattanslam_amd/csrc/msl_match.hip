@@ -129,6 +129,7 @@ __device__ __forceinline__ bool project_query(const MatchDev &P, int pair, int q
     if (!(u >= P.prm.minX && u <= P.prm.maxX)) return false;   // NaN: GetFeaturesInArea would find no feature
     if (!(v >= P.prm.minY && v <= P.prm.maxY)) return false;
     const int nLastOctave = P.lastOctave[(size_t)pair * P.cap + q];
+    if (nLastOctave < 0 || nLastOctave >= P.prm.nlevels) return false;   // not an octave of this pyramid (the reference would index out of bounds): no candidates
     const float radius = P.prm.th * P.prm.scale_factors[nLastOctave];
     Q.u = u; Q.v = v; Q.invzc = invzc; Q.radius = radius;
     if (mode == 1) { Q.minLevel = nLastOctave; Q.maxLevel = -1; }
@@ -420,13 +421,20 @@ int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t 
     int rc = bind_device(device);
     if (rc != MSL_OK) return rc;
     uint8_t *da = nullptr, *db = nullptr; int32_t *dout = nullptr;
-    M_TRY(hipMalloc(&da, (size_t)n * 32)); M_TRY(hipMalloc(&db, (size_t)n * 32)); M_TRY(hipMalloc(&dout, sizeof(int32_t) * n));
-    M_TRY(hipMemcpy(da, a32, (size_t)n * 32, hipMemcpyHostToDevice)); M_TRY(hipMemcpy(db, b32, (size_t)n * 32, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_descriptor_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, n, dout);
-    M_TRY(hipMemcpy(dist_out, dout, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    auto run = [&]() -> int {   // every exit path below frees the three buffers
+        M_TRY(hipMalloc(&da, (size_t)n * 32)); M_TRY(hipMalloc(&db, (size_t)n * 32)); M_TRY(hipMalloc(&dout, sizeof(int32_t) * n));
+        M_TRY(hipMemcpy(da, a32, (size_t)n * 32, hipMemcpyHostToDevice)); M_TRY(hipMemcpy(db, b32, (size_t)n * 32, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_descriptor_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, n, dout);
+        M_TRY(hipGetLastError());
+        M_TRY(hipMemcpy(dist_out, dout, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+        return MSL_OK;
+    };
+    rc = run();
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
 #undef M_TRY
-    return MSL_OK;
+    return rc;
 }
 
 }  // extern "C"

@@ -1010,7 +1010,8 @@ hipError_t grow(void *&p, size_t &cap, size_t need) {
 int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t frameStrideBytes, int width, int height, int n_frames, msl_mem mem, float fx,
                float fy, float cx, float cy, float factor, const msl_peac_params &prm, double *cloudDev, msl_peac_block **dBlocksOut, uint16_t **dHalfOut /* nullptr: not wanted */,
                msl_peac_block *blocksUser /* device output buffer or nullptr */) {
-    if (!depth || width < 2 || height < 2 || n_frames < 1 || prm.window_w < 1 || prm.window_h < 1 || prm.window_w * prm.window_h > 4096 ||
+    // k_peac_fit stages 72 bytes per window point in dynamic LDS: up to 900 points (e.g. 30 x 30) fit the 64 KB a launch may ask for
+    if (!depth || width < 2 || height < 2 || n_frames < 1 || prm.window_w < 1 || prm.window_h < 1 || prm.window_w * prm.window_h > 900 ||
         strideBytes < (size_t)width * 2 || (n_frames > 1 && frameStrideBytes < strideBytes * (size_t)(height - 1) + (size_t)width * 2) || fx == 0 || fy == 0) {
         set_error("msl_peac: invalid argument");
         return MSL_ERR_INVALID;

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     // unclipped window is guarded by the flat index range (:680-684).  16 wide loads per lane: 8 B of index, 16 B of depth,
     // 16 B of the row below, 4 B right of the quad (the other right neighbours are the quad's own elements). ----
     float maxDist = 0;
-    int nvalid = 0, base = 0;
+    int nvalid = 0, base = 0, poolUsed = 0;
     {
         const int rq = l >> 2, cq = l & 3;
         // wrapped pixels (App. B.6) without an integer division: a quad left / right of the image (window columns start
@@ -804,8 +804,11 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
         {   // list bases inside the pool, each rounded up to 4 entries
             const int pad = (nvalid + 3) & ~3;
-            const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64);
+            const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64), n3 = __shfl(pad, 48, 64);
             base = g == 0 ? 0 : g == 1 ? n0 : g == 2 ? n0 + n1 : n0 + n1 + n2;
+            poolUsed = n0 + n1 + n2 + n3;
+            // the <= 3 padding entries behind a list take part in the wave-wide pass below: give them a valid pixel (row 0, column 0)
+            if (l < pad - nvalid) { s_pool[2][base + nvalid + l] = 0.0f; s_pool[3][base + nvalid + l] = 0.0f; s_pool[4][base + nvalid + l] = 0.0f; s_pool[5][base + nvalid + l] = 0.0f; }
         }
         const int g15 = (lane & 48) | 15;
         int run = base;
@@ -832,17 +835,19 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) maxDist = fmaxf(maxDist, __shfl_xor(maxDist, d, 16));
     __builtin_amdgcn_wave_barrier();
-    // balanced: entry e -> position + cross-product normal, written back in place (order preserved)
-    for (int e = l; e < nvalid; e += 16) {
-        const int rc = __float_as_int(qZ[e]);
+    // entry e -> position + cross-product normal, written back in place (order preserved).  The work per entry does not depend on the seed, so
+    // the 64 lanes walk the whole pool together: ceil(pool / 64) rounds instead of ceil(longest list / 16) -- the four superpixels of a wave
+    // rarely have the same size.
+    for (int e = lane; e < poolUsed; e += 64) {
+        const int rc = __float_as_int(s_pool[5][e]);
         const int row = rc >> 16, col = rc & 0xFFFF;     // a valid pixel lies inside the image: (row, col) of its flat index
-        const float myDepth = pZ[e], rightD = qX[e], downD = qY[e];
+        const float myDepth = s_pool[2][e], rightD = s_pool[3][e], downD = s_pool[4][e];
         const float cxr = P.colX[col], cx1 = P.colX[col + 1], ryr = P.rowY[row], ry1 = P.rowY[row + 1];
         const float x = cxr * myDepth, y = ryr * myDepth;   // back_project(col, row, myDepth)
         float nX, nY, nZ;
         pixel_normal(P, row, col, x, y, myDepth, rightD, downD, cxr, cx1, ryr, ry1, nX, nY, nZ);
-        pX[e] = x; pY[e] = y;
-        qX[e] = nX; qY[e] = nY; qZ[e] = nZ;
+        s_pool[0][e] = x; s_pool[1][e] = y;
+        s_pool[3][e] = nX; s_pool[4][e] = nY; s_pool[5][e] = nZ;
     }
     __builtin_amdgcn_wave_barrier();
     SECTION_STAMP();   // 2: positions + pixel normals
@@ -914,12 +919,15 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int r0 = ca == 0 ? 1 : 0, r1 = ca <= 1 ? 2 : 1, r2 = ca <= 2 ? 3 : 2;
     const int c0 = cb == 0 ? 1 : 0, c1 = cb <= 1 ? 2 : 1, c2 = cb <= 2 ? 3 : 2;
     const int gbase = lane & 48;
+    int tRounds = active ? (ninl + 15) >> 4 : 0;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) tRounds = max(tRounds, __shfl_xor(tRounds, d, 64));   // ninl is uniform inside a group of 16 lanes
+    tRounds = __builtin_amdgcn_readfirstlane(tRounds);
     for (int gnI = 0; gnI < 5; gnI++) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
         unsigned mask = 0;
         if (active) {
-#pragma unroll
-            for (int t = 0; t < 16; t++) {
+            for (int t = 0; t < tRounds; t++) {   // (a wave-uniform bound: the longest inlier list of the four seeds, typically 4-6 of the 16 rounds)
                 const int o = l + 16 * t;
                 if (o < ninl) {
                     const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
@@ -942,8 +950,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         if (__ballot(diffGroups != 0)) {
             double H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
             if (active && diffGroups) {
-#pragma unroll
-                for (int t = 0; t < 16; t++)
+                for (int t = 0; t < tRounds; t++)
                     if (mask & (1u << t)) {
                         const int o = l + 16 * t;
                         const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
