@@ -2022,7 +2022,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // grid: the last known live count plus a margin (k_fuse is grid-stride, so a map that outgrew it is still covered), never beyond the upper
     // bound; hint: the sub-blocks that were full at the last known count load without waiting for the live count
     const size_t known = std::min(h->liveKnown, boundLive);
-    const int nSubGrid = (int)std::max<size_t>(1, (std::min(known + 8 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS);
+    const int nSubGrid = (int)std::max<size_t>(1, (std::min(known + 2 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS);
     const int nSubHint = (int)(known / SUB_ITEMS);
     for (int f = 0; f < n; f++) {
         LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubHint);

@@ -573,3 +573,23 @@ def test_host_image_batches_with_shared_membership_and_strided_frames(oracle):
         o.fuse_map(r, frames[j][0], frames[j][1], member, frames[j][3])
     assert_surfels_close(g.map_download(), o.map_get(), "host-image batches")
     g.close()
+
+
+def test_map_outgrows_the_fuse_grid_inside_one_call(oracle):
+    """k_fuse's grid covers the host's last KNOWN live count plus 2 keyframes' worth of seeds; a call whose keyframes add more than that (an
+    empty map and 16 fresh views) is still covered because the kernel is grid-stride over the device's live count."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    g.map_upload(np.zeros(0, SURFEL_DTYPE)); o.map_set(np.zeros(0, SURFEL_DTYPE))
+    frames = [synth.surfel_frame(45 * k) for k in range(16)]          # 45 degrees apart: every keyframe spawns thousands of new surfels
+    g.set_batch_capacity(16)
+    frames = [synth.surfel_frame(23 * k) for k in range(16)]
+    refs = [7] * 16      # one reference index for all of them (it is an opaque int, SURVEY.md App. D): nothing goes stale, the map only grows
+    g.fuse_resident_batch(refs, np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]),
+                          [f[3] for f in frames])
+    for k, f in enumerate(frames):
+        o.fuse_map(refs[k], f[0], f[1], f[2], f[3])
+    mo = o.map_get()
+    assert len(mo) > 2 * g.nseeds + 8192, len(mo)      # well beyond the grid of the call's later launches
+    assert_surfels_close(g.map_download(), mo, "map grown past the fuse grid inside one call")
+    g.close()
