@@ -477,6 +477,9 @@ def main():
         "counters_per_rank": gathered,
     }
 
+    if args.io == "host" and world == 1:
+        out["streaming"] = streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, local_rank, value)
+
     if not args.no_breakdown:
         # per-kernel HIP-event breakdown (outside the timed region) + stage-only rates
         if do_sf:
@@ -522,9 +525,6 @@ def main():
                                         "note": "single stream, no co-running kernels; HIP events carried by the dispatch"}
         if world == 1:
             out["dropin"] = dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf, local_rank)
-
-    if args.io == "host" and world == 1:
-        out["streaming"] = streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, local_rank, value)
 
     if args.cpu_frames > 0 and world == 1:
         out["cpu_baseline"] = cpu_baseline(args, cfg, W, H, kfe)

@@ -3,7 +3,8 @@
 // Replaces PlaneDetection::readDepthImage + runPlaneDetection (reference src/PlaneExtractor.cpp:44-81), i.e.
 // ahc::PlaneFitter<ImagePointCloud>::run (include/peac/AHCPlaneFitter.hpp:218-262) with the reference's default parameters.
 //
-//   GPU (frame-batched, FP64, bit-identical to the host arithmetic of the reference):
+//   GPU (frame-batched, FP64; the same operations in the same order as the host arithmetic of the reference, ties among exactly equal merge costs
+//   resolved by node creation order where the reference depends on heap addresses -- DESIGN.md section 3):
 //     k_peac_cloud  organised half-resolution cloud (src/PlaneExtractor.cpp:60-74), only when the caller asks for it
 //     k_peac_fit    ONE WAVE PER WINDOW: the lanes evaluate the window's points in parallel -- missing data, depth discontinuity
 //                   towards the right / lower neighbour (include/peac/AHCPlaneSeg.hpp:237-285, :41-43), the nine products of
