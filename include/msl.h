@@ -172,13 +172,14 @@ MSL_API const char *msl_orb_kernel_name(int k);
  * ---------------------------------------------------------------------------------------- */
 typedef struct msl_sf msl_sf;
 
-/* Replaces SurfelFusion::SurfelFusion (src/SurfelFusion.cpp:29-38). */
+/* Replaces SurfelFusion::SurfelFusion (src/SurfelFusion.cpp:29-38).  Any width, height >= 16: like the reference, the superpixel lattice is
+ * (width / 8) x (height / 8), truncated; the pixels right of / below the last whole cell still take part in every per-pixel step. */
 MSL_API msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy,
                               float fuseFar, float fuseNear, int device);
 MSL_API void msl_sf_destroy(msl_sf *h);
 
 /* Host-vector mode == SurfelFusion::fuseInitializeMap (src/SurfelFusion.cpp:40-73).
- * gray: CV_8UC1 w*h; depth: CV_32FC1 metres; member: CV_32SC1 (w/2)*(h/2), -1 = no plane; strides
+ * gray: CV_8UC1 w*h; depth: CV_32FC1 metres; member: CV_32SC1 ceil(w/2)*ceil(h/2), -1 = no plane; strides
  * in bytes; pose = Twc as column-major 4x4 (Eigen::Matrix4f storage).  `local` (n_local surfels)
  * is updated in place; new surfels are written to new_out (<= (w/8)*(h/8)), count in *n_new. */
 MSL_API int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride,

@@ -82,7 +82,7 @@ struct FrameDev {
 };
 
 struct SfDev {
-    int W, H, spW, spH, nseeds, npx;
+    int W, H, spW, spH, nseeds, npx;   // npx = W * H (the flat pixel index range of the reference); spW = W / 8, spH = H / 8 (truncated, :29-38)
     float fx, fy, cx, cy, fuseFar, fuseNear;
     unsigned long long gstride, gbytes, dstride, mstride;   // gray bytes, depth floats, member ints
     const FrameDev *frames;      // [slots]
@@ -111,6 +111,8 @@ struct SfDev {
     unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
     const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
+    int pxStride;                // per-slot stride of the per-pixel arrays: npx rounded up to 64 (16-byte vector accesses stay aligned); last, so that
+                                 // the kernel-argument offsets of everything above are those the map-stage kernels were tuned with
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
     if (colI >= P.W || rowI >= P.H) return;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
     const int p = rowI * P.W + colI;
-    unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
+    unsigned short *index = P.index + (size_t)slot * P.pxStride, *amap = P.amap + (size_t)slot * P.pxStride;
     if (F.memberG()[(size_t)(rowI / 2) * P.mstride + colI / 2] != -1) {
         if (it == 0) index[p] = 0; else amap[p] = IDX_PLANE;
         return;
@@ -300,9 +302,9 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
     if (it == 0) {
         const float dpx = depth_at(P, F, rowI, colI);
         if (dpx > 0.01) myInvDepth = (float)(1.0 / (double)dpx);
-        P.pxInv[(size_t)slot * P.npx + p] = myInvDepth;
+        P.pxInv[(size_t)slot * P.pxStride + p] = myInvDepth;
     } else {
-        myInvDepth = P.pxInv[(size_t)slot * P.npx + p];
+        myInvDepth = P.pxInv[(size_t)slot * P.pxStride + p];
     }
     const int baseSpX = colI / SP, baseSpY = rowI / SP;
     float minDistDepth = 1e6f, minDistNodepth = 1e6f;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
         } else if (pick != cur) {
             // Only these pixels can extend a chain: p is processed iff its (stable) seed gets unstabilised before p, and it
             // then unstabilises a DIFFERENT seed.  (pick == cur would only re-lower t(cur) above its current value.)
-            P.wl[(size_t)slot * P.npx + atomicAdd(&P.wlCount[slot], 1u)] = (unsigned)p;
+            P.wl[(size_t)slot * P.pxStride + atomicAdd(&P.wlCount[slot], 1u)] = (unsigned)p;
         }
     }
 }
@@ -379,8 +381,8 @@ __global__ __launch_bounds__(256) void kb_prop(SfDev P, int round, int nSlots) {
     if (!xcd_slot(PROP_BLOCKS, nSlots, slot, blk)) return;
     if (!P.changed[slot * 8 + round]) return;
     unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
-    const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
-    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    const unsigned short *index = P.index + (size_t)slot * P.pxStride, *amap = P.amap + (size_t)slot * P.pxStride;
+    const unsigned *wl = P.wl + (size_t)slot * P.pxStride;
     const unsigned nwl = P.wlCount[slot];
     bool any = false;
     for (unsigned e = blk * 256 + threadIdx.x; e < nwl; e += PROP_BLOCKS * 256) any |= relax_pixel(tmin, index, amap, (int)wl[e]);
@@ -394,8 +396,8 @@ __global__ __launch_bounds__(1024) void kb_prop_finish(SfDev P) {
     if (threadIdx.x == 0) s_ch = P.changed[slot * 8 + PROP_ROUNDS];
     __syncthreads();
     unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
-    const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
-    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    const unsigned short *index = P.index + (size_t)slot * P.pxStride, *amap = P.amap + (size_t)slot * P.pxStride;
+    const unsigned *wl = P.wl + (size_t)slot * P.pxStride;
     const unsigned nwl = P.wlCount[slot];
     while (s_ch) {
         __syncthreads();
@@ -419,8 +421,8 @@ __global__ __launch_bounds__(256) void kb_prop_lds(SfDev P) {
     const unsigned nwl = P.wlCount[slot];
     if (nwl == 0) return;
     unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
-    const unsigned short *index = P.index + (size_t)slot * P.npx, *amap = P.amap + (size_t)slot * P.npx;
-    const unsigned *wl = P.wl + (size_t)slot * P.npx;
+    const unsigned short *index = P.index + (size_t)slot * P.pxStride, *amap = P.amap + (size_t)slot * P.pxStride;
+    const unsigned *wl = P.wl + (size_t)slot * P.pxStride;
     constexpr int NT = 256, R = 16;   // a 256-thread workgroup finds room on a busy GPU; a 16-wave one waits for a whole CU
     unsigned ep[R];
     unsigned short ec[R], ea[R];
@@ -455,14 +457,14 @@ __global__ __launch_bounds__(256) void kb_prop_lds(SfDev P) {
 }
 
 __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
-    // 8 consecutive pixels per thread (16-byte loads of both maps; npx is a multiple of 64).  A pixel whose pick equals its
+    // 8 consecutive pixels per thread (16-byte loads of both maps; the slot stride is a multiple of 64).  A pixel whose pick equals its
     // current seed cannot change, so t(s) is only looked up for the few pixels that picked a different seed.
     int slot, blk;
-    if (!xcd_slot((P.npx / 8 + 255) / 256, nSlots, slot, blk)) return;
+    if (!xcd_slot(((P.npx + 7) / 8 + 255) / 256, nSlots, slot, blk)) return;
     const int p0 = (blk * 256 + threadIdx.x) * 8;
     if (p0 >= P.npx) return;
-    unsigned short *index = P.index + (size_t)slot * P.npx;
-    const uint4 a4 = *reinterpret_cast<const uint4 *>(P.amap + (size_t)slot * P.npx + p0);
+    unsigned short *index = P.index + (size_t)slot * P.pxStride;
+    const uint4 a4 = *reinterpret_cast<const uint4 *>(P.amap + (size_t)slot * P.pxStride + p0);
     uint4 i4 = *reinterpret_cast<const uint4 *>(index + p0);
     const unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
     unsigned aw[4] = {a4.x, a4.y, a4.z, a4.w}, iw[4] = {i4.x, i4.y, i4.z, i4.w};
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(256) void kb_commit_px(SfDev P, int nSlots) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const unsigned a = (aw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu, cur = (iw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-        if (a >= IDX_PLANE || a == cur) continue;
+        if (a >= IDX_PLANE || a == cur || p0 + k >= P.npx) continue;   // (the last group may reach into the slot's padding)
         if (tmin[cur] <= (unsigned)(p0 + k)) {
             iw[k >> 1] = (iw[k >> 1] & ~(0xFFFFu << (16 * (k & 1)))) | (a << (16 * (k & 1)));
             changed = true;
@@ -501,6 +503,8 @@ __device__ __forceinline__ int row_incl_scan(int v) {
 // kb_update_seeds (:428-515): 16 lanes per seed (lane = window row), 16 seeds per workgroup.
 // Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window
 // raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
+template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can stick out over the right edge); the common instantiation stays at 80 VGPRs,
+                           // so that three k_fuse waves (64 VGPRs) fit next to its four waves per SIMD -- with 88 only two did (+0.5 us per k_fuse launch)
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     __shared__ __attribute__((aligned(16))) float s_depth[16][256];
     __shared__ __attribute__((aligned(16))) float s_term[16][256];   // in-range: 2*residual; Huber tails: +-inf markers
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int seedI = blk * 16 + g;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
-    const unsigned short *index = P.index + (size_t)slot * P.npx;
+    const unsigned short *index = P.index + (size_t)slot * P.pxStride;
     msl_seed S;
     memset(&S, 0, sizeof(S));
     bool active = seedI < P.nseeds;
@@ -539,12 +543,14 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     {
         // Lane = (row r of a group of four window rows, quad q of four window columns): 12 wide loads per lane (8 B of
         // index, 16 B of depth, 4 B of gray, four times) instead of 48 scalar ones.  Window columns start at a multiple
-        // of 4 and W is a multiple of 8, so a quad lies inside or outside the image as a whole.  Raster order of the
-        // window = (iteration, lane, element), which the ordered depth list below follows.
+        // of 4: a quad lies left of the image as a whole (first lattice column) or starts inside it.  When W is not a multiple of 4 the last
+        // quad of a window may stick out over the right edge: it is then loaded from W - 4 (inside the row) and its first elements, which
+        // belong to the neighbouring lane's quad, are masked (col >= col0) -- no element-wise path, the window order is unchanged.  Raster
+        // order of the window = (iteration, lane, element), which the ordered depth list below follows.
         const int rq = l >> 2, cq = l & 3;
         const int col0 = xb0 + 4 * cq;
-        const bool quadIn = col0 >= 0 && col0 + 3 < P.W;
-        const int colc = quadIn ? col0 : 0;
+        const bool quadIn = col0 >= 0 && (STRADDLE ? col0 < P.W : col0 + 3 < P.W);
+        const int colc = quadIn ? (STRADDLE ? min(col0, P.W - 4) : col0) : 0;
         Quad<unsigned short> idq[4];
         Quad<float> dq[4];
         Quad<uint8_t> gq[4];
@@ -564,8 +570,8 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             int c = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                const int col = col0 + e;
-                const bool own = rowOk && col >= xb && col < xe && idq[m].v[e] == seedI;
+                const int col = colc + e;
+                const bool own = rowOk && (!STRADDLE || col >= col0) && col >= xb && col < xe && idq[m].v[e] == seedI;
                 hd[e] = own && dq[m].v[e] > 0.1;
                 if (own) { sumX += col; sumY += j; sumI += gq[m].v[e]; cnt++; }
                 c += hd[e] ? 1 : 0;
@@ -655,7 +661,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 
 // kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
 // although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
-// For image sizes this library accepts (multiples of 8) the rule can never fire: a used seed always owns the pixel at its lattice
+// The rule can never fire: a used seed (lattice position spX < W / 8, spY < H / 8) always owns the pixel at its lattice
 // centre (8 spX + 4, 8 spY + 4).  That pixel is free (what `use` means, :541-545); its ONLY updatePixels candidate is this seed
 // (|8 c + 4 - x| < 8 holds for c = spX alone when x mod 8 == 4, :384-389); pass 0 assigns it with cost 0 < 1e6 whatever intensity / depth
 // are; no later pass can move it; and it lies inside the clipped window updateSeeds counts.  So the owned-pixel count is >= 1 and the
@@ -727,6 +733,8 @@ __device__ __forceinline__ double group_sum_d(double v) {
 // 24x24 = 576 distinct pixels; every pixel belongs to one seed, hence the four ordered lists hold <= 576 entries in total
 // (+ 3 x 3 for 16-byte alignment of each list) instead of 4 x 256.  14 KB per wave: 11 waves per CU instead of 5.
 constexpr int PLANE_POOL = 24 * 24 + 12;
+template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} -- a window quad can stick out over the right edge (instantiated separately: the common
+                           // geometry carries none of that code)
 __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     __shared__ __attribute__((aligned(16))) float s_pool[6][PLANE_POOL];   // position x y z, normal x y z
     __shared__ __attribute__((aligned(16))) double s_h[4][16];
@@ -745,7 +753,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const bool inRange = spX < P.spW && spY < P.spH;
     const int seedI = inRange ? spY * P.spW + spX : 0;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
-    const unsigned short *index = P.index + (size_t)slot * P.npx;
+    const unsigned short *index = P.index + (size_t)slot * P.pxStride;
     msl_seed S;
     memset(&S, 0, sizeof(S));
     if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
@@ -757,10 +765,14 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     int nvalid = 0, base = 0, poolUsed = 0;
     {
         const int rq = l >> 2, cq = l & 3;
-        // wrapped pixels (App. B.6) without an integer division: a quad left / right of the image (window columns start
-        // at a multiple of 4, W is a multiple of 8: never a partial quad) belongs to the previous / next row of the flat index
+        // wrapped pixels (App. B.6) without an integer division: a quad left / right of the image (window columns start at a multiple
+        // of 4) belongs to the previous / next row of the flat index.  When W is not a multiple of 4 the last quad of a window in the last
+        // lattice column can straddle the right edge: its elements beyond W - 1 are the first pixels of the next row (`straddle`, rare:
+        // element-wise loads).
         const int cx0 = xb + 4 * cq;
         const int wrapRow = cx0 < 0 ? -1 : (cx0 >= P.W ? 1 : 0), wcol0 = cx0 - wrapRow * P.W;
+        const bool straddle = STRADDLE && cx0 < P.W && cx0 + 3 >= P.W;
+        auto elem_wrap = [&](int e) -> int { return (straddle && cx0 + e >= P.W) ? 1 : 0; };   // extra row wrap of element e of a straddling quad
         Quad<unsigned short> idq[4];
         Quad<float> dq[4], ddq[4];
         float dr3[4];
@@ -768,16 +780,27 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         for (int m = 0; m < 4; m++) {
             const int wr = yb + 4 * m + rq + wrapRow;
             const int row = min(max(wr, 0), P.H - 1);     // rows outside the image fail the flat-index test below
-            idq[m] = load_quad(index + (size_t)row * P.W + wcol0);
-            dq[m] = load_quad(F.depthG() + (size_t)row * P.dstride + wcol0);
-            ddq[m] = load_quad(F.depthG() + (size_t)min(row + 1, P.H - 1) * P.dstride + wcol0);
-            dr3[m] = F.depthG()[(size_t)row * P.dstride + min(wcol0 + 4, P.W - 1)];
+            if (!straddle) {
+                idq[m] = load_quad(index + (size_t)row * P.W + wcol0);
+                dq[m] = load_quad(F.depthG() + (size_t)row * P.dstride + wcol0);
+                ddq[m] = load_quad(F.depthG() + (size_t)min(row + 1, P.H - 1) * P.dstride + wcol0);
+                dr3[m] = F.depthG()[(size_t)row * P.dstride + min(wcol0 + 4, P.W - 1)];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int we = elem_wrap(e), col = cx0 + e - we * P.W, rowe = min(max(wr + we, 0), P.H - 1);
+                    idq[m].v[e] = index[(size_t)rowe * P.W + col];
+                    dq[m].v[e] = F.depthG()[(size_t)rowe * P.dstride + col];
+                    ddq[m].v[e] = F.depthG()[(size_t)min(rowe + 1, P.H - 1) * P.dstride + col];
+                }
+                dr3[m] = 0.0f;
+            }
         }
         // Texel map for k_fuse: every pixel's {depth, final index} as one 8-byte word.  The seed's own 8x8 cell is rows / columns
         // [4, 12) of its window (iterations 1, 2; column quads 1, 2), and the cells tile the image, so each pixel is written exactly
         // once from values this lane holds anyway: two 16-byte stores per iteration for half of the lanes.
         if (inRange && (cq == 1 || cq == 2)) {
-            uint2 *tex = P.tex + (size_t)slot * P.npx;
+            uint2 *tex = P.tex + (size_t)slot * P.pxStride;
 #pragma unroll
             for (int m = 1; m <= 2; m++) {
                 uint4 *t4 = reinterpret_cast<uint4 *>(tex + (size_t)(yb + 4 * m + rq) * P.W + cx0);
@@ -822,8 +845,15 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (q & (1u << e)) {   // depth, right depth, down depth, (row, col)
-                    s_pool[2][o] = dq[m].v[e]; s_pool[3][o] = e < 3 ? dq[m].v[e < 3 ? e + 1 : 3] : dr3[m];
-                    s_pool[4][o] = ddq[m].v[e]; s_pool[5][o] = __int_as_float(rc + e);
+                    float right = e < 3 ? dq[m].v[e < 3 ? e + 1 : 3] : dr3[m];
+                    int rce = rc + e;
+                    if (straddle) {   // (row, col) and the right neighbour of an element of a straddling quad, fetched here (rare)
+                        const int we = elem_wrap(e), col = cx0 + e - we * P.W, rowe = yb + 4 * m + rq + we;
+                        rce = (rowe << 16) | col;
+                        right = F.depthG()[(size_t)rowe * P.dstride + min(col + 1, P.W - 1)];
+                    }
+                    s_pool[2][o] = dq[m].v[e]; s_pool[3][o] = right;
+                    s_pool[4][o] = ddq[m].v[e]; s_pool[5][o] = __int_as_float(rce);
                     o++;
                 }
             run += __shfl(incl, g15, 64);
@@ -1058,6 +1088,22 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     }
 }
 
+// Image sizes that are not multiples of 8: the strips right of / below the last whole 8x8 cell belong to no cell, so kb_seed_plane does not
+// write their texels; this (tiny, rarely launched) kernel does.
+__global__ __launch_bounds__(256) void kb_tex_strips(SfDev P) {
+    const int slot = blockIdx.y;
+    const int wStrip = P.W - P.spW * SP, hStrip = P.H - P.spH * SP;
+    const int nRight = wStrip * P.spH * SP, nBottom = P.W * hStrip;   // right strip over the cell rows, bottom strip over the full width
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nRight + nBottom) return;
+    int x, y;
+    if (i < nRight) { y = i / wStrip; x = P.spW * SP + i % wStrip; }
+    else { const int j = i - nRight; y = P.spH * SP + j / P.W; x = j % P.W; }
+    const FrameDev F = P.frames[slot];
+    const size_t p = (size_t)y * P.W + x;
+    P.tex[(size_t)slot * P.pxStride + p] = make_uint2(__float_as_uint(F.depthG()[(size_t)y * P.dstride + x]), P.index[(size_t)slot * P.pxStride + p]);
+}
+
 // =============================================================================================
 // Map stage (per keyframe, sequential on the map stream)
 // =============================================================================================
@@ -1111,7 +1157,7 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     const MapSoA &M = P.map;
     const unsigned lane = threadIdx.x;
-    const uint2 *tex = P.tex + (size_t)slot * P.npx;
+    const uint2 *tex = P.tex + (size_t)slot * P.pxStride;
     const float4 *fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3;
     uint8_t *fused = P.fused + (size_t)slot * P.nseeds;
     const int ref = F.ref;
@@ -1814,7 +1860,7 @@ void free_slots(msl_sf *h) {
 int alloc_slots(msl_sf *h, int maxBatch) {
     free_slots(h);
     SfDev &D = h->dev;
-    const size_t slots = 2 * (size_t)maxBatch, ns = D.nseeds, npx = D.npx;
+    const size_t slots = 2 * (size_t)maxBatch, ns = D.nseeds, npx = D.pxStride;
     MSL_HIP_TRY(hipMalloc(&h->d_frames, sizeof(FrameDev) * slots));
     MSL_HIP_TRY(hipHostMalloc(&h->h_frames, sizeof(FrameDev) * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_seeds, sizeof(msl_seed) * ns * slots));
@@ -1892,7 +1938,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     SfDev &D = h->dev;
     const int W = D.W, H = D.H;
     if (n < 1 || n > h->maxBatch) { set_error("msl_sf: batch of %d keyframes exceeds the batch capacity %d", n, h->maxBatch); return MSL_ERR_INVALID; }
-    if (!gray || !depth || !member || !poses || !refs || gs < (size_t)W || ds < (size_t)W * 4 || ms < (size_t)(W / 2) * 4 || (ds & 3) || (ms & 3)) {
+    if (!gray || !depth || !member || !poses || !refs || gs < (size_t)W || ds < (size_t)W * 4 || ms < (size_t)((W + 1) / 2) * 4 || (ds & 3) || (ms & 3)) {
         set_error("msl_sf: bad image pointers or strides");
         return MSL_ERR_INVALID;
     }
@@ -1926,7 +1972,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     if (h->evMapValid[set] && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evMap[set], 0));   // the set's previous user is done
     D.gstride = gs; D.gbytes = gs * (size_t)(H - 1) + W; D.dstride = ds / 4; D.mstride = ms / 4;
     // bytes actually present in the caller's buffers: the last row carries no stride padding
-    const size_t gb = gs * (size_t)(H - 1) + W, db = ds * (size_t)(H - 1) + (size_t)W * 4, mb = ms * (size_t)(H / 2 - 1) + (size_t)(W / 2) * 4;
+    const size_t gb = gs * (size_t)(H - 1) + W, db = ds * (size_t)(H - 1) + (size_t)W * 4, mb = ms * (size_t)((H + 1) / 2 - 1) + (size_t)((W + 1) / 2) * 4;   // the membership image is ceil(H / 2) x ceil(W / 2) (PlaneDetection's cloud size)
     if (mem == MSL_MEM_HOST) {
         const size_t slots = 2 * (size_t)h->maxBatch;
         if (gb > h->grayCap || db > h->depthCap || mb > h->memberCap) {
@@ -1986,13 +2032,13 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // shift every per-slot base so that blockIdx.y/z == 0 addresses slot0
     P.frames = D.frames + slot0; P.seeds = D.seeds + (size_t)slot0 * D.nseeds; P.seedsTmp = D.seedsTmp + (size_t)slot0 * D.nseeds;
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
-    P.tex = D.tex + (size_t)slot0 * D.npx; P.fuseRec = D.fuseRec + (size_t)slot0 * D.nseeds * 3;
-    P.index = D.index + (size_t)slot0 * D.npx; P.amap = D.amap + (size_t)slot0 * D.npx; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
-    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.npx; P.wl = D.wl + (size_t)slot0 * D.npx; P.wlCount = D.wlCount + slot0;
+    P.tex = D.tex + (size_t)slot0 * D.pxStride; P.fuseRec = D.fuseRec + (size_t)slot0 * D.nseeds * 3;
+    P.index = D.index + (size_t)slot0 * D.pxStride; P.amap = D.amap + (size_t)slot0 * D.pxStride; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
+    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.pxStride; P.wl = D.wl + (size_t)slot0 * D.pxStride; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 seedGrid((D.nseeds + 255) / 256, un);
-    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid((D.npx / 8 + 255) / 256, n));
+    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid(((D.npx + 7) / 8 + 255) / 256, n));
     LAUNCH(SK_SEED_INIT, sp, kb_seed_init, seedGrid, dim3(256), P);
     for (int it = 0; it < 3; it++) {
         LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
@@ -2007,13 +2053,19 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             h->prof.end(sp);
             LAUNCH(SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
         }
-        LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
+        if ((W % SP) >= 1 && (W % SP) <= 3) LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds<true>, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
+        else LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         LAUNCH(SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
     // 1 KB of (unused) dynamic LDS caps the kernel at 10 waves per CU: with 11 only 2.9 KB of LDS stay free and the
     // latency-critical map-stage workgroups (3.3 and 4.1 KB) wait for a wave to retire before they can start
     constexpr unsigned planePad = 1024;
-    LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
+    if ((W % SP) >= 1 && (W % SP) <= 3) LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane<true>, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
+    else LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane<false>, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
+    if ((W % SP) || (H % SP)) {   // pixels outside the whole cells (sizes that are not multiples of 8)
+        const int nStrip = (W - D.spW * SP) * D.spH * SP + W * (H - D.spH * SP);
+        hipLaunchKernelGGL(kb_tex_strips, dim3((unsigned)((nStrip + 255) / 256), un), dim3(256), 0, sp, P);
+    }
     if (sp != sm) {
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
@@ -2052,15 +2104,16 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
 extern "C" {
 
 msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy, float fuseFar, float fuseNear, int device) {
-    if (width < 16 || height < 16 || (width % SP) || (height % SP) || fx == 0 || fy == 0 || (width / SP) * (height / SP) >= IDX_PLANE) {
-        set_error("msl_sf_create: width/height must be multiples of 8 (>= 16, < 65534 superpixels) and fx, fy non-zero");
+    if (width < 16 || height < 16 || fx == 0 || fy == 0 || (width / SP) * (height / SP) >= IDX_PLANE || (long long)width * height >= (1ll << 31)) {
+        set_error("msl_sf_create: width/height must be >= 16 with fewer than 65534 superpixels, fx and fy non-zero");
         return nullptr;
     }
     if (bind_device(device) != MSL_OK) return nullptr;
     msl_sf *h = new msl_sf;
     h->device = device;
     SfDev &D = h->dev;
-    D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;
+    D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;   // spWidth = width / SP_SIZE: truncation (:29-38)
+    D.pxStride = (D.npx + 63) & ~63;
     D.fx = fx; D.fy = fy; D.cx = cx; D.cy = cy; D.fuseFar = fuseFar; D.fuseNear = fuseNear;
     bool ok = true;
     {   // the per-keyframe map stage is the latency-critical chain: highest priority for its stream, lowest for the
@@ -2466,7 +2519,7 @@ int msl_sf_debug_index(msl_sf *h, int32_t *out) {
     if (rc != MSL_OK) return rc;
     const size_t npx = h->dev.npx;
     std::vector<unsigned short> tmp(npx);
-    MSL_HIP_TRY(hipMemcpy(tmp.data(), h->d_index + npx * h->lastSlot, sizeof(unsigned short) * npx, hipMemcpyDeviceToHost));
+    MSL_HIP_TRY(hipMemcpy(tmp.data(), h->d_index + (size_t)h->dev.pxStride * h->lastSlot, sizeof(unsigned short) * npx, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < npx; i++) out[i] = tmp[i];
     return MSL_OK;
 }

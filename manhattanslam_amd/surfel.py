@@ -129,8 +129,9 @@ class SurfelFusion:
         refs = np.ascontiguousarray(refs, np.int32)
         poses = np.ascontiguousarray(np.stack([_pose16(p) for p in poses]), np.float32)
         w, h = self.width, self.height
+        mw, mh = (w + 1) // 2, (h + 1) // 2      # the membership image is ceil(h / 2) x ceil(w / 2) (PlaneDetection's cloud size)
         check(lib.msl_sf_fuse_resident_batch(self._h, n, ptr(refs), ptr(grays), w, k * w * h, ptr(depths), 4 * w, 4 * k * w * h, ptr(members),
-                                             4 * (w // 2), 0 if member_shared else 4 * km * (w // 2) * (h // 2),
+                                             4 * mw, 0 if member_shared else 4 * km * mw * mh,
                                              MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch")
 
     def counters(self):

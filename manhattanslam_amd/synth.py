@@ -127,7 +127,7 @@ def surfel_frame(k, w=640, h=480, intr=TUM1, variant="A", seed=7, dropout=0.02):
     b = np.where(axis == 2, hit[:, :, 1], hit[:, :, 2])
     chk = (np.floor(a / 0.25).astype(np.int64) + np.floor(b / 0.25).astype(np.int64)) & 1
     gray = np.where(chk == 1, 180, 60) + rng.integers(-4, 5, size=t.shape)
-    member = np.full((h // 2, w // 2), -1, np.int32)
+    member = np.full(((h + 1) // 2, (w + 1) // 2), -1, np.int32)
     if variant == "B":
         s = w / 640.0
         for pid, (x0, y0, x1, y1) in enumerate(((20, 20, 90, 70), (130, 100, 210, 160), (240, 30, 300, 220))):

@@ -255,7 +255,7 @@ struct Fusion {
                             if (d > 0.1) { depthVector.push_back(d); sumDepth += d; sumDepthNum = (float)(sumDepthNum + 1.0); }
                         }
                     }
-                // `return`: ends this thread's chunk.  Unreachable for a used seed when width and height are multiples of 8: the pixel at the
+                // `return`: ends this thread's chunk.  Unreachable for a used seed (any image size): the pixel at the
                 // seed's lattice centre (8 spX + 4, 8 spY + 4) is free (that is what `use` means, :541-545), its ONLY candidate in
                 // updatePixels is this seed (|8 c + 4 - x| < 8 holds for c = spX alone when x mod 8 == 4, :384-389), pass 0 assigns it
                 // with cost 0 < 1e6 whatever intensity / depth are, no later pass can move it, and it lies inside the clipped window

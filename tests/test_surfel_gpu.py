@@ -593,3 +593,34 @@ def test_map_outgrows_the_fuse_grid_inside_one_call(oracle):
     assert len(mo) > 2 * g.nseeds + 8192, len(mo)      # well beyond the grid of the call's later launches
     assert_surfels_close(g.map_download(), mo, "map grown past the fuse grid inside one call")
     g.close()
+
+
+@pytest.mark.parametrize("w,h", [(324, 244), (322, 246), (333, 251), (330, 243), (641, 479)])
+def test_sizes_that_are_not_multiples_of_eight(oracle, w, h):
+    """The reference truncates (spWidth = width / SP_SIZE, src/SurfelFusion.cpp:29-38): the strips right of / below the last whole cell belong
+    to no superpixel cell but take part in updatePixels, the seed windows (flat-index wrap-around included) and the fusion.  Odd sizes, widths
+    with W mod 4 in {1, 2, 3} (window quads that straddle the right edge) and both execution modes against the oracle."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    intr = synth.scaled_intrinsics(synth.TUM1, w)
+    g, o = _mk(intr, w, h)
+    assert g.nseeds == (w // 8) * (h // 8)
+    local = synth.surfel_map(20000, ref=3).astype(SURFEL_DTYPE)
+    frames = [synth.surfel_frame(3 + k, w=w, h=h, intr=intr, variant="B") for k in range(3)]
+    gray, depth, member, pose = frames[0]
+    assert member.shape == ((h + 1) // 2, (w + 1) // 2)
+    lo, no = o.fuse(3, gray, depth, member, pose, local)
+    lg = local.copy()
+    ng = g.fuseInitializeMap(3, gray, depth, member, pose, lg)
+    assert np.array_equal(g.debug_index(), o.index())
+    assert_seeds_close(g.debug_seeds(), o.seeds())
+    assert_surfels_close(lg, lo, "local")
+    assert_surfels_close(ng, no, "new")
+    assert len(ng) > 20 and (lg["lastUpdate"] == 3).sum() > 100
+    # resident, batched
+    g.map_upload(local); o.map_set(local)
+    g.set_batch_capacity(3)
+    g.fuse_resident_batch([3, 4, 5], np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]), [f[3] for f in frames])
+    for k, f in enumerate(frames):
+        o.fuse_map(3 + k, f[0], f[1], f[2], f[3])
+    assert_surfels_close(g.map_download(), o.map_get(), "resident map")
+    g.close()
