@@ -49,10 +49,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8
 SURFEL_BYTES = 56              # sizeof(Surfel), reference include/Surfel.h:28-37
 
 CONFIGS = {
-    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=12,
+    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=13,
                      name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
     "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, passes=48, name="BASELINE config 2: ORBextractor only"),
-    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=12, name="BASELINE config 3: SurfelFusion only"),
+    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=15, name="BASELINE config 3: SurfelFusion only"),
     "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_pass=512, passes=7,
               name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + PEAC plane extractor and SurfelFusion every k-th "
                    "frame (block fit and agglomerative clustering on the GPU, erosion / region growing on host threads; its membership "
@@ -75,7 +75,7 @@ def parse(argv=None):
                     "is put back at the start of every pass.  0 = the configuration's default (256; config 4: 512, because the plane extractor clusters "
                     "one keyframe per wave and is latency-bound per call, so its throughput grows with the keyframes handed over at once)")
     ap.add_argument("--passes-per-step", type=int, default=0, help="passes one step makes over the batch; 0 = the configuration's default, chosen so that "
-                    "the default 20 steps time about 3 s (frontend: 12 x 256 = 3072 frames per step)")
+                    "the default 20 steps time at least 3 s (frontend: 13 x 256 = 3328 frames per step)")
     ap.add_argument("--no-reseed", action="store_true", help="free-running sequence of rounds 1-2: never put the map back (not stationary)")
     ap.add_argument("--batch", type=int, default=32, help="frames per library call; a pass issues frames-per-pass / batch calls.  The scratch of "
                     "2 x batch keyframe slots plus the map should stay inside the 256 MB Infinity Cache: 128-frame batches measured 35 %% slower")

@@ -957,6 +957,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
         unsigned mask = 0;
         if (active) {
+#pragma unroll 1   // (not unrolled: 128 instead of 130 VGPRs = 3 x 128 per SIMD, which leaves room for two 64-register k_fuse waves instead of one)
             for (int t = 0; t < tRounds; t++) {   // (a wave-uniform bound: the longest inlier list of the four seeds, typically 4-6 of the 16 rounds)
                 const int o = l + 16 * t;
                 if (o < ninl) {
@@ -980,6 +981,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         if (__ballot(diffGroups != 0)) {
             double H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
             if (active && diffGroups) {
+#pragma unroll 1
                 for (int t = 0; t < tRounds; t++)
                     if (mask & (1u << t)) {
                         const int o = l + 16 * t;
