@@ -27,7 +27,4 @@ for _ in range(16): step()
 sf.sync()
 dt = time.perf_counter() - t0
 ms, nl = sf.profile_read()["k_fuse"]
-c = sf.debug_ctr()
-if c[9]:
-    print("tail stamps (cycles, 100 MHz? see s_memtime):", [int(c[9 + k] - c[9]) for k in range(1, 6)])
 print(json.dumps({"lib": os.environ.get("MSL_LIB", "default"), "keyframes_per_s": round(16 * F / dt, 1), "k_fuse_us": round(ms * 1e3 / nl, 2), "ctr": sf.counters()}))
