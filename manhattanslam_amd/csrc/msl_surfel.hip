@@ -2059,9 +2059,11 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         else LAUNCH(SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((D.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         LAUNCH(SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    // 1 KB of (unused) dynamic LDS caps the kernel at 10 waves per CU: with 11 only 2.9 KB of LDS stay free and the
-    // latency-critical map-stage workgroups (3.3 and 4.1 KB) wait for a wave to retire before they can start
-    constexpr unsigned planePad = 1024;
+    // 4 KB of (unused) dynamic LDS cap the kernel at 8 waves per CU (it could run 11).  Measured on the whole front end (round 3, same box,
+    // alternating runs): 11 waves 19.6 k frames/s, 10 waves 20.6-20.9 k, 9 waves 21.0-21.1 k, 8 waves 21.3-21.5 k, 7 waves 20.3-20.9 k -- the
+    // kernel alone is no slower with fewer waves (its waves are VALU-latency bound), and the wave slots, registers and LDS it leaves go to the
+    // ORB kernels and to the map stage's k_fuse / k_compact (3.3 KB LDS) that run beside it.
+    constexpr unsigned planePad = 4096;
     if ((W % SP) >= 1 && (W % SP) <= 3) LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane<true>, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     else LAUNCH_LDS(SK_SEED_PLANE, sp, kb_seed_plane<false>, dim3(xcd_grid(((D.spW + 1) / 2) * ((D.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     if ((W % SP) || (H % SP)) {   // pixels outside the whole cells (sizes that are not multiples of 8)
