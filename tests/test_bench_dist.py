@@ -91,3 +91,20 @@ def test_bench_eight_ranks_bind_distinct_devices_and_sequences():
     frames = sum(c[0] for c in line["counters_per_rank"])
     assert frames == 8 * 2 * line["config"]["frames_per_pass"] * line["config"]["passes_per_step"]
     assert line["value"] == round(frames / 0.045, 1)               # rank 7 is the slowest fabricated rank: 10 + 5 * 7 ms
+
+
+def test_pmc_traffic_is_quoted_only_for_the_profiled_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed PMC summary only while the kernel sources still hash to the value stored in it."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    got, src = bench.pmc_traffic("k_fuse", "frontend")
+    doc = json.load(open(os.path.join(ROOT, "profiles", open(os.path.join(ROOT, "profiles", "current.txt")).read().strip() + "_summary.json")))
+    if doc["_meta"]["kernel_source_hash"] == bench.kernel_source_hash():
+        assert got == doc["k_fuse"]["fetch_bytes_corrected"] + doc["k_fuse"]["write_bytes"] and src.endswith("_summary.json")
+    else:
+        assert got is None and "hash mismatch" in src
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda: "0" * 16)
+    got, src = bench.pmc_traffic("k_fuse", "frontend")
+    assert got is None and "hash mismatch" in src
+    assert bench.pmc_traffic("k_fuse", "9")[0] is None          # no summary for that configuration
