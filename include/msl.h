@@ -388,6 +388,10 @@ MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
 MSL_API int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us);
 MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words);
 
+/* Test hook (host only): mse_out[i] = the MSE ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183) reports for stats[i], evaluated by the
+ * scalar code (lanes = 0) or by the clustering's lock-step SIMD form with `lanes` (2, 4, 8, 16) candidates per group; MSL_ERR_INVALID if the CPU
+ * lacks the instruction set that width is built for (4 and 8: AVX2, 16: AVX-512F). */
+MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out);
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);
 

@@ -16,8 +16,9 @@
 //                   plane for each neighbour of the popped node (one per lane); binary heap and disjoint set in LDS, neighbour sets as a bit matrix.
 //   Host: graph initialisation (AHCPlaneFitter.hpp:756-928; needs cos()), then -- after the device clustering -- block erosion + seeds (:490-596), the
 //   FIFO region growing (:422-471), final merge and relabelling (:296-372): order-dependent pixel work, one frame per worker thread at a time, index based
-//   (node pool + sorted adjacency vectors instead of shared_ptr / std::set<PlaneSeg*>).  The host also keeps the whole clustering (cluster()) for frames
-//   whose node data does not fit the LDS, for MSL_PEAC_CLUSTER=host, and for msl_peac_membership_from_blocks (no device).
+//   (node pool + sorted adjacency vectors instead of shared_ptr / std::set<PlaneSeg*>).  The host also keeps the whole clustering (cluster()): it is the
+//   path of small calls -- a single frame, the reference's call pattern, in ~2 ms: the candidate merges of a pop are fitted 16 at a time in SIMD lanes
+//   (plane_mse_lanes) -- of frames whose node data does not fit the LDS, of MSL_PEAC_CLUSTER=host, and of msl_peac_membership_from_blocks (no device).
 //
 // The membership image keeps every quirk a consumer can observe: rid2plid[] default-inserts plane 0 for an
 // unknown set id, pixels whose plane was eroded keep their old id, rejected pixels keep their visit counters -2..-6.
@@ -520,6 +521,157 @@ struct Thresholds {
     }
 };
 
+// ---- the MSE of several candidate merges at once (host SIMD) ------------------------------------------------------------------------------
+// ahCluster fits a plane to every neighbour's merged statistics before it picks one (AHCPlaneFitter.hpp:985-1010): for a frame that is ~30 000
+// 3x3 eigenvalue problems, all but ~1 500 of them discarded, and the whole latency of a single-frame call.  The lanes below run plane_mse() for
+// VW candidates in lock-step: every lane performs exactly the scalar sequence of IEEE double operations of eig33sym_t<false> (same expressions,
+// same association, no contraction; divisions and square roots are correctly rounded in either form), branches become selects, and a lane whose
+// QR iteration has finished is masked, so the result is the scalar result bit for bit (tests/test_peac_host.py compares both on random and
+// degenerate matrices, and the whole segmentation against the oracle with every width).
+template <int VW> struct Lanes {
+    typedef double D __attribute__((ext_vector_type(VW)));
+    typedef long M __attribute__((ext_vector_type(VW)));   // comparison results: all ones / zero per lane
+};
+#define MSL_SEL(m, a, b) ((m) ? (a) : (b))
+
+// in: 10 rows of VW doubles (sx sy sz sxx syy szz sxy syz sxz N); out: VW MSEs
+template <int VW>
+__attribute__((always_inline)) inline void plane_mse_lanes(const double *in, double *out) {
+    typedef typename Lanes<VW>::D D;
+    typedef typename Lanes<VW>::M M;
+    D r[10];
+    for (int i = 0; i < 10; i++) __builtin_memcpy(&r[i], in + (size_t)i * VW, sizeof(D));
+    const D zero = 0.0, one = 1.0;
+    const M izero = 0, ione = 1, itwo = 2;
+    const D sc = one / r[9];
+    D a00 = r[3] - r[0] * r[0] * sc, a10 = r[6] - r[0] * r[1] * sc, a20 = r[8] - r[0] * r[2] * sc;
+    D a11 = r[4] - r[1] * r[1] * sc, a21 = r[7] - r[1] * r[2] * sc, a22 = r[5] - r[2] * r[2] * sc;
+    auto vabs = [](D v) { return __builtin_elementwise_abs(v); };
+    auto vmax = [](D a, D b) { return __builtin_elementwise_max(a, b); };   // fmax: a NaN operand is ignored
+    auto vsqrt = [](D v) { return __builtin_elementwise_sqrt(v); };
+    D scale = vmax(vmax(vmax(vabs(a00), vabs(a10)), vmax(vabs(a11), vabs(a20))), vmax(vabs(a21), vabs(a22)));
+    scale = MSL_SEL(scale == zero, one, scale);
+    a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
+    const D tiny = 2.2250738585072014e-308, precision = 2.0 * 2.220446049250313e-16;
+    const D v1norm2 = a20 * a20;
+    const M small = v1norm2 <= tiny;
+    const D beta = vsqrt(a10 * a10 + v1norm2), invBeta = one / beta, m01 = a10 * invBeta, m02 = a20 * invBeta;
+    const D qq = (D)2.0 * m01 * a21 + m02 * (a22 - a11);
+    D dg0 = a00, dg1 = MSL_SEL(small, a11, a11 + m02 * qq), dg2 = MSL_SEL(small, a22, a22 - m02 * qq);
+    D sb0 = MSL_SEL(small, a10, beta), sb1 = MSL_SEL(small, a21, a21 - m01 * qq);
+    M end = itwo, start = izero, iter = izero, active = ~izero;
+    // Givens rotation that annihilates z against x: the three scalar cases share one division, one square root and one reciprocal
+    auto givens = [&](D x, D z, D &c, D &sn) {
+        const M big = vabs(x) > vabs(z);
+        const D num = MSL_SEL(big, z, x), den = MSL_SEL(big, x, z);
+        const D t = num / den;
+        D u = vsqrt(one + t * t);
+        u = MSL_SEL(den < zero, -u, u);
+        const D rr = MSL_SEL(big, one, -one) / u, oo = -t * rr;   // |x| > |z|: c = 1 / u, sn = -t c; otherwise sn = -1 / u, c = -t sn
+        c = MSL_SEL(big, rr, oo); sn = MSL_SEL(big, oo, rr);
+        const M x0 = x == zero;
+        c = MSL_SEL(x0, zero, c); sn = MSL_SEL(x0, MSL_SEL(z < zero, one, -one), sn);
+    };
+    for (;;) {
+        const M c0 = active & (start <= izero) & (end > izero) & ((vabs(sb0) <= (vabs(dg0) + vabs(dg1)) * precision) | (vabs(sb0) <= tiny));
+        sb0 = MSL_SEL(c0, zero, sb0);
+        const M c1 = active & (start <= ione) & (end > ione) & ((vabs(sb1) <= (vabs(dg1) + vabs(dg2)) * precision) | (vabs(sb1) <= tiny));
+        sb1 = MSL_SEL(c1, zero, sb1);
+        end = MSL_SEL(active & (end == itwo) & (sb1 == zero), ione, end);
+        end = MSL_SEL(active & (end == ione) & (sb0 == zero), izero, end);
+        active &= end > izero;
+        iter = MSL_SEL(active, iter + ione, iter);
+        active &= ~(iter > (M)90);
+        if (!__builtin_reduce_or(active)) break;
+        start = end - ione;
+        start = MSL_SEL((start == ione) & (sb0 != zero), izero, start);
+        const M e2m = end == itwo;
+        const D dEnd = MSL_SEL(e2m, dg2, dg1), dEm1 = MSL_SEL(e2m, dg1, dg0), e = MSL_SEL(e2m, sb1, sb0);
+        const D td = (dEm1 - dEnd) * (D)0.5;
+        const D ax = vabs(td), ay = vabs(e);
+        const M gt = ax > ay;
+        const D pp = MSL_SEL(gt, ax, ay), qp = MSL_SEL(gt, ay, ax) / pp;
+        const D h = MSL_SEL(pp == zero, zero, pp * vsqrt(one + qp * qp));
+        const D e2 = e * e, denom = td + MSL_SEL(td > zero, h, -h);
+        const D muA = dEnd - vabs(e), muC = dEnd - e2 / denom;
+        D mu = MSL_SEL(td == zero, muA, MSL_SEL(e != zero, muC, dEnd));
+        const M under = active & (td != zero) & (e != zero) & (e2 == zero);   // e * e underflowed: the scalar code divides twice instead
+        if (__builtin_reduce_or(under)) mu = MSL_SEL(under, dEnd - e / (denom / e), mu);
+        const M s0 = start == izero;
+        D x = MSL_SEL(s0, dg0, dg1) - mu, z = MSL_SEL(s0, sb0, sb1);
+        const M doK0 = active & s0 & (z != zero);
+        if (__builtin_reduce_or(doK0)) {   // k = 0
+            const M doK = doK0;
+            D c, sn;
+            givens(x, z, c, sn);
+            const D sdk = sn * dg0 + c * sb0, dkp1 = sn * sb0 + c * dg1;
+            const D n0 = c * (c * dg0 - sn * sb0) - sn * (c * sb0 - sn * dg1), n1 = sn * sdk + c * dkp1, nsb = c * sdk - sn * dkp1;
+            dg0 = MSL_SEL(doK, n0, dg0); dg1 = MSL_SEL(doK, n1, dg1); sb0 = MSL_SEL(doK, nsb, sb0);
+            x = MSL_SEL(doK, nsb, x);
+            const M more = doK & e2m;                      // k < end - 1
+            const D nz = -sn * sb1, nsb1 = c * sb1;
+            // a lane that ran k = 0 with end == 1 has left the scalar loop: end > 1 below keeps it out of k = 1
+            z = MSL_SEL(more, nz, z); sb1 = MSL_SEL(more, nsb1, sb1);
+        }
+        const M doK1 = active & e2m & (z != zero);
+        if (__builtin_reduce_or(doK1)) {   // k = 1 (a lane that skipped k = 0 at start == 0 did so with z == 0, which also ends its loop here)
+            const M doK = doK1;
+            D c, sn;
+            givens(x, z, c, sn);
+            const D sdk = sn * dg1 + c * sb1, dkp1 = sn * sb1 + c * dg2;
+            const D n1 = c * (c * dg1 - sn * sb1) - sn * (c * sb1 - sn * dg2), n2 = sn * sdk + c * dkp1, nsb = c * sdk - sn * dkp1;
+            sb0 = MSL_SEL(doK & s0, c * sb0 - sn * z, sb0);    // k > start
+            dg1 = MSL_SEL(doK, n1, dg1); dg2 = MSL_SEL(doK, n2, dg2); sb1 = MSL_SEL(doK, nsb, sb1);
+        }
+    }
+    const D lo01 = MSL_SEL(dg1 < dg0, dg1, dg0), lo = MSL_SEL(dg2 < lo01, dg2, lo01);   // s[0] of the selection sort
+    const D mse = lo * scale * sc;
+    __builtin_memcpy(out, &mse, sizeof(D));
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MSL_TARGET(t)
+inline int host_simd_level() { return 2; }
+#else
+#define MSL_TARGET(t) __attribute__((target(t)))
+// instruction set the lanes may use: 8 = AVX-512F, 4 = AVX2, 2 = the x86-64 baseline (SSE2), 0 = the scalar code; MSL_PEAC_SIMD lowers it
+inline int host_simd_level() {
+    static const int w = [] {
+        int best = __builtin_cpu_supports("avx512f") ? 8 : __builtin_cpu_supports("avx2") ? 4 : 2;
+        if (const char *e = getenv("MSL_PEAC_SIMD")) { const int v = atoi(e); if (v == 0 || v == 2 || v == 4 || v == 8) best = std::min(best, v); }
+        return best;
+    }();
+    return w;
+}
+#endif
+inline int host_lane_cap() {   // MSL_PEAC_LANES = 2 / 4 / 8 / 16 caps the candidates per group (tests run every width)
+    static const int c = [] { const char *e = getenv("MSL_PEAC_LANES"); const int v = e ? atoi(e) : 16; return v == 2 || v == 4 || v == 8 ? v : 16; }();
+    return c;
+}
+// The solver is a single dependent chain of divisions and square roots, so a group twice as wide as the registers (two independent chains the
+// core interleaves) costs little more than one register's worth: 16 lanes on AVX-512, 8 on AVX2.
+void plane_mse_x2(const double *in, double *out) { plane_mse_lanes<2>(in, out); }
+MSL_TARGET("avx2") void plane_mse_x4(const double *in, double *out) { plane_mse_lanes<4>(in, out); }
+MSL_TARGET("avx2") void plane_mse_x8_avx2(const double *in, double *out) { plane_mse_lanes<8>(in, out); }
+MSL_TARGET("avx512f") void plane_mse_x8(const double *in, double *out) { plane_mse_lanes<8>(in, out); }
+MSL_TARGET("avx512f") void plane_mse_x16(const double *in, double *out) { plane_mse_lanes<16>(in, out); }
+// lanes for a group when `left` candidates remain (0: scalar)
+inline int lanes_for(size_t left) {
+    const int simd = host_simd_level(), cap = host_lane_cap();
+    if (left < 2 || simd == 0) return 0;
+    int vw = 2;
+    if (simd >= 4 && left > 2) vw = 4;
+    if (simd >= 4 && left > 4) vw = 8;
+    if (simd >= 8 && left > 8) vw = 16;
+    return std::min(vw, cap);
+}
+inline void plane_mse_group(int vw, const double *in, double *out) {
+    if (vw == 16) plane_mse_x16(in, out);
+    else if (vw == 8) { if (host_simd_level() >= 8) plane_mse_x8(in, out); else plane_mse_x8_avx2(in, out); }
+    else if (vw == 4) plane_mse_x4(in, out);
+    else plane_mse_x2(in, out);
+}
+
 struct Node {
     msl_peac_stats st;
     double center[3], normal[3], mse, curvature;
@@ -704,6 +856,30 @@ private:
         t.sxy = x.sxy + y.sxy; t.syz = x.syz + y.syz; t.sxz = x.sxz + y.sxz; t.N = x.N + y.N; t.nouse = 0;
         return plane_mse(t);
     }
+    // candMse_[i] = merged_mse(p, cand_[i]), the candidates taken VW at a time (a short last group is padded with its first candidate)
+    std::vector<int> cand_;
+    std::vector<double> candMse_;
+    void candidate_mses(int p) {
+        const size_t n = cand_.size();
+        candMse_.resize(n);
+        const msl_peac_stats &x = nodes_[p].st;
+        alignas(64) double in[10 * 16], out[16];
+        for (size_t i0 = 0; i0 < n;) {
+            const size_t left = n - i0;
+            const int vw = lanes_for(left);
+            if (vw == 0) { candMse_[i0] = merged_mse(p, cand_[i0]); ++i0; continue; }
+            for (int l = 0; l < vw; l++) {
+                const msl_peac_stats &y = nodes_[cand_[i0 + ((size_t)l < left ? l : 0)]].st;
+                in[0 * vw + l] = x.sx + y.sx; in[1 * vw + l] = x.sy + y.sy; in[2 * vw + l] = x.sz + y.sz;
+                in[3 * vw + l] = x.sxx + y.sxx; in[4 * vw + l] = x.syy + y.syy; in[5 * vw + l] = x.szz + y.szz;
+                in[6 * vw + l] = x.sxy + y.sxy; in[7 * vw + l] = x.syz + y.syz; in[8 * vw + l] = x.sxz + y.sxz;
+                in[9 * vw + l] = (double)(x.N + y.N);
+            }
+            plane_mse_group(vw, in, out);
+            for (int l = 0; l < vw && (size_t)l < left; l++) candMse_[i0 + l] = out[l];
+            i0 += vw;
+        }
+    }
     Node merged_node(int a, int b) const {   // PlaneSeg(pa, pb) (AHCPlaneSeg.hpp:299-322)
         Node nd;
         const msl_peac_stats &x = nodes_[a].st, &y = nodes_[b].st;
@@ -726,9 +902,13 @@ private:
             bool have = false;
             double bestMse = 0;
             int bestN = 0, bestNb = -1;
-            for (int nb : nodes_[p].nbs) {
-                if (similarity(nodes_[p], nodes_[nb]) < T.p.similarity_th_merge) continue;
-                const double mse = merged_mse(p, nb);
+            cand_.clear();
+            for (int nb : nodes_[p].nbs)
+                if (!(similarity(nodes_[p], nodes_[nb]) < T.p.similarity_th_merge)) cand_.push_back(nb);
+            candidate_mses(p);
+            for (size_t ci = 0; ci < cand_.size(); ci++) {
+                const int nb = cand_[ci];
+                const double mse = candMse_[ci];
                 if (!have || bestMse > mse || (bestMse == mse && bestN < mse)) { bestMse = mse; bestN = nodes_[p].st.N + nodes_[nb].st.N; bestNb = nb; have = true; }   // (sic: N against mse, :1005)
             }
             Node best;
@@ -1204,11 +1384,12 @@ int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes
         const int maxN = 2 * (int)nBlocks, words = (maxN + 31) / 32;
         maxPl = (int)std::min<size_t>(nBlocks, 256);
         const size_t ldsBytes = (size_t)maxN * (6 * sizeof(double) + 4 * sizeof(int) + 1) + 2 * nBlocks * sizeof(int) + 64;
-        // auto: the device clusters any number of frames in the time of one (~13-20 ms, one latency-bound wave per frame), a host worker needs ~6-7 ms
-        // per frame: the device wins once a call holds more than about three frames per usable CPU.
+        // auto: the device clusters any number of frames in the time of one (~13-20 ms, one latency-bound wave per frame), a host worker needs ~2 ms
+        // per frame (candidate merges evaluated 16 at a time, plane_mse_lanes): the device wins once a call holds more than about eight frames per
+        // usable CPU (measured: 64 frames on 16 workers, host 25.5 k frames/s of configuration 4 against 22.9 k with the device clustering).
         const char *mode = getenv("MSL_PEAC_CLUSTER");
         const bool forceHost = mode && !strcmp(mode, "host"), forceDev = mode && !strcmp(mode, "device");
-        const bool wantDevice = forceDev || (!forceHost && n_frames > 3 * SegPool::get().workers());
+        const bool wantDevice = forceDev || (!forceHost && n_frames > 8 * SegPool::get().workers());
         if (ldsBytes <= 150 * 1024 && wantDevice) {
             Scratch &sc = g_scratch[device & 15];
             const int maxE = 4 * (int)nBlocks;
@@ -1321,6 +1502,25 @@ int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t
                                     const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
     return msl_peac_extract_from_blocks(blocks, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, fx, fy, cx, cy, depth_map_factor, params,
                                         membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
+}
+
+int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) {
+    if (n == 0) return MSL_OK;
+    const int level = host_simd_level();
+    if (!stats || !mse_out || !(lanes == 0 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16)) { set_error("msl_debug_peac_mse: invalid argument"); return MSL_ERR_INVALID; }
+    if ((lanes == 16 && level < 8) || (lanes >= 4 && level < 4) || (lanes >= 2 && level < 2)) { set_error("msl_debug_peac_mse: %d lanes need a wider instruction set than this CPU (or MSL_PEAC_SIMD) allows", lanes); return MSL_ERR_INVALID; }
+    if (lanes == 0) { for (size_t i = 0; i < n; i++) mse_out[i] = plane_mse(stats[i]); return MSL_OK; }
+    alignas(64) double in[10 * 16], out[16];
+    for (size_t i0 = 0; i0 < n; i0 += lanes) {
+        for (int l = 0; l < lanes; l++) {
+            const msl_peac_stats &y = stats[i0 + l < n ? i0 + l : i0];
+            const double v[10] = {y.sx, y.sy, y.sz, y.sxx, y.syy, y.szz, y.sxy, y.syz, y.sxz, (double)y.N};
+            for (int k = 0; k < 10; k++) in[k * lanes + l] = v[k];
+        }
+        plane_mse_group(lanes, in, out);
+        for (int l = 0; l < lanes && i0 + l < n; l++) mse_out[i0 + l] = out[l];
+    }
+    return MSL_OK;
 }
 
 }  // extern "C"

@@ -188,3 +188,109 @@ def test_worker_budget_is_divided_among_local_ranks(oracle):
     w8, _ = workers(LOCAL_WORLD_SIZE="8")
     assert w1 == min(64, cpus) and w8 == max(1, cpus // 8)
     assert workers(LOCAL_WORLD_SIZE="8", MSL_PEAC_THREADS="3")[0] == 3
+
+
+def _stats_of_points(pts):
+    from manhattanslam_amd import PEAC_STATS_DTYPE
+    s = np.zeros((), PEAC_STATS_DTYPE)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    for name, v in (("sx", x), ("sy", y), ("sz", z), ("sxx", x * x), ("syy", y * y), ("szz", z * z), ("sxy", x * y), ("syz", y * z), ("sxz", x * z)):
+        s[name] = v.sum()
+    s["N"] = len(pts)
+    return s
+
+
+def _mse_cases():
+    """Merged-segment statistics of every kind the clustering meets, and the degenerate ones the eigen-solver branches on."""
+    from manhattanslam_amd import PEAC_STATS_DTYPE
+    rng = np.random.default_rng(20260927)
+    out = []
+    for i in range(600):   # noisy planes of all orientations, sizes and distances (the sums of one to a few hundred windows)
+        n = int(rng.integers(4, 30000))
+        nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+        a = np.cross(nrm, [1.0, 0, 0] if abs(nrm[0]) < 0.9 else [0, 1.0, 0]); a /= np.linalg.norm(a)
+        b = np.cross(nrm, a)
+        uv = rng.uniform(-1, 1, size=(min(n, 400), 2)) * rng.uniform(0.02, 3.0)
+        pts = rng.uniform(0.3, 8.0) * nrm + uv[:, :1] * a + uv[:, 1:] * b + rng.normal(size=(len(uv), 1)) * nrm * rng.choice([0.0, 1e-4, 3e-3, 0.05, 0.5])
+        s = _stats_of_points(pts)
+        if n > len(pts):   # scale the sums up: the same shape with more points
+            k = n // len(pts)
+            for name in s.dtype.names[:9]:
+                s[name] *= k
+            s["N"] = len(pts) * k
+        out.append(s)
+    for axis in range(3):   # exactly axis-aligned planes, lines and single points: zero sub-diagonals, the v1norm2 <= tiny branch, scale == 0
+        for kind in ("plane", "line", "point"):
+            pts = rng.uniform(-2, 2, size=(50, 3))
+            pts[:, axis] = 1.5
+            if kind != "plane":
+                pts[:, (axis + 1) % 3] = -0.25
+            if kind == "point":
+                pts[:] = pts[0]
+            out.append(_stats_of_points(pts))
+    for i in range(300):   # arbitrary symmetric sums: indefinite matrices, huge / tiny magnitudes, equal eigenvalues
+        s = np.zeros((), PEAC_STATS_DTYPE)
+        mag = 10.0 ** rng.integers(-160, 150)
+        for name in s.dtype.names[:9]:
+            s[name] = rng.normal() * mag * rng.choice([1.0, 1.0, 1e-8, 0.0])
+        s["N"] = int(rng.integers(1, 100000))
+        out.append(s)
+    for v in (0.0, 1.0, -3.0, 1e-300, 1e300):   # multiples of the identity (td == 0), and N = 0 (sc = inf: NaN everywhere)
+        s = np.zeros((), PEAC_STATS_DTYPE); s["sxx"] = s["syy"] = s["szz"] = v; s["N"] = 7
+        out.append(s)
+        s = s.copy(); s["sxy"] = v * 0.5; out.append(s)
+    z = np.zeros((), PEAC_STATS_DTYPE); z["sx"] = 1.0; z["sxx"] = 2.0
+    out.append(z)
+    return np.array(out, PEAC_STATS_DTYPE)
+
+
+def test_simd_candidate_mse_is_the_scalar_mse():
+    """The clustering evaluates candidate merges several at a time (lock-step lanes, branches as selects): every lane must give the bits the scalar
+    eigen-solver gives, whatever shares its group.  Runs on the CPU; widths the CPU cannot execute are skipped, 2 lanes (SSE2) always run."""
+    from manhattanslam_amd._lib import lib, ptr
+    st = _mse_cases()
+    want = np.zeros(len(st))
+    assert lib.msl_debug_peac_mse(ptr(st), len(st), 0, ptr(want)) == 0
+    assert np.isfinite(want).sum() > 800 and np.isnan(want).any()
+    ran = []
+    rng = np.random.default_rng(5)
+    for lanes in (2, 4, 8, 16):
+        got = np.full(len(st), -1.0)
+        if lib.msl_debug_peac_mse(ptr(st), len(st), lanes, ptr(got)) != 0:
+            continue
+        ran.append(lanes)
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (lanes, np.flatnonzero(~same)[:5], got[~same][:5], want[~same][:5])
+        perm = rng.permutation(len(st))   # other neighbours in the group: same values
+        got2 = np.full(len(st), -1.0)
+        assert lib.msl_debug_peac_mse(ptr(np.ascontiguousarray(st[perm])), len(st), lanes, ptr(got2)) == 0
+        w2 = want[perm]
+        assert ((got2.view(np.uint64) == w2.view(np.uint64)) | (np.isnan(got2) & np.isnan(w2))).all(), lanes
+    assert 2 in ran
+    assert lib.msl_debug_peac_mse(ptr(st), len(st), 3, ptr(want)) != 0
+
+
+def test_simd_width_does_not_change_the_segmentation(oracle):
+    """The whole host stage with the scalar solver (MSL_PEAC_SIMD=0) and with every group width gives the oracle's images."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from manhattanslam_amd import peac, synth\n"
+        "from tests import oracle_lib\n"
+        "from tests.test_peac_host import _scenes\n"
+        "I = synth.ICL; fac = np.float32(1 / 5000.0)\n"
+        "frames = _scenes(I)\n"
+        "ref = [oracle_lib.peac_run(d, I['fx'], I['fy'], I['cx'], I['cy'], fac) for d in frames]\n"
+        "m, n = peac.plane_membership_from_blocks(np.stack([r[2] for r in ref]), np.stack(frames), I['fx'], I['fy'], I['cx'], I['cy'], fac)\n"
+        "assert all(n[f] == ref[f][1] and np.array_equal(m[f], ref[f][0]) for f in range(len(frames)))\n"
+        "print('same as oracle')\n" % root)
+    for envs in ({"MSL_PEAC_SIMD": "0"}, {"MSL_PEAC_SIMD": "2"}, {"MSL_PEAC_LANES": "4"}, {"MSL_PEAC_LANES": "8"}, {"MSL_PEAC_SIMD": "4"}, {}):
+        env = dict(os.environ)
+        env.pop("MSL_PEAC_SIMD", None); env.pop("MSL_PEAC_LANES", None)
+        env.update(envs)
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "same as oracle" in r.stdout, (envs, r.stdout + r.stderr[-2000:])
