@@ -29,6 +29,7 @@ constexpr int ML = 12;          // max pyramid levels
 constexpr int MAXCELL = 64;     // max FAST cell extent (pixels)
 constexpr int MAXNODE = 1024;   // max quadtree list length per level
 constexpr int OCT_NT = 512;     // threads of the quadtree workgroup
+constexpr int OCT_NODE_BYTES = 66;   // k_octree's LDS per node slot
 
 struct LevelDev {
     int w, h, pitch;
@@ -75,6 +76,7 @@ struct OrbDev {
     msl_frame_params fp; float gridWInv, gridHInv;
     const float *depth; unsigned long long depthRowStride, depthFrameStride;   // bytes
     float *unXY, *depthOut, *uRight; int *gridCell;
+    int maxNode;   // k_octree: node-array length (dynamic LDS = OCT_NODE_BYTES * maxNode)
 };
 
 __constant__ int8_t c_pattern[1024] = {
@@ -312,15 +314,20 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 }
 
 __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
-    __shared__ Rect s_rect[2][MAXNODE];
-    __shared__ unsigned s_cnt[2][MAXNODE];
-    __shared__ short s_crank[2][MAXNODE];     // creation rank among the nodes recorded for careful mode, -1 = none
-    __shared__ unsigned s_cc[4 * MAXNODE];    // child key counts
-    __shared__ unsigned short s_F[4 * MAXNODE];  // scan of "child exists"
-    __shared__ unsigned short s_G[4 * MAXNODE];  // scan of "child expandable"
-    __shared__ unsigned short s_L[MAXNODE];      // scan of kept old nodes
-    __shared__ unsigned short s_order[MAXNODE];  // careful mode: sorted candidates
-    __shared__ unsigned short s_rankOf[MAXNODE]; // careful mode: node -> sorted rank (0xFFFF = not a candidate)
+    // Node arrays sized for THIS extractor's longest possible list (P.maxNode = max over levels of max(quota, 4 nIni) + 2, rounded up to 64; 66 bytes
+    // per node: 16.5 KB for 1000 features instead of a fixed 66 KB for MAXNODE = 1024), so that the frame-batched kernels of the other streams keep
+    // their LDS -- and with it their occupancy -- while this latency-bound kernel runs.
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    const int M = P.maxNode;
+    Rect *const s_rectB = reinterpret_cast<Rect *>(s_dyn);                         // [2][M]
+    unsigned *const s_cntB = reinterpret_cast<unsigned *>(s_rectB + 2 * M);        // [2][M]
+    unsigned *const s_cc = s_cntB + 2 * M;                                         // [4 M] child key counts
+    short *const s_crankB = reinterpret_cast<short *>(s_cc + 4 * M);               // [2][M] creation rank among the nodes recorded for careful mode, -1 = none
+    unsigned short *const s_F = reinterpret_cast<unsigned short *>(s_crankB + 2 * M);   // [4 M] scan of "child exists"
+    unsigned short *const s_G = s_F + 4 * M;                                       // [4 M] scan of "child expandable"
+    unsigned short *const s_L = s_G + 4 * M;                                       // [M] scan of kept old nodes
+    unsigned short *const s_order = s_L + M;                                       // [M] careful mode: sorted candidates
+    unsigned short *const s_rankOf = s_order + M;                                  // [M] careful mode: node -> sorted rank (0xFFFF = not a candidate)
     __shared__ unsigned s_wave[17];
     __shared__ int s_misc[8];
 
@@ -358,23 +365,23 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
     // ---- root nodes (:536-572) ----
     int cur = 0, S = 0;
     const int H = G.h - 32;
-    for (int i = tid; i < MAXNODE; i += OCT_NT) { s_cnt[0][i] = 0; s_crank[0][i] = -1; }
+    for (int i = tid; i < M; i += OCT_NT) { s_cntB[i] = 0; s_crankB[i] = -1; }
     __syncthreads();
     for (unsigned k = tid; k < n; k += OCT_NT) {
         const unsigned key = keys[k];
         const int ini = (int)((float)(key & 0xFFF) / G.hX);
-        atomicAdd(&s_cnt[0][ini], 1u);
+        atomicAdd(&s_cntB[ini], 1u);
         knode[k] = (uint16_t)ini;
     }
     __syncthreads();
     if (tid == 0) {
         int s = 0;
         for (int i = 0; i < G.nIni; i++) {
-            const unsigned c = s_cnt[0][i];
+            const unsigned c = s_cntB[i];
             s_L[i] = (unsigned short)s;
             if (c) {
                 Rect r; r.x0 = (short)(int)(G.hX * (float)i); r.x1 = (short)(int)(G.hX * (float)(i + 1)); r.y0 = 0; r.y1 = (short)H;
-                s_rect[1][s] = r; s_cnt[1][s] = c; s_crank[1][s] = -1;
+                s_rectB[M + s] = r; s_cntB[M + s] = c; s_crankB[M + s] = -1;
                 s++;
             }
         }
@@ -390,8 +397,8 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
     // ---- full rounds (:580-640) ----
     while (true) {
         const int prevS = S;
-        Rect *rect = s_rect[cur]; unsigned *cnt = s_cnt[cur];
-        Rect *nrect = s_rect[cur ^ 1]; unsigned *ncnt = s_cnt[cur ^ 1]; short *ncrank = s_crank[cur ^ 1];
+        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M);
+        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
         for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
         __syncthreads();
         for (unsigned k = tid; k < n; k += OCT_NT) {
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
         block_scan_array_incl(s_L, S, s_wave);
         const int Ctot = s_F[4 * S - 1], nToExpand = s_G[4 * S - 1], Ltot = s_L[S - 1];
         const int S2 = Ctot + Ltot;
-        if (S2 > MAXNODE) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
         for (int j = tid; j < 4 * S; j += OCT_NT) {
             const unsigned c = cnt[j >> 2] > 1 ? s_cc[j] : 0;
             if (c) {
@@ -447,8 +454,8 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
     // ---- careful mode (:641-700) ----
     while (careful) {
         const int prevS = S;
-        Rect *rect = s_rect[cur]; unsigned *cnt = s_cnt[cur]; short *crank = s_crank[cur];
-        Rect *nrect = s_rect[cur ^ 1]; unsigned *ncnt = s_cnt[cur ^ 1]; short *ncrank = s_crank[cur ^ 1];
+        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M); short *crank = (s_crankB + cur * M);
+        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
         for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
         for (int i = tid; i < S; i += OCT_NT) s_rankOf[i] = 0xFFFF;
         __syncthreads();
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
         block_scan_array_incl(s_L, S, s_wave);
         const int Ctot = s_F[4 * J - 1];
         const int S2 = Ctot + (S - J);
-        if (S2 > MAXNODE) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
         for (int jj = tid; jj < 4 * J; jj += OCT_NT) {
             const int i = s_order[jj >> 2];
             const unsigned c = s_cc[4 * i + (jj & 3)];
@@ -888,7 +895,7 @@ int build_geometry(msl_orb *h, int W, int H) {
     std::vector<ResizeTap> taps;
     size_t pyrOff = 0, blurOff = 0;
     unsigned keyOff = 0;
-    int tileBase = 0, maxQuota = 0;
+    int tileBase = 0, maxQuota = 0, maxList = 0;
     for (int l = 0; l < L; l++) {
         LevelDev &G = D.lv[l];
         const float s = h->invScale[l];
@@ -938,7 +945,10 @@ int build_geometry(msl_orb *h, int W, int H) {
         G.nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
         if (G.nIni < 1) { set_error("unsupported aspect ratio (nIni = 0)"); return MSL_ERR_INVALID; }
         G.hX = (float)(maxBX - minB) / G.nIni;
+        // longest quadtree list of this level: a full round only runs when its outcome stays <= quota (the first one makes <= 4 nIni nodes), the
+        // one-by-one phase stops at the first length >= quota and every expansion adds <= 3
         if (std::max(G.quota, 4 * G.nIni) + 2 > MAXNODE) { set_error("per-level quota %d exceeds %d", G.quota, MAXNODE - 2); return MSL_ERR_INVALID; }
+        maxList = std::max(maxList, std::max(G.quota, 4 * G.nIni) + 2);
         // blur tiles
         G.tilesX = (G.w + BT_W - 1) / BT_W; G.tilesY = (G.h + BT_H - 1) / BT_H;
         G.tileBase = tileBase; tileBase += G.tilesX * G.tilesY;
@@ -1019,6 +1029,9 @@ int build_geometry(msl_orb *h, int W, int H) {
     D.cellsPerFrame = (int)cells.size();
     D.keysPerFrame = (int)keyOff;
     D.selCap = maxQuota + 2;
+    D.maxNode = (maxList + 63) & ~63;
+    if ((size_t)OCT_NODE_BYTES * D.maxNode > 32 * 1024)   // (a large feature budget: more dynamic LDS than a launch gets by default)
+        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, OCT_NODE_BYTES * D.maxNode));
     D.outCap = h->nfeatures + 2 * L;
     D.blurTiles = tileBase;
     D.pyrStride = (pyrOff + 255) & ~(size_t)255;
@@ -1094,7 +1107,7 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     hipLaunchKernelGGL(k_fast, dim3(P.cellsPerFrame, n), dim3(256), 0, s, P);
     h->prof.end(s);
     h->prof.begin(KID_OCTREE, s);
-    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), 0, s, P);
+    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), (size_t)OCT_NODE_BYTES * P.maxNode, s, P);
     h->prof.end(s);
     h->prof.begin(KID_BLUR, s);
     hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);

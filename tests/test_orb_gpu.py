@@ -119,6 +119,20 @@ def test_other_sizes_and_params(oracle):
     ex.close()
 
 
+def test_feature_budgets_size_the_quadtree(oracle):
+    """The quadtree kernel's node arrays (dynamic LDS) follow the per-level feature budget: a large budget (more than the default dynamic LDS of a
+    launch), a budget below four root children, and the default give the oracle's keypoints; low thresholds so that the budgets are reached."""
+    from manhattanslam_amd import ORBextractor, synth
+    img = synth.orb_frame(77)
+    for nf, ini, mn in ((4000, 7, 5), (3000, 20, 7), (40, 20, 7), (24, 20, 7)):
+        ex = ORBextractor(nf, 1.2, 8, ini, mn)
+        ko, do = oracle.orb_create(nf, 1.2, 8, ini, mn).extract(img)
+        kg, dg = ex(img)
+        _assert_same(kg, dg, ko, do)
+        assert len(kg) > 0
+        ex.close()
+
+
 def test_device_resident_batch(oracle):
     """Asynchronous batch path with inputs and outputs resident in HBM (the bench.py path)."""
     import torch
