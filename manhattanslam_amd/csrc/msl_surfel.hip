@@ -81,6 +81,22 @@ struct FrameDev {
     __device__ __forceinline__ gptr<int32_t> memberG() const { return (gptr<int32_t>)member; }
 };
 
+// What the pixel pass needs of a seed, 32 bytes, so that a wave fetches a candidate with one scalar load (and the two candidates of a lattice row,
+// neighbours in memory, with a single 64-byte one): written wherever a seed's x / y / meanDepth / meanIntensity change.
+struct alignas(32) AssignRec {
+    float x, y, meanIntensity;
+    unsigned stable;               // the seed's stable flag as the next pixel pass finds it (t(s) == T_INF)
+    double invDepth;               // meanDepth > 0: 1.0 / (double)meanDepth, the value calculateCost's divide gives (:349) -- never negative;
+                                   // otherwise -1.0, i.e. the sign doubles as the seed's "has depth" test (:348) and the record needs no meanDepth
+    unsigned long long _pad;
+};
+__device__ __forceinline__ AssignRec assign_rec(const msl_seed &s) {
+    AssignRec a;
+    a.x = s.x; a.y = s.y; a.meanIntensity = s.meanIntensity; a.stable = s.stable ? 1u : 0u;
+    a.invDepth = s.meanDepth > 0 ? 1.0 / (double)s.meanDepth : -1.0; a._pad = 0;
+    return a;
+}
+
 struct SfDev {
     int W, H, spW, spH, nseeds, npx;   // npx = W * H (the flat pixel index range of the reference); spW = W / 8, spH = H / 8 (truncated, :29-38)
     float fx, fy, cx, cy, fuseFar, fuseNear;
@@ -94,7 +110,7 @@ struct SfDev {
     float4 *fuseRec;             // [slots][nseeds][3] what k_fuse needs of a seed, per-seed terms of :236-277 evaluated once (FuseRec below)
     unsigned short *index, *amap;  // [slots][npx]
     unsigned *tmin;              // [slots][nseeds]
-    double *invDepth;            // [slots][nseeds] 1.0 / (double)meanDepth (0 when meanDepth <= 0)
+    AssignRec *arec;             // [slots][nseeds] (+ one record of padding at either end) what kb_assign reads of a seed
     float *pxInv;                // [slots][npx] (float)(1.0 / (double)depth) of every pixel (0 when depth <= 0.01): pass 0 writes, passes 1-2 read
     unsigned *wl;                // [slots][npx] relaxation worklist: pixels on a stable seed that pick a different seed
     unsigned *wlCount;           // [slots]
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     memset(&s, 0, sizeof(s));
     P.fused[(size_t)slot * P.nseeds + seedI] = 0;
     if (F.memberG()[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
-        P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.invDepth[(size_t)slot * P.nseeds + seedI] = 0.0;
+        P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.arec[(size_t)slot * P.nseeds + seedI] = assign_rec(s);
         return;
     }
     s.use = 1;
@@ -259,107 +275,137 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
             }
     }
     P.seeds[(size_t)slot * P.nseeds + seedI] = s;
-    P.invDepth[(size_t)slot * P.nseeds + seedI] = s.meanDepth > 0 ? 1.0 / (double)s.meanDepth : 0.0;
+    P.arec[(size_t)slot * P.nseeds + seedI] = assign_rec(s);
 }
 
 // kb_assign: a(p) = argmin seed of pixel p (:357-415 without the `stable` gate).  it == 0: every seed is
 // unstable, so every free pixel is processed: write the index map directly.  it > 0: store a(p) and run
 // relaxation round 0 (pixels whose current seed is unstable at pass start are processed for sure).
-__global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots) {
-    const int tilesX = (P.W + 31) / 32, tilesY = (P.H + 7) / 8;
+//
+// One wave per "dual cell" [8 bx + 4, 8 bx + 12) x [8 by + 4, 8 by + 12), bx / by from -1.  Of the 3x3 neighbourhood only the seeds with
+// |8c + 4 - x| < 8 on both axes are candidates (:384-389): per axis the pixel's own cell plus the left / upper neighbour when (x mod 8) < 4 or
+// the right / lower one when (x mod 8) > 4 -- so ALL pixels of a dual cell have the same candidates {bx, bx + 1} x {by, by + 1} (its first
+// column / row, x mod 8 == 4, only the first of each pair).  The candidates are therefore wave-uniform: their fields are scalar operands, and
+// the per-pixel work is the four cost evaluations and nothing else.  Enumeration in the reference's order (checkI outer, checkJ inner, ascending).
+constexpr int ASSIGN_NY = 2;   // dual cells (one below the other) per wave.  Everything the wave reads -- the NY + 1 lattice rows of candidate records
+                               // (scalar loads) and the pixels' member / gray / depth / index words -- is requested before the first use: with one
+                               // pixel per lane and loads that wait for one another the kernel had too few bytes in flight to keep HBM busy while
+                               // other waves computed (35 us of memory time and 43 us of cost arithmetic per pass simply added up).
+__global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots, int nbx, int nby) {
+    const int bpr = (nbx + 3) >> 2;   // workgroups per row of dual cells (four waves = four dual cells along x)
+    const int nbyG = (nby + ASSIGN_NY - 1) / ASSIGN_NY;
     int slot, blk;
-    if (!xcd_slot(tilesX * tilesY, nSlots, slot, blk)) return;
-    const int colI = (blk % tilesX) * 32 + (threadIdx.x & 31), rowI = (blk / tilesX) * 8 + (threadIdx.x >> 5);
+    if (!xcd_slot(bpr * nbyG, nSlots, slot, blk)) return;
     if (blk == 0) {
         if (it > 0 && threadIdx.x < 8) P.changed[slot * 8 + threadIdx.x] = threadIdx.x == 0 ? 1 : 0;
         if (threadIdx.x >= 64 && threadIdx.x < 64 + NCHUNK) P.chunkAbort[(slot * 2 + (it & 1)) * 16 + threadIdx.x - 64] = 0x7FFFFFFF;
     }
-    // stage the 6 x 3 seeds any pixel of this 32 x 8 tile can pick (fields the cost needs: x, y, meanDepth, meanIntensity,
-    // reciprocal depth); clamped at the lattice border -- out-of-lattice candidates are skipped by the range test below
-    __shared__ float2 s_xy[18], s_di[18];
-    __shared__ double s_inv[18];
-    const int sx0 = (blk % tilesX) * 4 - 1, sy0 = (blk / tilesX) - 1;
-    if (threadIdx.x < 18) {
-        const int sxI = min(max(sx0 + (int)threadIdx.x % 6, 0), P.spW - 1), syI = min(max(sy0 + (int)threadIdx.x / 6, 0), P.spH - 1);
-        const msl_seed *sp = P.seeds + (size_t)slot * P.nseeds + syI * P.spW + sxI;
-        s_xy[threadIdx.x] = *reinterpret_cast<const float2 *>(&sp->x);
-        s_di[threadIdx.x] = *reinterpret_cast<const float2 *>(&sp->meanDepth);   // (meanDepth, meanIntensity)
-        s_inv[threadIdx.x] = P.invDepth[(size_t)slot * P.nseeds + syI * P.spW + sxI];   // 1.0 / (double)meanDepth, the value the divide gives
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int byg = blk / bpr, bxi = (blk - byg * bpr) * 4 + wv;
+    if (bxi >= nbx) return;
+    const int bx = bxi - 1, by0 = byg * ASSIGN_NY - 1;
+    // The candidates (wave-uniform): cell k uses lattice rows by0 + k and by0 + k + 1, in each the neighbours bx and bx + 1 -- two records that
+    // are adjacent in memory.  Rows / columns outside the lattice are clamped for the address (the array has a record of padding either side)
+    // and never evaluated (the range test of :384-389).
+    const bool okx0 = bx >= 0 && bx < P.spW, okx1 = bx + 1 < P.spW;
+    const int bxc = min(bx, P.spW - 1);
+    const AssignRec *arec = P.arec + (unsigned)slot * (unsigned)P.nseeds;
+    AssignRec cr[ASSIGN_NY + 1][2];
+    int rowIdx[ASSIGN_NY + 1];
+#pragma unroll
+    for (int r = 0; r <= ASSIGN_NY; r++) {
+        const int rc = min(max(by0 + r, 0), P.spH - 1);
+        rowIdx[r] = rc * P.spW + bx;                       // seed index of (bx, by0 + r) when valid
+        const AssignRec *rp = arec + (rc * P.spW + bxc);
+        cr[r][0] = rp[0]; cr[r][1] = rp[1];
     }
-    __syncthreads();
-    if (colI >= P.W || rowI >= P.H) return;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
-    const int p = rowI * P.W + colI;
     unsigned short *index = P.index + (size_t)slot * P.pxStride, *amap = P.amap + (size_t)slot * P.pxStride;
-    if (F.memberG()[(size_t)(rowI / 2) * P.mstride + colI / 2] != -1) {
-        if (it == 0) index[p] = 0; else amap[p] = IDX_PLANE;
-        return;
-    }
-    const msl_seed *seeds = P.seeds + (size_t)slot * P.nseeds;
-    const float myIntensity = gray_at(P, F, rowI, colI);
-    // (float)(1.0 / (double)depth) is the same in all three passes: computed (one f64 divide) in pass 0, read back afterwards
-    float myInvDepth = 0.0f;
-    if (it == 0) {
-        const float dpx = depth_at(P, F, rowI, colI);
-        if (dpx > 0.01) myInvDepth = (float)(1.0 / (double)dpx);
-        P.pxInv[(size_t)slot * P.pxStride + p] = myInvDepth;
-    } else {
-        myInvDepth = P.pxInv[(size_t)slot * P.pxStride + p];
-    }
-    const int baseSpX = colI / SP, baseSpY = rowI / SP;
-    float minDistDepth = 1e6f, minDistNodepth = 1e6f;
-    int minSpIndexDepth = -1, minSpIndexNodepth = -1;
-    bool allHasDepth = true;
-    // Of the 3x3 neighbourhood only the seeds with |8c+4-x| < 8 on both axes are candidates (:384-389): per axis the
-    // pixel's own cell plus the left/upper neighbour when (x mod 8) < 4 or the right/lower one when (x mod 8) > 4.
-    // Enumerate those <= 2x2 candidates in the reference's order (checkI outer, checkJ inner, ascending).
-    const int rx = colI - baseSpX * SP, ry = rowI - baseSpY * SP;
-    const int x0 = baseSpX - (rx < SP / 2 ? 1 : 0), nx = (rx == SP / 2) ? 1 : 2;
-    const int y0 = baseSpY - (ry < SP / 2 ? 1 : 0), ny = (ry == SP / 2) ? 1 : 2;
-    // the (up to) four candidates of every pixel of the tile are among the 6 x 3 seeds staged in LDS
-    float2 cxy[4], cdi[4];
-    double cinv[4];
+    float *pxInv = P.pxInv + (size_t)slot * P.pxStride;
+    unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
+    const int lane = threadIdx.x & 63, lx = lane & 7, ly = lane >> 3;
+    const int colI = 8 * bx + 4 + lx;
+    const float colF = (float)colI;
+    const bool colIn = colI >= 0 && colI < P.W;
+    // ---- all loads of the wave's pixels ----
+    bool inImg[ASSIGN_NY];
+    int mem[ASSIGN_NY], cur[ASSIGN_NY];
+    float gI[ASSIGN_NY], dIn[ASSIGN_NY];
+    unsigned tCur[ASSIGN_NY];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int li = (y0 + (c & 1) - sy0) * 6 + (x0 + (c >> 1) - sx0);
-        cxy[c] = s_xy[li]; cdi[c] = s_di[li]; cinv[c] = s_inv[li];
+    for (int k = 0; k < ASSIGN_NY; k++) {
+        const int rowI = 8 * (by0 + k) + 4 + ly;
+        inImg[k] = colIn && rowI >= 0 && rowI < P.H && by0 + k + 1 < nby;
+        const int rowC = min(max(rowI, 0), P.H - 1), colC = min(max(colI, 0), P.W - 1), pc = rowC * P.W + colC;   // (a clamped address: loaded, never used)
+        mem[k] = F.memberG()[(size_t)(rowC / 2) * P.mstride + colC / 2];
+        gI[k] = gray_at(P, F, rowC, colC);
+        dIn[k] = it == 0 ? depth_at(P, F, rowC, colC) : pxInv[pc];
+        cur[k] = it == 0 ? 0 : (int)index[pc];
     }
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int checkSpX = x0 + (c >> 1), checkSpY = y0 + (c & 1);
-        if ((c >> 1) < nx && (c & 1) < ny && checkSpX >= 0 && checkSpX < P.spW && checkSpY >= 0 && checkSpY < P.spH) {
-            const int spIndex = checkSpY * P.spW + checkSpX;
-            const float sx = cxy[c].x, sy = cxy[c].y, sI = cdi[c].y, sD = cdi[c].x;
-            // calculateCost (:333-355)
-            float nodepthCost = 0;
-            const float dist = (sx - colI) * (sx - colI) + (sy - rowI) * (sy - rowI);
-            nodepthCost += dist / ((SP / 2) * (SP / 2));
-            const float intensityDiff = sI - myIntensity;
-            nodepthCost = (float)((double)nodepthCost + div100_exact((double)(intensityDiff * intensityDiff)));
-            float depthCost = nodepthCost;
-            bool has = false;
-            if (sD > 0 && myInvDepth > 0) {
-                const float inverseDepthDiff = (float)(cinv[c] - (double)myInvDepth);
-                depthCost = (float)((double)depthCost + (double)(inverseDepthDiff * inverseDepthDiff) * 400.0);
-                has = true;
-            }
-            allHasDepth &= has;
-            if (depthCost < minDistDepth) { minDistDepth = depthCost; minSpIndexDepth = spIndex; }
-            if (nodepthCost < minDistNodepth) { minDistNodepth = nodepthCost; minSpIndexNodepth = spIndex; }
+    for (int k = 0; k < ASSIGN_NY; k++)
+        tCur[k] = it == 0 ? 0u : tmin[cur[k]];   // (a plain load: 0 stays 0 and non-zero stays non-zero during the pass, so a stale line answers the same)
+    // ---- per cell: the four cost evaluations ----
+#pragma unroll
+    for (int k = 0; k < ASSIGN_NY; k++) {
+        const int by = by0 + k;
+        if (__ballot(inImg[k]) == 0) continue;
+        const bool oky0 = by >= 0 && by < P.spH, oky1 = by + 1 < P.spH;
+        const int rowI = 8 * by + 4 + ly;
+        const int p = rowI * P.W + colI;
+        const bool isPlane = mem[k] != -1;
+        const float myIntensity = gI[k];
+        // (float)(1.0 / (double)depth) is the same in all three passes: computed (one f64 divide) in pass 0, read back afterwards
+        float myInvDepth = dIn[k];
+        if (it == 0) {
+            myInvDepth = 0.0f;
+            if (dIn[k] > 0.01) myInvDepth = (float)(1.0 / (double)dIn[k]);
+            if (inImg[k] && !isPlane) pxInv[p] = myInvDepth;
         }
-    }
-    const int pick = allHasDepth ? minSpIndexDepth : minSpIndexNodepth;
-    if (it == 0) { index[p] = (unsigned short)(pick >= 0 ? pick : 0); return; }
-    amap[p] = pick >= 0 ? (unsigned short)pick : IDX_NONE;
-    if (pick >= 0) {
-        unsigned *tmin = P.tmin + (size_t)slot * P.nseeds;
-        const int cur = index[p];
-        if (seeds[cur].stable == 0) {
-            if (tmin[pick] > (unsigned)p + 1u) atomicMin(&tmin[pick], (unsigned)p + 1u);       // processed for sure: round 0
-        } else if (pick != cur) {
-            // Only these pixels can extend a chain: p is processed iff its (stable) seed gets unstabilised before p, and it
-            // then unstabilises a DIFFERENT seed.  (pick == cur would only re-lower t(cur) above its current value.)
-            P.wl[(size_t)slot * P.pxStride + atomicAdd(&P.wlCount[slot], 1u)] = (unsigned)p;
+        const bool pxHasDepth = myInvDepth > 0;
+        const double myInvD = (double)myInvDepth;
+        const float rowF = (float)rowI;
+        float minDistDepth = 1e6f, minDistNodepth = 1e6f;
+        int minSpIndexDepth = -1, minSpIndexNodepth = -1;
+        bool allHasDepth = true;
+        // calculateCost (:333-355) + the two running minima (:398-410) for one candidate; `use` = this pixel has the candidate (x mod 8 == 4:
+        // the pixel's own cell only).  Selects instead of branches.
+        auto consider = [&](const AssignRec &C, int spIndex, bool use) {
+            float nodepthCost = 0;
+            const float dist = (C.x - colF) * (C.x - colF) + (C.y - rowF) * (C.y - rowF);
+            nodepthCost += dist / ((SP / 2) * (SP / 2));
+            const float intensityDiff = C.meanIntensity - myIntensity;
+            nodepthCost = (float)((double)nodepthCost + div100_exact((double)(intensityDiff * intensityDiff)));
+            const bool has = C.invDepth >= 0 && pxHasDepth;
+            const float inverseDepthDiff = (float)(C.invDepth - myInvD);
+            const float withDepth = (float)((double)nodepthCost + (double)(inverseDepthDiff * inverseDepthDiff) * 400.0);
+            const float depthCost = has ? withDepth : nodepthCost;
+            allHasDepth = allHasDepth && (has || !use);
+            const bool bd = use && depthCost < minDistDepth, bn = use && nodepthCost < minDistNodepth;
+            minDistDepth = bd ? depthCost : minDistDepth; minSpIndexDepth = bd ? spIndex : minSpIndexDepth;
+            minDistNodepth = bn ? nodepthCost : minDistNodepth; minSpIndexNodepth = bn ? spIndex : minSpIndexNodepth;
+        };
+        const bool anyStable = (cr[k][0].stable | cr[k][1].stable | cr[k + 1][0].stable | cr[k + 1][1].stable) != 0;   // (wave-uniform; rare)
+        // the reference's order: checkI (x) outer, checkJ (y) inner, ascending
+        if (okx0 && oky0) consider(cr[k][0], rowIdx[k], true);
+        if (okx0 && oky1) consider(cr[k + 1][0], rowIdx[k + 1], ly != 0);
+        if (okx1 && oky0) consider(cr[k][1], rowIdx[k] + 1, lx != 0);
+        if (okx1 && oky1) consider(cr[k + 1][1], rowIdx[k + 1] + 1, lx != 0 && ly != 0);
+        const int pick = allHasDepth ? minSpIndexDepth : minSpIndexNodepth;
+        if (!inImg[k]) continue;
+        if (it == 0) { index[p] = isPlane ? (unsigned short)0 : (unsigned short)(pick >= 0 ? pick : 0); continue; }
+        amap[p] = isPlane ? IDX_PLANE : (pick >= 0 ? (unsigned short)pick : IDX_NONE);
+        if (!isPlane && pick >= 0) {
+            // the current seed is unstable at pass start <=> t(cur) == 0 (kb_update_seeds / kb_commit_seeds left 0 or T_INF, and this pass
+            // only ever lowers a t to p + 1 >= 1, so a value read at any time during the pass answers the same)
+            if (tCur[k] == 0) {
+                // processed for sure (round 0): t(pick) = min(t(pick), p + 1) -- only a candidate that entered the pass stable has a t above 0
+                if (anyStable && tmin[pick] > (unsigned)p + 1u) atomicMin(&tmin[pick], (unsigned)p + 1u);
+            } else if (pick != cur[k]) {
+                // Only these pixels can extend a chain: p is processed iff its (stable) seed gets unstabilised before p, and it
+                // then unstabilises a DIFFERENT seed.  (pick == cur would only re-lower t(cur) above its current value.)
+                P.wl[(size_t)slot * P.pxStride + atomicAdd(&P.wlCount[slot], 1u)] = (unsigned)p;
+            }
         }
     }
 }
@@ -528,6 +574,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         if (!S.use || stable) {
             if (l == 0) {   // skipped: only the stable flag (as left by the pixel pass) and t(s) change
                 P.seeds[(size_t)slot * P.nseeds + seedI].stable = stable;
+                P.arec[(size_t)slot * P.nseeds + seedI].stable = stable ? 1u : 0u;
                 P.seedsTmp[(size_t)slot * P.nseeds + seedI]._pad = 0;
                 P.tmin[(size_t)slot * P.nseeds + seedI] = stable ? T_INF : 0u;
             }
@@ -645,7 +692,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     if (active && l == 0) {
         const size_t si = (size_t)slot * P.nseeds + seedI;
         if (aborted) {
-            P.seeds[si].stable = 0; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
+            P.seeds[si].stable = 0; P.arec[si].stable = 0u; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
         } else {
             if (depthLoop) T.meanDepth = s_mean[g];
             msl_seed old = S;
@@ -654,7 +701,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             T._pad = 0;
             P.seeds[si] = T;
             P.tmin[si] = T.stable ? T_INF : 0u;
-            P.invDepth[si] = T.meanDepth > 0 ? 1.0 / (double)T.meanDepth : 0.0;
+            P.arec[si] = assign_rec(T);
         }
     }
 }
@@ -678,7 +725,7 @@ __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     out.stable = 0; out._pad = 0;
     P.seeds[si] = out;
     P.tmin[si] = 0u;
-    P.invDepth[si] = out.meanDepth > 0 ? 1.0 / (double)out.meanDepth : 0.0;
+    P.arec[si] = assign_rec(out);
 }
 
 // kb_seed_plane: calculateNorms (:775-803) fused per seed, 16 lanes per seed, 4 seeds per wave/workgroup.
@@ -1761,7 +1808,7 @@ struct msl_sf {
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
     msl_seed *d_seeds = nullptr, *d_seedsTmp = nullptr; msl_surfel *d_cand = nullptr; uint8_t *d_candOk = nullptr, *d_fused = nullptr; uint2 *d_tex = nullptr; float4 *d_fuseRec = nullptr;
     unsigned short *d_index = nullptr, *d_amap = nullptr; unsigned *d_tmin = nullptr; int *d_chunkAbort = nullptr, *d_changed = nullptr;
-    double *d_invDepth = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
+    AssignRec *d_arec = nullptr; unsigned *d_wl = nullptr, *d_wlCount = nullptr;
     float *d_pxInv = nullptr;
     // staged images (host input mode), per slot
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
@@ -1854,7 +1901,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_tex); F(h->d_fuseRec); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_invDepth); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_arec); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
     h->grayCap = h->depthCap = h->memberCap = 0;
 }
@@ -1877,11 +1924,12 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_index, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_amap, sizeof(unsigned short) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_tmin, sizeof(unsigned) * ns * slots));
-    MSL_HIP_TRY(hipMalloc(&h->d_invDepth, sizeof(double) * ns * slots));
+    MSL_HIP_TRY(hipMalloc(&h->d_arec, sizeof(AssignRec) * (ns * slots + 2)));   // + a record either side: kb_assign loads row pairs that may start one before / end one after
     MSL_HIP_TRY(hipMalloc(&h->d_pxInv, sizeof(float) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_wl, sizeof(unsigned) * npx * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_wlCount, sizeof(unsigned) * slots));
     MSL_HIP_TRY(hipMemset(h->d_wlCount, 0, sizeof(unsigned) * slots));
+    MSL_HIP_TRY(hipMemset(h->d_arec, 0, sizeof(AssignRec) * (ns * slots + 2)));
     MSL_HIP_TRY(hipMalloc(&h->d_chunkAbort, sizeof(int) * 32 * slots));
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
@@ -1890,7 +1938,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, ns * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused; D.tex = h->d_tex; D.fuseRec = h->d_fuseRec;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
-    D.invDepth = h->d_invDepth; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
+    D.arec = h->d_arec + 1; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
     h->maxBatch = maxBatch;
     h->lastSlot = 0;            // the debug accessors must never index beyond the reallocated slot buffers
     h->evMapValid[0] = h->evMapValid[1] = false;
@@ -2036,14 +2084,15 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     P.cand = D.cand + (size_t)slot0 * D.nseeds; P.candOk = D.candOk + (size_t)slot0 * D.nseeds; P.fused = D.fused + (size_t)slot0 * D.nseeds;
     P.tex = D.tex + (size_t)slot0 * D.pxStride; P.fuseRec = D.fuseRec + (size_t)slot0 * D.nseeds * 3;
     P.index = D.index + (size_t)slot0 * D.pxStride; P.amap = D.amap + (size_t)slot0 * D.pxStride; P.tmin = D.tmin + (size_t)slot0 * D.nseeds;
-    P.invDepth = D.invDepth + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.pxStride; P.wl = D.wl + (size_t)slot0 * D.pxStride; P.wlCount = D.wlCount + slot0;
+    P.arec = D.arec + (size_t)slot0 * D.nseeds; P.pxInv = D.pxInv + (size_t)slot0 * D.pxStride; P.wl = D.wl + (size_t)slot0 * D.pxStride; P.wlCount = D.wlCount + slot0;
     P.chunkAbort = D.chunkAbort + slot0 * 32; P.changed = D.changed + slot0 * 8;
     const unsigned un = (unsigned)n;
     const dim3 seedGrid((D.nseeds + 255) / 256, un);
-    const dim3 pxGrid(xcd_grid(((W + 31) / 32) * ((H + 7) / 8), n)), flatPx(xcd_grid(((D.npx + 7) / 8 + 255) / 256, n));
+    const int nbx = ((W - 5) >> 3) + 2, nby = ((H - 5) >> 3) + 2;   // dual cells [8 b + 4, 8 b + 12), b from -1, that meet the image
+    const dim3 pxGrid(xcd_grid(((nbx + 3) / 4) * ((nby + ASSIGN_NY - 1) / ASSIGN_NY), n)), flatPx(xcd_grid(((D.npx + 7) / 8 + 255) / 256, n));
     LAUNCH(SK_SEED_INIT, sp, kb_seed_init, seedGrid, dim3(256), P);
     for (int it = 0; it < 3; it++) {
-        LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n);
+        LAUNCH(SK_ASSIGN, sp, kb_assign, pxGrid, dim3(256), P, it, n, nbx, nby);
         if (it > 0) {
             h->prof.begin(SK_PROP, sp);
             if (h->propLds) {
