@@ -558,6 +558,13 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     __shared__ int s_cnt[16], s_done[16];
     int slot, blk;
     if (!xcd_slot((P.nseeds + 15) / 16, nSlots, slot, blk)) return;
+#ifdef MSL_FUSE_STAMPS   // section cycle counts of the waves of slot 0, summed into delList[96 ..] (tools/fuse_stamps.py)
+    unsigned long long ust[8]; int usn = 0;
+#define USTAMP() ust[usn++] = __builtin_amdgcn_s_memtime()
+#else
+#define USTAMP()
+#endif
+    USTAMP();
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int seedI = blk * 16 + g;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             nd += __shfl(incl, g15, 64);
         }
     }
+    USTAMP();   // 1: seed record + window gather + ordered depth list
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) {
         sumX += __shfl_xor(sumX, d, 16); sumY += __shfl_xor(sumY, d, 16);
@@ -664,6 +672,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         s_done[g] = depthLoop ? 0 : 1;
     }
     __builtin_amdgcn_wave_barrier();
+    USTAMP();   // 2: means, colour fetch, sequential depth sum
     // Huber mean depth: <= 5 Newton steps (:492-512); terms in parallel, accumulation in list order
     for (int newtonI = 0; newtonI < 5; newtonI++) {
         if (s_done[g]) break;
@@ -689,6 +698,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         }
         __builtin_amdgcn_wave_barrier();
     }
+    USTAMP();   // 3: Newton steps
     if (active && l == 0) {
         const size_t si = (size_t)slot * P.nseeds + seedI;
         if (aborted) {
@@ -704,7 +714,15 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             P.arec[si] = assign_rec(T);
         }
     }
+#ifdef MSL_FUSE_STAMPS
+    USTAMP();   // 4: stores
+    if (slot == 0 && (threadIdx.x & 63) == 0) {
+        for (int q = 1; q < usn; q++) atomicAdd(&P.delList[96 + q], (unsigned)(ust[q] - ust[q - 1]));
+        atomicAdd(&P.delList[96], 1u);
+    }
+#endif
 }
+
 
 // kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
 // although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
@@ -789,7 +807,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int bW = (P.spW + 1) / 2, bH = (P.spH + 1) / 2;
     if (!xcd_slot(bW * bH, nSlots, slot, blk)) return;
 #ifdef MSL_FUSE_STAMPS   // section cycle counts of the waves of slot 0, summed into delList[64 ..] (tools/fuse_stamps.py)
-    unsigned long long sst[12]; int ssn = 0;
+    unsigned long long sst[14]; int ssn = 0;
 #define SECTION_STAMP() sst[ssn++] = __builtin_amdgcn_s_memtime()
 #else
 #define SECTION_STAMP()
@@ -800,10 +818,18 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const bool inRange = spX < P.spW && spY < P.spH;
     const int seedI = inRange ? spY * P.spW + spX : 0;
     const FrameDev F = P.frames[slot];   // by value: one load up front instead of re-reading fields around every store
+#ifdef MSL_FUSE_STAMPS
+    { unsigned long long a = (unsigned long long)F.depth; asm volatile("" :: "s"(a)); }
+    SECTION_STAMP();   // 0a: kernel arguments + frame record
+#endif
     const unsigned short *index = P.index + (size_t)slot * P.pxStride;
     msl_seed S;
     memset(&S, 0, sizeof(S));
     if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
+#ifdef MSL_FUSE_STAMPS
+    asm volatile("" :: "v"(S.x), "v"(S.meanDepth));
+    SECTION_STAMP();   // 0b: seed record
+#endif
     const int xb = spX * SP + SP / 2 - SP, yb = spY * SP + SP / 2 - SP;
     // ---- gather: lane = (row r of a group of four window rows, quad q of four window columns), four iterations; the
     // unclipped window is guarded by the flat index range (:680-684).  16 wide loads per lane: 8 B of index, 16 B of depth,
@@ -870,6 +896,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                 }
             }
         nvalid = __popc(vm);
+        SECTION_STAMP();   // 1a: window loads arrived, ownership tests
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
         {   // list bases inside the pool, each rounded up to 4 entries

@@ -33,10 +33,14 @@ n = sf.map_size()
 nsub = ((n + 255) // 256 + int(os.environ.get("FUSE_SB", "2")) - 1) // int(os.environ.get("FUSE_SB", "2"))   # waves
 w = sf.debug_scratch(8 * (nsub + 1024)).reshape(-1, 8)
 cst = sf.debug_scratch(8, which=1).astype(np.int64)
-sec = sf.debug_scratch(16, which=1, offset=64).astype(np.float64)
+sec = sf.debug_scratch(20, which=1, offset=64).astype(np.float64)
 if sec[0] > 0:
-    names = ["gather+lists", "positions+normals", "inliers", "six sums", "GN1", "GN2", "GN3", "GN4", "GN5"]
+    names = ["kernarg+frame record", "seed record", "window loads+ownership", "ordered lists", "positions+normals", "inliers", "six sums", "GN1", "GN2", "GN3", "GN4", "GN5"]
     print("kb_seed_plane sections (shader cycles per wave, slot 0, %d waves): " % sec[0] + ", ".join(f"{n} {sec[1 + i] / sec[0]:.0f}" for i, n in enumerate(names)))
+usec = sf.debug_scratch(8, which=1, offset=96).astype(np.float64)
+if usec[0] > 0:
+    names = ["seed record + gather + depth list", "means + colour + depth sum", "Newton steps", "stores"]
+    print("kb_update_seeds sections (shader cycles per wave, slot 0, all three passes, %d waves): " % usec[0] + ", ".join(f"{n} {usec[1 + i] / usec[0]:.0f}" for i, n in enumerate(names)))
 w = w[(w[:, 0] != 0) & (w[:, 0].astype(np.int64) > w[:, 0].astype(np.int64).max() - 100000)]   # waves of the stamped launch only (keyframe MSL_FUSE_STAMPS of the last pass)
 nsub = len(w)
 t0, t1, t2, tot = (w[:, i].astype(np.int64) for i in range(4))
