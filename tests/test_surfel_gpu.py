@@ -164,6 +164,32 @@ def test_degenerate_depth(oracle):
     g.close()
 
 
+def test_stable_seeds_and_relaxation_chains(oracle):
+    """Flat grey regions next to textured ones: more than half of the seeds turn stable after the first update, so the pixel passes skip most
+    pixels, processed pixels un-stabilise neighbouring seeds in raster order (the `stable` chains the relaxation restates), and the pixel pass's
+    candidate records carry stable flags.  Index map and seeds as the oracle's, two keyframes in a row on the same handle."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    local = synth.surfel_map(3000, ref=5).astype(SURFEL_DTYPE)
+    lg = local.copy()
+    for k in (5, 6):
+        gray, depth, member, pose = synth.surfel_frame(k)
+        g2 = np.full_like(gray, 120)
+        g2[:, 200:260] = gray[:, 200:260]
+        g2[300:, 400:] = 60
+        g2[50:120, 420:600] = np.random.default_rng(k).integers(0, 255, (70, 180), dtype=np.uint8)
+        lo, no = o.fuse(k, g2, depth, member, pose, local)
+        ng = g.fuseInitializeMap(k, g2, depth, member, pose, lg)
+        so = o.seeds()
+        assert int((so["stable"] & so["use"]).sum()) > 2000
+        assert np.array_equal(g.debug_index(), o.index())
+        assert_seeds_close(g.debug_seeds(), so)
+        assert_surfels_close(lg, lo, "local")
+        assert_surfels_close(ng, no, "new")
+        local = lo
+    g.close()
+
+
 def test_compaction_matches_literal_loop(oracle):
     """Slot refill / tail compaction against the literal back-to-front loop for adversarial delete patterns."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
