@@ -199,8 +199,8 @@ __device__ __forceinline__ bool fast_candidate(const uint8_t *t, int tp, int th)
 }
 
 __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
-    __shared__ uint8_t s_tile[(MAXCELL + 6) * (MAXCELL + 8)];
-    __shared__ uint8_t s_score[(MAXCELL + 2) * (MAXCELL + 2)];
+    __shared__ __attribute__((aligned(4))) uint8_t s_tile[(MAXCELL + 6) * (MAXCELL + 8)];
+    __shared__ __attribute__((aligned(4))) uint8_t s_score[(MAXCELL + 2) * (MAXCELL + 2)];
     __shared__ unsigned s_bits[2][MAXCELL * MAXCELL / 32];   // kept-pixel bitmaps: [0] at iniTh, [1] at minTh
     __shared__ unsigned short s_list[MAXCELL * MAXCELL];   // pixels that pass the quick test
     __shared__ unsigned s_wave[17];
@@ -218,13 +218,21 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
     // stage (cw+6) x (ch+6) pixels: rows y0-3.., cols x0-3..
     const int tw = cw + 6, th = ch + 6, tp = (tw + 3) & ~3;
     // exact floor(i / w) for i < 2^13, w <= 2^7 by multiply-shift: one division per thread instead of one per pixel
-    const unsigned mTw = ((1u << 20) + tw - 1) / tw, mCw = ((1u << 20) + cw - 1) / cw;
-    for (int i = tid; i < tw * th; i += 256) {
-        const int r = (int)(((unsigned)i * mTw) >> 20), c = i - r * tw;
-        s_tile[r * tp + c] = img[(size_t)(C.y0 - 3 + r) * pitch + (C.x0 - 3 + c)];
+    const unsigned mCw = ((1u << 20) + cw - 1) / cw;
+    {   // four bytes per load and LDS store (the tile's rows start at any byte; a row's last word may reach 3 bytes past the tile, still inside
+        // the image row: the cells end 13 px before the level's right edge)
+        const int nw = tp >> 2;
+        const unsigned mNw = ((1u << 20) + nw - 1) / nw;
+        const uint8_t *src = img + (size_t)(C.y0 - 3) * pitch + (C.x0 - 3);
+        for (int i = tid; i < nw * th; i += 256) {
+            const int r = (int)(((unsigned)i * mNw) >> 20), q = i - r * nw;
+            uint32_t w4;
+            __builtin_memcpy(&w4, src + (size_t)r * pitch + 4 * q, 4);
+            *reinterpret_cast<uint32_t *>(&s_tile[r * tp + 4 * q]) = w4;
+        }
     }
     const int sp = cw + 2;
-    for (int i = tid; i < sp * (ch + 2); i += 256) s_score[i] = 0;
+    for (int i = tid; i < (sp * (ch + 2) + 3) >> 2; i += 256) reinterpret_cast<uint32_t *>(s_score)[i] = 0u;
     if (tid < MAXCELL * MAXCELL / 32) { s_bits[0][tid] = 0; s_bits[1][tid] = 0; }
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
