@@ -168,3 +168,231 @@ def surfel_map(n, ref=0, seed=11, min_update_times=1):
 def depth_u16(depth_m, factor=5000.0):
     """Metres -> the raw 16-bit depth image the plane extractor reads (TUM / ICL convention: 5000 units per metre)."""
     return np.clip(np.rint(depth_m * factor), 0, 65535).astype(np.uint16)
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 4: a furnished room (curved and small objects, depth edges, z^2 sensor noise, dropout blobs) and a
+# dense-in-view live map (SURVEY.md 8(d) config 3: "~35 % inside the current frustum").
+#
+# A scene is the box room plus a list of solids; rays are cast in closed form (float64).  All ray functions take
+# flat arrays: origins o [N, 3], directions d [N, 3] (camera z component 1, so t IS the z-depth) and return the
+# smallest positive t with the outward surface normal at the hit.
+# ------------------------------------------------------------------------------------------------
+def clutter_scene(seed=5):
+    """Deterministic furniture: spheres, vertical cylinders (axis = world y) and yawed boxes standing on the floor
+    (y = +1.5 is down: camera_pose yaws about the downward y axis) or hanging in the room, all >= 1.2 m away from the
+    camera circle (radius 0.5 m about the origin)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    spheres, cyls, boxes = [], [], []
+
+    def ring(rmin, rmax):
+        a = rng.uniform(0, 2 * np.pi); r = rng.uniform(rmin, rmax)
+        return np.clip(r * np.cos(a), -2.6, 2.6), np.clip(r * np.sin(a), -2.1, 2.1)
+    for _ in range(26):     # spheres, some resting on the floor, some floating at camera height
+        x, z = ring(1.5, 2.7); r = rng.uniform(0.1, 0.4)
+        y = ROOM[1] - r if rng.random() < 0.5 else rng.uniform(-0.5, 0.6)
+        spheres.append((np.array([x, y, z]), r))
+    for _ in range(16):     # pillars and lamp posts
+        x, z = ring(1.6, 2.8); r = rng.uniform(0.05, 0.25)
+        y1 = ROOM[1]; y0 = y1 - rng.uniform(0.6, 2.6)
+        cyls.append((x, z, r, y0, y1))
+    for _ in range(26):     # cupboards, tables, small boxes: (centre, half extents, yaw)
+        x, z = ring(1.6, 2.9); hx, hy, hz = rng.uniform(0.08, 0.5), rng.uniform(0.1, 0.7), rng.uniform(0.08, 0.5)
+        boxes.append((np.array([x, ROOM[1] - hy, z]), np.array([hx, hy, hz]), rng.uniform(0, np.pi)))
+    return dict(spheres=spheres, cyls=cyls, boxes=boxes)
+
+
+ROOM_ONLY = dict(spheres=[], cyls=[], boxes=[])
+
+
+def cast(scene, o, d, subsets=None):
+    """(t [N], outward normal [N, 3], object id [N]) of the first hit of rays o + t d; id 0..5 = room faces, then the solids.
+    subsets: optional {solid number: indices of the only rays that can hit it} (a caller that knows the projection culls with it)."""
+    o = np.asarray(o, np.float64); d = np.asarray(d, np.float64)
+    n = len(d)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t1 = (ROOM[None, :] - o) / d
+        t2 = (-ROOM[None, :] - o) / d
+    tw = np.where(d > 0, t1, np.where(d < 0, t2, np.inf))
+    ax = np.argmin(tw, axis=1)
+    t = tw[np.arange(n), ax]
+    nrm = np.zeros((n, 3))
+    nrm[np.arange(n), ax] = -np.sign(d[np.arange(n), ax])          # pointing into the room
+    oid = 2 * ax + (d[np.arange(n), ax] < 0)
+    nid = 6
+
+    O, D = o, d          # all rays; o, d below are the rays the current solid is tested against
+    sel = None
+
+    def choose():
+        nonlocal o, d, sel, n
+        sel = None if subsets is None else subsets.get(nid - 6)
+        o, d = (O, D) if sel is None else (O[sel], D[sel])
+        n = len(d)
+
+    def take(tc, nc, valid):
+        m = valid & (tc > 1e-6) & (tc < (t if sel is None else t[sel]))
+        i = np.flatnonzero(m) if sel is None else sel[m]
+        t[i] = tc[m]; nrm[i] = nc[m]; oid[i] = nid
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for c, r in scene["spheres"]:
+            choose()
+            oc = o - c
+            a = (d * d).sum(1); b = (oc * d).sum(1); cc = (oc * oc).sum(1) - r * r
+            disc = b * b - a * cc
+            tc = (-b - np.sqrt(np.maximum(disc, 0))) / a
+            take(tc, (oc + d * tc[:, None]) / r, disc > 0)
+            nid += 1
+        for x, z, r, y0, y1 in scene["cyls"]:
+            choose()
+            ox, oz = o[:, 0] - x, o[:, 2] - z
+            a = d[:, 0] ** 2 + d[:, 2] ** 2; b = ox * d[:, 0] + oz * d[:, 2]; cc = ox * ox + oz * oz - r * r
+            disc = b * b - a * cc
+            tc = (-b - np.sqrt(np.maximum(disc, 0))) / a
+            yh = o[:, 1] + d[:, 1] * tc
+            ns = np.stack([(ox + d[:, 0] * tc) / r, np.zeros(n), (oz + d[:, 2] * tc) / r], 1)
+            take(tc, ns, (disc > 0) & (a > 0) & (yh >= y0) & (yh <= y1))
+            tc = (y0 - o[:, 1]) / d[:, 1]                              # top cap (the bottom one stands on the floor)
+            hx, hz = ox + d[:, 0] * tc, oz + d[:, 2] * tc
+            take(tc, np.tile([0.0, -1.0, 0.0], (n, 1)), (hx * hx + hz * hz <= r * r) & (d[:, 1] > 0))
+            nid += 1
+        for c, hs, yaw in scene["boxes"]:
+            choose()
+            cy_, sy_ = np.cos(yaw), np.sin(yaw)
+            R = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])      # box -> world
+            ob = (o - c) @ R; db = d @ R                                    # world -> box (R^T applied to row vectors)
+            ta = (-hs[None, :] - ob) / db; tb = (hs[None, :] - ob) / db
+            tn = np.minimum(ta, tb); tf = np.maximum(ta, tb)
+            tn = np.where(np.isnan(tn), -np.inf, tn); tf = np.where(np.isnan(tf), np.inf, tf)
+            axn = np.argmax(tn, axis=1)
+            tnear = tn[np.arange(n), axn]; tfar = tf.min(axis=1)
+            nb = np.zeros((n, 3)); nb[np.arange(n), axn] = -np.sign(db[np.arange(n), axn])
+            take(tnear, nb @ R.T, tnear <= tfar)
+            nid += 1
+    return t, nrm, oid
+
+
+def bounding_spheres(scene):
+    """(centre, radius) of every solid, in cast()'s numbering."""
+    out = [(c, r) for c, r in scene["spheres"]]
+    out += [(np.array([x, 0.5 * (y0 + y1), z]), float(np.hypot(r, 0.5 * (y1 - y0)))) for x, z, r, y0, y1 in scene["cyls"]]
+    out += [(c, float(np.linalg.norm(hs))) for c, hs, _ in scene["boxes"]]
+    return out
+
+
+def _pose_matrix(k):
+    return camera_pose(k).reshape(4, 4).T.astype(np.float64)
+
+
+def clutter_frame(k, w=640, h=480, intr=TUM1, seed=7, scene=None, noise_z2=0.0015, blobs=0.07, edge_dropout=0.5):
+    """Keyframe k of the furnished room: (gray u8, depth f32 metres, membership i32 all -1, pose f32[16], object id map).
+    Depth = exact z-depth + N(0, (noise_z2 z^2)^2) (structured-light noise grows with z^2: ~6 mm at 2 m) with `blobs` of the
+    image knocked out in elliptic patches and `edge_dropout` of the pixels next to a depth discontinuity invalid, as real
+    sensors do -- so superpixels straddle depth edges with partial data, curved patches and a few dozen valid pixels."""
+    scene = clutter_scene() if scene is None else scene
+    rng = np.random.Generator(np.random.PCG64(seed * 100003 + k + 77))
+    pose = camera_pose(k)
+    T = _pose_matrix(k)
+    u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    dc = np.stack([(u - intr["cx"]) / intr["fx"], (v - intr["cy"]) / intr["fy"], np.ones_like(u)], axis=2).reshape(-1, 3)
+    dw = dc @ T[:3, :3].T
+    # cull: a solid is only tested against the rays of the pixel rectangle its bounding sphere projects into
+    Ti = np.linalg.inv(T)
+    subsets = {}
+    for j, (c, r) in enumerate(bounding_spheres(scene)):
+        cc = Ti[:3, :3] @ c + Ti[:3, 3]
+        if cc[2] + r < 0.05:
+            subsets[j] = np.zeros(0, np.int64)
+            continue
+        if cc[2] - r < 0.05:
+            continue                                       # straddles the camera plane: all rays
+        zn = cc[2] - r
+        x0 = (cc[0] - r) / (zn if cc[0] - r < 0 else cc[2] + r); x1 = (cc[0] + r) / (zn if cc[0] + r > 0 else cc[2] + r)
+        y0 = (cc[1] - r) / (zn if cc[1] - r < 0 else cc[2] + r); y1 = (cc[1] + r) / (zn if cc[1] + r > 0 else cc[2] + r)
+        us = sorted((x0 * intr["fx"] + intr["cx"], x1 * intr["fx"] + intr["cx"])); vs = sorted((y0 * intr["fy"] + intr["cy"], y1 * intr["fy"] + intr["cy"]))
+        ua, ub = max(int(np.floor(us[0])) - 1, 0), min(int(np.ceil(us[1])) + 2, w)
+        va, vb = max(int(np.floor(vs[0])) - 1, 0), min(int(np.ceil(vs[1])) + 2, h)
+        subsets[j] = (np.arange(va, vb)[:, None] * w + np.arange(ua, ub)[None, :]).reshape(-1) if ua < ub and va < vb else np.zeros(0, np.int64)
+    t, nrm, oid = cast(scene, np.broadcast_to(T[:3, 3], dw.shape), dw, subsets)
+    hit = T[:3, 3][None, :] + dw * t[:, None]
+    t = t.reshape(h, w); oid = oid.reshape(h, w)
+    depth = t + rng.normal(0.0, 1.0, size=t.shape) * noise_z2 * t * t
+    # dropout: elliptic blobs ...
+    s = w / 640.0
+    area = 0.0
+    yy, xx = np.mgrid[0:h, 0:w]
+    while area < blobs * w * h:
+        bx, by = rng.uniform(0, w), rng.uniform(0, h); ra, rb = rng.uniform(3, 28) * s, rng.uniform(3, 28) * s
+        m = ((xx - bx) / ra) ** 2 + ((yy - by) / rb) ** 2 <= 1.0
+        depth[m] = 0.0
+        area += np.pi * ra * rb
+    # ... and a share of the pixels at depth discontinuities (> 5 cm to a 4-neighbour)
+    edge = np.zeros_like(t, bool)
+    dx = np.abs(np.diff(t, axis=1)) > 0.05; dy = np.abs(np.diff(t, axis=0)) > 0.05
+    edge[:, :-1] |= dx; edge[:, 1:] |= dx; edge[:-1, :] |= dy; edge[1:, :] |= dy
+    depth[edge & (rng.random(t.shape) < edge_dropout)] = 0.0
+    # texture: a checker on the two dominant tangent coordinates of the hit, phase / contrast / cell size by object
+    an = np.abs(nrm)
+    dom = np.argmax(an, axis=1)
+    a = np.where(dom == 0, hit[:, 1], hit[:, 0]); b = np.where(dom == 2, hit[:, 1], hit[:, 2])
+    oidf = oid.reshape(-1)
+    cell = np.where(oidf < 6, 0.25, 0.07 + 0.02 * (oidf % 5))
+    chk = (np.floor(a / cell).astype(np.int64) + np.floor(b / cell).astype(np.int64)) & 1
+    lo = np.where(oidf < 6, 60, 30 + (oidf * 37) % 90); hi = np.where(oidf < 6, 180, 140 + (oidf * 53) % 110)
+    shade = 0.65 + 0.35 * np.abs((nrm * dw).sum(1)) / np.linalg.norm(dw, axis=1)          # Lambert-ish: curved objects get gradients
+    gray = (np.where(chk == 1, hi, lo) * shade).reshape(h, w) + rng.integers(-4, 5, size=t.shape)
+    member = np.full(((h + 1) // 2, (w + 1) // 2), -1, np.int32)
+    return (np.clip(np.rint(gray), 0, 255).astype(np.uint8), np.ascontiguousarray(depth.astype(np.float32)), member, pose, oid.astype(np.int32))
+
+
+def surfel_map_dense(n, ref=0, seed=11, w=640, h=480, intr=TUM1, scene=None, k_lo=-150, k_hi=214, flip=0.01, floating=0.003,
+                     min_update_times=5, order="creation", scatter=0.01):
+    """n live surfels the way a camera that panned over keyframes k_lo .. k_hi - 1 would have left them: each surfel is the
+    back-projection of a uniformly drawn pixel of a uniformly drawn source keyframe onto the scene.  With the 0.5 degree pan of
+    camera_pose() and TUM1's 63.5 degree horizontal field of view a frustum overlaps the sources within +-127 keyframes, so for the
+    default 364 sources about 127 / 364 = 35 % of the map lies inside the frustum of ANY keyframe 0..63 (SURVEY.md 8(d) config 3;
+    the reference's local map = the surfels of the last <= 10 pose-graph hops, src/SurfelMapping.cpp:326-351, is mostly in view).
+    order="creation": array order = (source keyframe, superpixel raster index), the order initializeSurfels appends them in
+    (src/SurfelFusion.cpp:285-331); "random": no locality between neighbours in the array at all.
+    flip / floating: shares of surfels with an outward normal (normal-disagreement deletion, :230-233) and of surfels floating
+    1.2-2 m in front of the surface (occlusion deletion, :208-211)."""
+    scene = ROOM_ONLY if scene is None else scene
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ks = rng.integers(k_lo, k_hi, n)
+    u = rng.uniform(1.0, w - 2.0, n); v = rng.uniform(1.0, h - 2.0, n)
+    if order == "creation":
+        key = (ks - k_lo).astype(np.int64) * ((w // 8) * (h // 8)) + (v.astype(np.int64) // 8) * (w // 8) + u.astype(np.int64) // 8
+        o_ = np.argsort(key, kind="stable")
+        ks, u, v = ks[o_], u[o_], v[o_]
+    Ts = {k: _pose_matrix(k) for k in range(k_lo, k_hi)}
+    Rm = np.stack([Ts[k][:3, :3] for k in range(k_lo, k_hi)]); Cm = np.stack([Ts[k][:3, 3] for k in range(k_lo, k_hi)])
+    dc = np.stack([(u - intr["cx"]) / intr["fx"], (v - intr["cy"]) / intr["fy"], np.ones(n)], axis=1)
+    R = Rm[ks - k_lo]; cw = Cm[ks - k_lo]
+    dw = np.einsum("nij,nj->ni", R, dc)
+    t, nrm, _ = cast(scene, cw, dw)
+    far = rng.random(n) < floating
+    shift = np.where(far, np.minimum(rng.uniform(1.2, 2.0, n), 0.7 * t), 0.0)
+    p = cw + dw * (t - shift)[:, None] + nrm * rng.normal(0, scatter, n)[:, None]
+    fl = rng.random(n) < flip
+    nv = nrm * np.where(fl, -1.0, 1.0)[:, None] + rng.normal(0, 0.05, size=(n, 3))
+    nv /= np.linalg.norm(nv, axis=1, keepdims=True)
+    m = np.zeros(n, surfel_dtype())
+    m["px"], m["py"], m["pz"] = p[:, 0], p[:, 1], p[:, 2]
+    m["nx"], m["ny"], m["nz"] = nv[:, 0], nv[:, 1], nv[:, 2]
+    m["size"] = rng.uniform(0.005, 0.03, n)
+    m["color"] = rng.integers(0, 256, n)
+    m["r"] = m["g"] = m["b"] = rng.integers(0, 256, n)
+    m["weight"] = rng.uniform(1, 20, n)
+    m["updateTimes"] = rng.integers(min_update_times, 21, n)
+    m["lastUpdate"] = ref - rng.integers(0, 9, n)
+    return m
+
+
+def in_view_fraction(m, k, w=640, h=480, intr=TUM1, near=0.5, far=30.0):
+    """Share of the surfels m that keyframe k's fuse step finds in range and inside the image (src/SurfelFusion.cpp:196-207)."""
+    T = np.linalg.inv(_pose_matrix(k))
+    p = np.stack([m["px"], m["py"], m["pz"]], 1).astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pu = np.floor(p[:, 0] * intr["fx"] / p[:, 2] + intr["cx"] + 0.5); pv = np.floor(p[:, 1] * intr["fy"] / p[:, 2] + intr["cy"] + 0.5)
+    ok = (p[:, 2] >= near) & (p[:, 2] <= far) & (pu >= 1) & (pu <= w - 2) & (pv >= 1) & (pv <= h - 2)
+    return float(ok.mean())
