@@ -49,17 +49,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md): 8
 SURFEL_BYTES = 56              # sizeof(Surfel), reference include/Surfel.h:28-37
 
 CONFIGS = {
-    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=13,
+    "frontend": dict(orb=True, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=13, map="dense",
                      name="ORB (1000 features, 8 levels, 1.2, FAST 20/7) + SurfelFusion on every frame"),
     "2": dict(orb=True, sf=False, size="640x480", intr="TUM1", variant="A", kfe=1, passes=56, orb_batch=128,
               name="BASELINE config 2: ORBextractor only (128 frames per call: alone, its launch sequences amortise better than in 32-frame calls, 94.8 k vs "
                    "81.7 k frames/s; next to the surfel stage the call size makes no difference)"),
-    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=15, name="BASELINE config 3: SurfelFusion only"),
-    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_pass=512, passes=7,
+    "3": dict(orb=False, sf=True, size="640x480", intr="TUM1", variant="A", kfe=1, passes=15, map="dense", name="BASELINE config 3: SurfelFusion only"),
+    "4": dict(orb=True, sf=True, size="640x480", intr="ICL", variant="A", kfe=4, peac=True, dropout=0.001, frames_per_pass=512, passes=7, map="dense", scene="clutter",
               name="BASELINE config 4: ICL-NUIM intrinsics (fy < 0), ORB every frame + PEAC plane extractor and SurfelFusion every k-th "
                    "frame (block fit and agglomerative clustering on the GPU, erosion / region growing on host threads; its membership "
                    "image feeds the fusion)"),
-    "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1, passes=3,
+    "5": dict(orb=True, sf=True, size="1280x960", intr="TUM1", variant="A", kfe=1, passes=3, map="dense",
               name="BASELINE config 5: ORB + SurfelFusion on every frame, 1280x960 sequences"),
 }
 
@@ -85,6 +85,11 @@ def parse(argv=None):
                     "so its launch sequences amortise better over more frames than the surfel stage's 32-keyframe calls allow")
     ap.add_argument("--distinct-frames", type=int, default=64, help="distinct synthetic frames generated per sequence (SURVEY.md 8(d): 64), tiled to a pass")
     ap.add_argument("--surfels", type=int, default=1_000_000)
+    ap.add_argument("--map", default=None, choices=["dense", "sparse"], help="pre-seeded live map: dense = ~35 %% of it inside the frustum of every keyframe (SURVEY.md "
+                    "8(d) config 3 as written; the default of every configuration); sparse = the area-uniform room map of rounds 1-3 (~6 %% in view)")
+    ap.add_argument("--map-order", default="creation", choices=["creation", "random"], help="array order of the dense map: creation = (source keyframe, superpixel) as "
+                    "initializeSurfels appends surfels; random = no locality between array neighbours")
+    ap.add_argument("--scene", default=None, choices=["room", "clutter"], help="depth / membership content: the bare box room or the furnished room (config 4's default)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the single-thread CPU-baseline sample (0 = no CPU baseline)")
     ap.add_argument("--no-breakdown", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launcher / aggregation / device-binding check on CPU (gloo), no GPU work, fabricated timings")
@@ -109,24 +114,17 @@ def self_launch(args):
 
 
 def sequence_seeds(rank):
-    """Seeds of rank r's independent sequence ('seeds offset by rank')."""
-    return {"frame": 7 + 1000 * rank, "orb": 20210530 + 1000 * rank, "map": 11 + rank}
+    from manhattanslam_amd import synth
+    return synth.sequence_seeds(rank)
 
 
-def build_inputs(rank, D, n_surfels, W, H, intr, variant, need_orb_texture=True, dropout=0.02):
-    """D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host)."""
+def build_inputs(rank, D, n_surfels, W, H, intr, cfg, args):
+    """D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host): manhattanslam_amd.synth.bench_inputs."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
-    sd = sequence_seeds(rank)
-    grays, depths, poses = [], [], []
-    member = None
-    for f in range(D):
-        g, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=sd["frame"], dropout=dropout)
-        # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
-        grays.append(synth.orb_frame(sd["orb"] + f, W, H) if need_orb_texture else g)
-        depths.append(depth)
-        poses.append(pose)
-    smap = synth.surfel_map(n_surfels, ref=0, seed=sd["map"], min_update_times=5).astype(SURFEL_DTYPE)
-    return np.stack(grays), np.stack(depths), member, poses, smap
+    g, d, member, poses, smap = synth.bench_inputs(rank, D, n_surfels, W, H, intr, variant=cfg["variant"], dropout=cfg.get("dropout", 0.02),
+                                                   map_kind=args.map or cfg.get("map", "dense"), map_order=args.map_order,
+                                                   scene=args.scene or cfg.get("scene", "room"))
+    return g, d, member, poses, smap.astype(SURFEL_DTYPE)
 
 
 def kernel_source_hash():
@@ -178,7 +176,8 @@ def cpu_baseline(args, cfg, W, H, kfe):
     """tools/cpu_baseline.py in its own interpreter: the oracle (a port: the reference cannot be built without OpenCV/Eigen)
     on bounded samples of the same workload -- 1 thread, the reference's 10-thread SurfelFusion, one sequence per host core."""
     cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--frames", str(args.cpu_frames), "--size", f"{W}x{H}",
-           "--intrinsics", cfg["intr"], "--surfels", str(args.surfels), "--keyframe-every", str(kfe)]
+           "--intrinsics", cfg["intr"], "--surfels", str(args.surfels), "--keyframe-every", str(kfe), "--map", args.map or cfg.get("map", "dense"),
+           "--map-order", args.map_order, "--scene", args.scene or cfg.get("scene", "room")]
     if not cfg["orb"]:
         cmd.append("--no-orb")
     if not cfg["sf"]:
@@ -269,7 +268,8 @@ def main():
     if OB % B or F % OB:
         raise SystemExit("--orb-batch must be a multiple of --batch and divide --frames-per-pass")
     intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
-    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg["variant"], dropout=cfg.get("dropout", 0.02))
+    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg, args)
+    map_kind, scene_kind = args.map or cfg.get("map", "dense"), args.scene or cfg.get("scene", "room")
     use_peac = bool(cfg.get("peac")) and do_sf
 
     orb = sf = None
@@ -459,6 +459,9 @@ def main():
                    "stationary": bool(reseed) or not do_sf,
                    "map_reseed": "msl_sf_map_restore (device-to-device, inside the timed region) at the start of every pass" if reseed else "none",
                    "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg),
+                   "map": (f"{map_kind} ({'~35 % of the map inside the frustum of every keyframe, SURVEY.md 8(d) config 3' if map_kind == 'dense' else 'area-uniform over the room, ~6 % in view'}"
+                           f"{', array order = ' + args.map_order if map_kind == 'dense' else ''})") if do_sf else None,
+                   "in_view_fraction_keyframe0": round(synth.in_view_fraction(smap, 0, W, H, intr), 4) if do_sf else None, "scene": scene_kind,
                    "surfels_updated_per_keyframe": round(avg_upd, 1), "surfels_new_per_keyframe": round(avg_new, 2), "surfels_deleted_per_keyframe": round(avg_del, 2),
                    "intrinsics": cfg["intr"], "membership": "PEAC plane extractor (msl_peac_membership_batch)" if use_peac else cfg["variant"],
                    "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4), "timed_frames_per_gpu": frames_rank},

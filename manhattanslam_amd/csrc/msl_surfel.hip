@@ -150,7 +150,9 @@ __device__ __forceinline__ void back_project(const SfDev &P, float u, float v, f
     y = (v - P.cy) / P.fy * d;
     z = d;
 }
-__device__ __forceinline__ float get_weight(float d) { return (float)fmin(1.0 / (double)d / (double)d, 1.0); }
+// std::min(1.0 / depth / depth, 1.0) (:87-89) is `(1.0 < a) ? 1.0 : a`: a NaN depth (a seed whose plane fit produced NaN) gives NaN, where
+// fmin() would give 1.0 -- found by the furnished-room parity tests of round 4.
+__device__ __forceinline__ float get_weight(float d) { const double a = 1.0 / (double)d / (double)d; return (float)(1.0 < a ? 1.0 : a); }
 __device__ __forceinline__ void mul4(const float *m, float v0, float v1, float v2, float v3, float out[4]) {
 #pragma unroll
     for (int r = 0; r < 4; r++) out[r] = ((m[r] * v0 + m[4 + r] * v1) + m[8 + r] * v2) + m[12 + r] * v3;

@@ -396,3 +396,35 @@ def in_view_fraction(m, k, w=640, h=480, intr=TUM1, near=0.5, far=30.0):
         pu = np.floor(p[:, 0] * intr["fx"] / p[:, 2] + intr["cx"] + 0.5); pv = np.floor(p[:, 1] * intr["fy"] / p[:, 2] + intr["cy"] + 0.5)
     ok = (p[:, 2] >= near) & (p[:, 2] <= far) & (pu >= 1) & (pu <= w - 2) & (pv >= 1) & (pv <= h - 2)
     return float(ok.mean())
+
+
+def sequence_seeds(rank):
+    """Seeds of rank r's independent sequence ('seeds offset by rank')."""
+    return {"frame": 7 + 1000 * rank, "orb": ORB_SEED + 1000 * rank, "map": 11 + rank}
+
+
+def bench_inputs(rank, D, n_surfels, W, H, intr, variant="A", dropout=0.02, need_orb_texture=True, map_kind="dense", map_order="creation",
+                 scene="room", flip=0.01, floating=0.003):
+    """The benchmark's workload, shared by bench.py and tools/cpu_baseline.py so that the GPU and the CPU baseline see the same bytes:
+    D distinct RGB-D frames of this rank's sequence + the pre-seeded live map (numpy, host).
+    map_kind "dense": surfel_map_dense (~35 % of the map inside the frustum of every keyframe: SURVEY.md 8(d) config 3 as written);
+    "sparse": the area-uniform room map of rounds 1-3 (~6 % in view).  scene "room": the bare box room; "clutter": the furnished room."""
+    sd = sequence_seeds(rank)
+    sc = clutter_scene() if scene == "clutter" else ROOM_ONLY
+    grays, depths, poses = [], [], []
+    member = None
+    for f in range(D):
+        if scene == "clutter":
+            g, depth, member, pose, _ = clutter_frame(f, w=W, h=H, intr=intr, seed=sd["frame"], scene=sc)
+        else:
+            g, depth, member, pose = surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=sd["frame"], dropout=dropout)
+        # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
+        grays.append(orb_frame(sd["orb"] + f, W, H) if need_orb_texture else g)
+        depths.append(depth)
+        poses.append(pose)
+    if map_kind == "dense":
+        smap = surfel_map_dense(n_surfels, ref=0, seed=sd["map"], w=W, h=H, intr=intr, scene=sc, flip=flip, floating=floating, min_update_times=5,
+                                order=map_order)
+    else:
+        smap = surfel_map(n_surfels, ref=0, seed=sd["map"], min_update_times=5)
+    return np.stack(grays), np.stack(depths), member, poses, smap

@@ -22,21 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_inputs(F, n_surfels, W, H, intr_name, rank=0):
+def build_inputs(F, n_surfels, W, H, intr_name, rank=0, map_kind="dense", map_order="creation", scene="room"):
     import importlib.util
     spec = importlib.util.spec_from_file_location("msl_synth", os.path.join(ROOT, "manhattanslam_amd", "synth.py"))
     synth = importlib.util.module_from_spec(spec)   # synth.py alone: importing the package would load libmsl.so / HIP
     spec.loader.exec_module(synth)
     intr = synth.scaled_intrinsics(getattr(synth, intr_name), W)
-    grays, depths, poses = [], [], []
-    member = None
-    for f in range(F):
-        _, depth, member, pose = synth.surfel_frame(f, w=W, h=H, intr=intr, seed=7 + 1000 * rank)
-        grays.append(synth.orb_frame(synth.ORB_SEED + 1000 * rank + f, W, H))
-        depths.append(depth)
-        poses.append(pose)
-    smap = synth.surfel_map(n_surfels, ref=0, seed=11 + rank, min_update_times=5)
-    return np.stack(grays), np.stack(depths), member, poses, smap, intr
+    grays, depths, member, poses, smap = synth.bench_inputs(rank, F, n_surfels, W, H, intr, map_kind=map_kind, map_order=map_order, scene=scene)
+    return grays, depths, member, poses, smap, intr
 
 
 def run_sequence(inp, W, H, n_frames, do_orb=True, do_sf=True, threads10=False, keyframe_every=1):
@@ -121,14 +114,17 @@ def main():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-surfel", action="store_true")
     ap.add_argument("--keyframe-every", type=int, default=1)
+    ap.add_argument("--map", default="dense", choices=["dense", "sparse"])
+    ap.add_argument("--map-order", default="creation", choices=["creation", "random"])
+    ap.add_argument("--scene", default="room", choices=["room", "clutter"])
     args = ap.parse_args()
     W, H = (int(v) for v in args.size.lower().split("x"))
     do_orb, do_sf, kfe = not args.no_orb, not args.no_surfel, args.keyframe_every
-    inp = build_inputs(args.distinct_frames, args.surfels if do_sf else 16, W, H, args.intrinsics)
+    inp = build_inputs(args.distinct_frames, args.surfels if do_sf else 16, W, H, args.intrinsics, map_kind=args.map, map_order=args.map_order, scene=args.scene)
     ncpu = usable_cpus()
     out = {"host_cpus": os.cpu_count() or 1, "usable_cpus": ncpu, "kind": "port",
            "code": "oracle/libmsl_oracle.so (CPU restatement of src/ORBextractor.cc + src/SurfelFusion.cpp + SurfelMapping::fuseMap; g++ -O3, no -march=native)"}
-    what = ("ORB + " if do_orb else "") + (f"SurfelFusion every {kfe} frame(s), {args.surfels} seeded surfels" if do_sf else "no surfel stage")
+    what = ("ORB + " if do_orb else "") + (f"SurfelFusion every {kfe} frame(s), {args.surfels} seeded surfels ({args.map} map, {args.scene} scene)" if do_sf else "no surfel stage")
 
     if args.frames > 0:
         tb, te, t_orb, t_sf, nkf = run_sequence(inp, W, H, args.frames, do_orb, do_sf, False, kfe)

@@ -14,7 +14,9 @@ grays = np.stack([synth.orb_frame(synth.ORB_SEED + f) for f in range(64)]); dept
 poses = [f[3] for f in frames]
 sf = SurfelFusion(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
 sf.set_batch_capacity(B); sf.map_reserve(2200000)
-sf.map_upload(synth.surfel_map(1000000, ref=0, seed=11, min_update_times=5).astype(SURFEL_DTYPE)); sf.map_snapshot()
+dense = os.environ.get("MAP", "dense")
+smap = synth.surfel_map(1000000, ref=0, seed=11, min_update_times=5) if dense == "sparse" else synth.surfel_map_dense(1000000, order=os.environ.get("ORDER", "creation"))
+sf.map_upload(smap.astype(SURFEL_DTYPE)); sf.map_snapshot()
 orb = ORBextractor(1000, 1.2, 8, 20, 7, max_batch=B)
 dg = torch.from_numpy(grays).cuda().repeat(F // 64, 1, 1).contiguous(); dd = torch.from_numpy(depths).cuda().repeat(F // 64, 1, 1).contiguous(); dm = torch.from_numpy(member).cuda()
 cap = orb.capacity
@@ -52,7 +54,13 @@ np.save(f"gpurun_out/fuse_stamps_{'alone' if alone else ('noorb' if os.environ.g
 pc = lambda a: [round(float(np.percentile(a, q)), 2) for q in (5, 25, 50, 75, 95, 100)]
 print("k_compact workgroup 0 (us): loads %.2f, scans %.2f, emission %.2f, tail %.2f; after k_fuse's first wave start: start %.2f end %.2f; K=%d D=%d" % (
     (cst[1] - cst[0]) * 0.01, (cst[2] - cst[1]) * 0.01, (cst[3] - cst[2]) * 0.01, (cst[4] - cst[3]) * 0.01, (cst[0] - base) * 0.01, (cst[4] - base) * 0.01, cst[5], cst[6]))
-print(json.dumps({"lib": os.environ.get("MSL_LIB", "default"), "alone": alone, "waves": int(nsub), "kernel_span_us": round(float(end.max()), 2),
+dense_w = w[:, 7] == 1
+order = np.argsort(w[:, 0].astype(np.int64))
+print("per-decile of wave START order: mean lifetime us / mean survivors / dense share:", [(round(float(life[o].mean()), 1), int(tot[o].mean()), round(float(dense_w[o].mean()), 2)) for o in np.array_split(order, 10)])
+print("lifetime by survivors bucket (0, 1-63, 64-127, 128-191, 192-256):", [round(float(life[(tot >= a) & (tot <= b)].mean()), 2) if ((tot >= a) & (tot <= b)).any() else None for a, b in ((0, 0), (1, 63), (64, 127), (128, 191), (192, 256))],
+      "counts", [int(((tot >= a) & (tot <= b)).sum()) for a, b in ((0, 0), (1, 63), (64, 127), (128, 191), (192, 256))])
+print("phase A by survivors bucket:", [round(float(gather[(tot >= a) & (tot <= b)].mean()), 2) if ((tot >= a) & (tot <= b)).any() else None for a, b in ((0, 0), (1, 63), (64, 127), (128, 191), (192, 256))])
+print(json.dumps({"lib": os.environ.get("MSL_LIB", "default"), "alone": alone, "map": dense, "waves": int(nsub), "kernel_span_us": round(float(end.max()), 2),
                   "start_delay_us_pct": pc(start), "phaseA_us_pct": pc(gather), "lifetime_us_pct": pc(life), "survivors_pct": pc(tot),
                   "waves_per_xcc": np.bincount(xcc, minlength=8).tolist(), "pipe_ids": np.bincount((w[:, 4] >> 6) & 3, minlength=4).tolist(), "queue_ids": np.bincount((w[:, 4] >> 24) & 7, minlength=8).tolist(),
                   "slot_ids": np.bincount(w[:, 4] & 15, minlength=8).tolist(),
