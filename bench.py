@@ -85,6 +85,8 @@ def parse(argv=None):
                     "so its launch sequences amortise better over more frames than the surfel stage's 32-keyframe calls allow")
     ap.add_argument("--distinct-frames", type=int, default=64, help="distinct synthetic frames generated per sequence (SURVEY.md 8(d): 64), tiled to a pass")
     ap.add_argument("--surfels", type=int, default=1_000_000)
+    ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent RGB-D sequences per GPU, each with its own handles, streams, resident map and host "
+                    "thread (the weak-scaling unit stays the sequence; BASELINE's shape is 1).  `value` is the total over all sequences")
     ap.add_argument("--map", default=None, choices=["dense", "sparse"], help="pre-seeded live map: dense = ~35 %% of it inside the frustum of every keyframe (SURVEY.md "
                     "8(d) config 3 as written; the default of every configuration); sparse = the area-uniform room map of rounds 1-3 (~6 %% in view)")
     ap.add_argument("--map-order", default="creation", choices=["creation", "random"], help="array order of the dense map: creation = (source keyframe, superpixel) as "
@@ -218,9 +220,10 @@ def dry_run(args, world, rank, local_rank):
         dist.barrier()
     cfg, W, H, kfe, F, P, B, D = geometry(args)
     local_ms = 10.0 + 5.0 * rank
-    sd = sequence_seeds(rank)
-    counters = [args.steps * P * F, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
-    binding = [rank, local_rank, local_rank, sd["frame"], sd["orb"], sd["map"], int(os.environ.get("LOCAL_WORLD_SIZE", world)), 0]
+    S = max(1, args.sequences_per_gpu)
+    sd = sequence_seeds(rank * S)                      # this rank's sequences are the global sequences rank * S .. rank * S + S - 1
+    counters = [args.steps * P * F * S, 1000 * (rank + 1), 990000 + rank, 3, 50000, 7, int(local_ms * 1e6), 1000000]
+    binding = [rank, local_rank, local_rank, sd["frame"], sd["orb"], sd["map"], int(os.environ.get("LOCAL_WORLD_SIZE", world)), S]
     total_ms, gathered = aggregate(local_ms, counters, world, None)
     _, bindings = aggregate(local_ms, binding, world, None)
     if rank == 0:
@@ -231,7 +234,8 @@ def dry_run(args, world, rank, local_rank):
                           "dry_run": True, "data": "none (fabricated timings: launcher / gloo aggregation / binding check only)",
                           "config": {"config": args.config, "frames_per_pass": F, "passes_per_step": P},
                           "counters_per_rank": gathered,
-                          "binding_per_rank": [dict(zip(("rank", "local_rank", "device", "frame_seed", "orb_seed", "map_seed", "local_world_size"), b)) for b in bindings]}),
+                          "binding_per_rank": [dict(zip(("rank", "local_rank", "device", "frame_seed", "orb_seed", "map_seed", "local_world_size", "sequences"), b)) for b in bindings],
+                          "sequences_per_gpu": S, "global_sequences_per_rank": [[b[0] * S + i for i in range(S)] for b in bindings]}),
               flush=True)
     if world > 1:
         dist.barrier()
@@ -268,113 +272,144 @@ def main():
     if OB % B or F % OB:
         raise SystemExit("--orb-batch must be a multiple of --batch and divide --frames-per-pass")
     intr = synth.scaled_intrinsics(getattr(synth, cfg["intr"]), W)
-    grays, depths, member, poses, smap = build_inputs(rank, D, args.surfels if do_sf else 16, W, H, intr, cfg, args)
+    S = max(1, args.sequences_per_gpu)
     map_kind, scene_kind = args.map or cfg.get("map", "dense"), args.scene or cfg.get("scene", "room")
     use_peac = bool(cfg.get("peac")) and do_sf
 
-    orb = sf = None
-    d_gray = torch.from_numpy(grays).to(dev).repeat(F // D, 1, 1).contiguous()
-    if do_orb:
-        orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=OB, device=local_rank)
-        cap = orb.capacity
-        d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
-        d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
-        d_n = torch.zeros(F, dtype=torch.int32, device=dev)
-    if do_sf:
-        sf = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=local_rank)
-        sf.set_batch_capacity(nkf)
-        sf.map_reserve(2 * args.surfels + 65536)
-        sf.map_upload(smap)
-        sf.map_snapshot()
-        d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
-        d_member = torch.from_numpy(member).to(dev)
-        if use_peac:
-            from manhattanslam_amd import peac
-            # raw 16-bit depth of the keyframes (5000 units per metre), resident in HBM like the other inputs
-            d_depth16 = torch.from_numpy(np.stack([synth.depth_u16(d) for d in depths]).view(np.int16)).to(dev).repeat(F // D, 1, 1).contiguous()
-            peac_prm = peac.default_params()
-            # The extractor of the NEXT pass's keyframes runs on a host thread (block fit on the GPU, clustering on the library's worker
-            # threads) while this pass's ORB / SurfelFusion calls are enqueued, the way the reference runs plane extraction in the tracking
-            # thread and surfel mapping in its own (src/Tracking.cc:228, src/SurfelMapping.cpp:46-60).  Every timed pass still pays one full
-            # extraction of its nkf * nsub keyframes: the one in flight at the end of the region is waited for inside it (sync_all).
-            import concurrent.futures
-            h_member = [np.zeros((nkf * nsub, H // 2, W // 2), np.int32) for _ in range(2)]
-            h_nplanes = [np.zeros(nkf * nsub, np.int32) for _ in range(2)]
-            peac_pool = concurrent.futures.ThreadPoolExecutor(1)
-            peac_job = [None, 0]   # (future, buffer index)
+    def make_seq(s_idx):
+        """One independent RGB-D sequence on this GPU: its own inputs (seeds of global sequence rank * S + s_idx), extractor and fusion handles
+        (own streams, own resident map) and the closures that enqueue its passes."""
+        grays, depths, member, poses, smap = build_inputs(rank * S + s_idx, D, args.surfels if do_sf else 16, W, H, intr, cfg, args)
 
-            def peac_submit():
-                b = peac_job[1] ^ 1
-                peac_job[0] = peac_pool.submit(peac.plane_membership_device, d_depth16, kfe, nkf * nsub, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"],
-                                               np.float32(1.0 / 5000.0), peac_prm, h_member[b], h_nplanes[b], local_rank)
-                peac_job[1] = b
-        kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
-    torch.cuda.synchronize()
-
-    kf_no = [0]
-    peac_dev = [None]
-    cap_ = orb.capacity if do_orb else 0
-
-    def sub_orb(sb):   # the ORB call that starts at surfel call sb (one ORB call covers OB / B surfel calls)
-        if (sb * B) % OB == 0:
-            orb.extract_batch_device(d_gray[sb * B:], d_kps[sb * B * cap_ * 28:], d_desc[sb * B * cap_ * 32:], d_n[sb * B:], OB, W, H)
-
-    def sub_sf(sb):
-        if use_peac:
-            if sb == 0:
-                # plane membership of this pass's keyframes (one call: block fit on the GPU, clustering on one host thread per keyframe),
-                # computed while the previous pass was enqueued; back to HBM, then start the next pass's
-                if peac_job[0] is None:
-                    peac_submit()
-                peac_job[0].result()
-                peac_dev[0] = torch.from_numpy(h_member[peac_job[1]]).to(dev)
-                peac_submit()
-            sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], peac_dev[0][sb * nkf:], kf_poses[sb], device=True,
-                                   member_shared=False, frame_step=kfe, member_frame_step=1)
-            kf_no[0] += nkf
-            return
-        # the superpixel stage of a call's keyframes is frame-batched, the map stage runs keyframe after keyframe
-        sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], d_member, kf_poses[sb], device=True,
-                               member_shared=True, frame_step=kfe)
-        kf_no[0] += nkf
-
-    def begin_pass():
-        if reseed:           # the pre-seeded map again (device-to-device, asynchronous on the map stream), keyframe numbering from 0
-            sf.map_restore()
-            kf_no[0] = 0
-
-    def pass_orb():
-        for sb in range(nsub):
-            sub_orb(sb)
-
-    def pass_sf():
-        begin_pass()
-        for sb in range(nsub):
-            sub_sf(sb)
-
-    def one_pass():
-        begin_pass()
-        for sb in range(nsub):
-            if do_orb:
-                sub_orb(sb)
-            if do_sf:
-                sub_sf(sb)
-
-    def step():
-        for _ in range(P):
-            one_pass()
-
-    def sync_all():
-        if use_peac and peac_job[0] is not None:
-            peac_job[0].result()
+        orb = sf = None
+        d_gray = torch.from_numpy(grays).to(dev).repeat(F // D, 1, 1).contiguous()
         if do_orb:
-            orb.sync()
+            orb = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=OB, device=local_rank)
+            cap = orb.capacity
+            d_kps = torch.zeros(F * cap * 28, dtype=torch.uint8, device=dev)
+            d_desc = torch.zeros(F * cap * 32, dtype=torch.uint8, device=dev)
+            d_n = torch.zeros(F, dtype=torch.int32, device=dev)
         if do_sf:
-            sf.sync()
+            sf = SurfelFusion(W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"], 30.0, 0.5, device=local_rank)
+            sf.set_batch_capacity(nkf)
+            sf.map_reserve(2 * args.surfels + 65536)
+            sf.map_upload(smap)
+            sf.map_snapshot()
+            d_depth = torch.from_numpy(depths).to(dev).repeat(F // D, 1, 1).contiguous()
+            d_member = torch.from_numpy(member).to(dev)
+            if use_peac:
+                from manhattanslam_amd import peac
+                # raw 16-bit depth of the keyframes (5000 units per metre), resident in HBM like the other inputs
+                d_depth16 = torch.from_numpy(np.stack([synth.depth_u16(d) for d in depths]).view(np.int16)).to(dev).repeat(F // D, 1, 1).contiguous()
+                peac_prm = peac.default_params()
+                # The extractor of the NEXT pass's keyframes runs on a host thread (block fit on the GPU, clustering on the library's worker
+                # threads) while this pass's ORB / SurfelFusion calls are enqueued, the way the reference runs plane extraction in the tracking
+                # thread and surfel mapping in its own (src/Tracking.cc:228, src/SurfelMapping.cpp:46-60).  Every timed pass still pays one full
+                # extraction of its nkf * nsub keyframes: the one in flight at the end of the region is waited for inside it (sync_all).
+                import concurrent.futures
+                h_member = [np.zeros((nkf * nsub, H // 2, W // 2), np.int32) for _ in range(2)]
+                h_nplanes = [np.zeros(nkf * nsub, np.int32) for _ in range(2)]
+                peac_pool = concurrent.futures.ThreadPoolExecutor(1)
+                peac_job = [None, 0]   # (future, buffer index)
+
+                def peac_submit():
+                    b = peac_job[1] ^ 1
+                    peac_job[0] = peac_pool.submit(peac.plane_membership_device, d_depth16, kfe, nkf * nsub, W, H, intr["fx"], intr["fy"], intr["cx"], intr["cy"],
+                                                   np.float32(1.0 / 5000.0), peac_prm, h_member[b], h_nplanes[b], local_rank)
+                    peac_job[1] = b
+            kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+        kf_no = [0]
+        peac_dev = [None]
+        cap_ = orb.capacity if do_orb else 0
+
+        def sub_orb(sb):   # the ORB call that starts at surfel call sb (one ORB call covers OB / B surfel calls)
+            if (sb * B) % OB == 0:
+                orb.extract_batch_device(d_gray[sb * B:], d_kps[sb * B * cap_ * 28:], d_desc[sb * B * cap_ * 32:], d_n[sb * B:], OB, W, H)
+
+        def sub_sf(sb):
+            if use_peac:
+                if sb == 0:
+                    # plane membership of this pass's keyframes (one call: block fit on the GPU, clustering on one host thread per keyframe),
+                    # computed while the previous pass was enqueued; back to HBM, then start the next pass's
+                    if peac_job[0] is None:
+                        peac_submit()
+                    peac_job[0].result()
+                    peac_dev[0] = torch.from_numpy(h_member[peac_job[1]]).to(dev)
+                    peac_submit()
+                sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], peac_dev[0][sb * nkf:], kf_poses[sb], device=True,
+                                       member_shared=False, frame_step=kfe, member_frame_step=1)
+                kf_no[0] += nkf
+                return
+            # the superpixel stage of a call's keyframes is frame-batched, the map stage runs keyframe after keyframe
+            sf.fuse_resident_batch(np.arange(kf_no[0], kf_no[0] + nkf), d_gray[sb * B:], d_depth[sb * B:], d_member, kf_poses[sb], device=True,
+                                   member_shared=True, frame_step=kfe)
+            kf_no[0] += nkf
+
+        def begin_pass():
+            if reseed:           # the pre-seeded map again (device-to-device, asynchronous on the map stream), keyframe numbering from 0
+                sf.map_restore()
+                kf_no[0] = 0
+
+        def pass_orb():
+            for sb in range(nsub):
+                sub_orb(sb)
+
+        def pass_sf():
+            begin_pass()
+            for sb in range(nsub):
+                sub_sf(sb)
+
+        def one_pass():
+            begin_pass()
+            for sb in range(nsub):
+                if do_orb:
+                    sub_orb(sb)
+                if do_sf:
+                    sub_sf(sb)
+
+        def step():
+            for _ in range(P):
+                one_pass()
+
+        def sync_all():
+            if use_peac and peac_job[0] is not None:
+                peac_job[0].result()
+            if do_orb:
+                orb.sync()
+            if do_sf:
+                sf.sync()
+            torch.cuda.synchronize()
+
+        import types
+        return types.SimpleNamespace(**{k: v for k, v in locals().items() if k != "types"})
+
+    seqs = [make_seq(i) for i in range(S)]
+    q0 = seqs[0]    # the primary sequence: carries the roofline kernel's events and the per-kernel breakdown
+    grays, depths, member, poses, smap, orb, sf = q0.grays, q0.depths, q0.member, q0.poses, q0.smap, q0.orb, q0.sf
+    step, one_pass, pass_orb, pass_sf, begin_pass, sub_sf = q0.step, q0.one_pass, q0.pass_orb, q0.pass_sf, q0.begin_pass, q0.sub_sf
+    d_n = q0.d_n if do_orb else None
+    nkf_nsub = nkf * nsub
+
+    def run_steps(k):
+        """k steps of every sequence: one host thread per sequence beyond the first (the library calls release the GIL)."""
+        if S == 1:
+            for _ in range(k):
+                step()
+            return
+        import threading
+        th = [threading.Thread(target=lambda q=q: [q.step() for _ in range(k)]) for q in seqs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    def sync_all():
+        for q in seqs:
+            q.sync_all()
+
+    run_steps(args.warmup)
     sync_all()
     n_live_start = int(len(smap)) if reseed else (sf.counters()["n_live_after"] if do_sf else 0)
     tot0 = sf.debug_ctr() if do_sf else None
@@ -391,8 +426,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     sync_all()
     if world > 1:
         dist.barrier()
@@ -410,8 +444,8 @@ def main():
         orb.profile_enable(0)
     ctr = sf.counters() if do_sf else dict(n_live_after=0, n_new=0, n_updated=0, n_deleted=0)
     tot1 = sf.debug_ctr() if do_sf else None
-    n_kp_pass = int(d_n.sum().item()) if do_orb else 0
-    frames_rank = args.steps * P * F
+    n_kp_pass = sum(int(q.d_n.sum().item()) for q in seqs) if do_orb else 0       # all sequences of this GPU
+    frames_rank = args.steps * P * F * S
     counters = [frames_rank, n_kp_pass * args.steps * P, ctr["n_live_after"], ctr["n_new"], ctr["n_updated"], ctr["n_deleted"], int(local_ms * 1e6), n_live_start]
     total_ms, gathered = aggregate(local_ms, counters, world, dev)
 
@@ -442,7 +476,7 @@ def main():
     achieved_rw = (alg_bytes + alg_write) / launch_s / 1e9 if roof_launches else 0.0
     # R = 2 sum P_l per frame + (56 N_live + 5 W H + 4 (W/2)(H/2)) per keyframe; W = (sum_{l>=1} P_l + sum P_l + 60 N_kp)
     # per frame + 56 (N_updated + N_new) per keyframe
-    n_kp_frame = n_kp_pass / F if do_orb else 0.0
+    n_kp_frame = n_kp_pass / (F * S) if do_orb else 0.0
     r_frame = (2 * sum_pl if do_orb else 0) + ((SURFEL_BYTES * n_live_avg + 5 * W * H + W * H) / kfe if do_sf else 0)
     w_frame = ((2 * sum_pl - W * H + 60 * n_kp_frame) if do_orb else 0) + (SURFEL_BYTES * (avg_upd + avg_new) / kfe if do_sf else 0)
     traffic, traffic_src = pmc_traffic(roof_kernel, args.config)
@@ -464,7 +498,7 @@ def main():
                    "in_view_fraction_keyframe0": round(synth.in_view_fraction(smap, 0, W, H, intr), 4) if do_sf else None, "scene": scene_kind,
                    "surfels_updated_per_keyframe": round(avg_upd, 1), "surfels_new_per_keyframe": round(avg_new, 2), "surfels_deleted_per_keyframe": round(avg_del, 2),
                    "intrinsics": cfg["intr"], "membership": "PEAC plane extractor (msl_peac_membership_batch)" if use_peac else cfg["variant"],
-                   "sequences_per_gpu": 1, "timed_region_s": round(total_ms * 1e-3, 4), "timed_frames_per_gpu": frames_rank},
+                   "sequences_per_gpu": S, "per_sequence_ms_per_pass": round(total_ms / (args.steps * P), 4), "timed_region_s": round(total_ms * 1e-3, 4), "timed_frames_per_gpu": frames_rank},
         "roofline": {"bound": "hbm", "kernel": roof_kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": traffic_src,

@@ -20,6 +20,10 @@
  *
  * There is NO CPU fallback: creation fails with MSL_ERR_NO_DEVICE when no gfx950 device is
  * usable.  The CPU oracle under oracle/ is test infrastructure and is not linked here.
+ *
+ * This header is the drop-in surface only.  The accessors the parity tests and bench.py use to look inside a handle (intermediate
+ * stages, device counters, per-kernel HIP-event timing) are declared in msl_debug.h: exported by the same library, not part of the
+ * boundary a maintainer of the reference binds.
  */
 #ifndef MSL_H
 #define MSL_H
@@ -70,7 +74,7 @@ typedef struct msl_surfel {
 } msl_surfel;
 
 /* Same layout as SurfelFusion::SuperpixelSeed (include/SurfelFusion.h:46-58), 64 bytes.
- * Only used by the debug accessors that let the parity tests look at intermediate stages. */
+ * Only used by the debug accessors of msl_debug.h that let the parity tests look at intermediate stages. */
 typedef struct msl_seed {
     float x, y;
     float size;
@@ -105,7 +109,9 @@ MSL_API int msl_orb_scale_tables(const msl_orb *h, float *scaleFactors, float *i
                                  float *levelSigma2, float *invLevelSigma2);
 /* mnFeaturesPerLevel (src/ORBextractor.cc:433-445). */
 MSL_API int msl_orb_features_per_level(const msl_orb *h, int32_t *out);
-/* Upper bound on keypoints per frame: nfeatures + 2*nlevels (src/ORBextractor.cc:691-696). */
+/* Upper bound on keypoints per frame: nfeatures + 2*nlevels (the one-by-one phase of DistributeOctTree overshoots a level's quota by at most 2,
+ * src/ORBextractor.cc:691-696); for frames at least ~4 times as wide as high with a small budget the first quadtree round alone returns up to
+ * 4 * round(width / height) nodes per level (:536-552, 575-640), and the capacity of an extractor created for such a frame size includes them. */
 MSL_API int msl_orb_capacity(const msl_orb *h);
 MSL_API int msl_orb_levels(const msl_orb *h);
 
@@ -150,22 +156,6 @@ MSL_API int msl_orb_sync(msl_orb *h);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
 MSL_API int msl_orb_set_stream(msl_orb *h, void *hip_stream);
 
-/* Debug accessors for the parity tests (host output, synchronous, after an extract call):
- * pyramid level image of frame f (unpadded, tightly packed w*h), its blurred version, and the
- * FAST candidates handed to the quadtree (x,y in level pixel coords, response), in order. */
-MSL_API int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out);
-MSL_API int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out);
-MSL_API int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys /*3 ints each*/,
-                                     int cap, int *n_out);
-/* Per-kernel timing with HIP events on the handle's stream.  mode 0 = off, -1 = every kernel,
- * otherwise a bit mask of kernel ids (bit k = time kernel k only, so a timed region can carry a
- * single kernel's events).  msl_orb_profile_read returns accumulated milliseconds and launch
- * counts per kernel since the last enable call. */
-#define MSL_ORB_NKERNELS 6
-MSL_API int msl_orb_profile_enable(msl_orb *h, int mode);
-MSL_API int msl_orb_profile_read(msl_orb *h, float *ms /*[MSL_ORB_NKERNELS]*/,
-                                 int32_t *launches /*[MSL_ORB_NKERNELS]*/);
-MSL_API const char *msl_orb_kernel_name(int k);
 
 /* ------------------------------------------------------------------------------------------
  * Surfel fusion
@@ -336,7 +326,7 @@ MSL_API int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uin
  * last-frame keypoint whose MapPoint current keypoint i2 holds, or -1 (NULL); nmatches[f] is the function's return value.
  * The greedy, order-dependent assignment of the reference (a candidate already held by a point with Observations() > 0 is
  * skipped, later points overwrite earlier ones) is reproduced exactly.  Limits: cap <= 8192, nlevels <= MSL_MATCH_MAX_LEVELS.
- * Synchronous; `mem` / `out_mem` say where the input / the two output arrays live. */
+ * `mem` / `out_mem` say where the input / the two output arrays live. */
 #define MSL_MATCH_MAX_LEVELS 16
 typedef struct msl_match_params {
     float fx, fy, cx, cy;             /* CurrentFrame.fx .. cy */
@@ -347,6 +337,26 @@ typedef struct msl_match_params {
     int32_t nlevels;
     float scale_factors[MSL_MATCH_MAX_LEVELS];   /* CurrentFrame.mvScaleFactors (msl_orb_scale_tables) */
 } msl_match_params;
+/* One matcher handle = one ORBmatcher object of the reference (src/ORBmatcher.cc:41): its own HIP stream and its own grow-only scratch and staging
+ * buffers, used by one thread at a time, device re-bound at every entry.  msl_match_by_projection is asynchronous on the handle's stream when inputs
+ * AND outputs are device memory (msl_match_sync / msl_match_set_stream as for the other handles); with host memory on either side it returns when the
+ * caller's buffers are its own again. */
+typedef struct msl_match msl_match;
+MSL_API msl_match *msl_match_create(int device);
+MSL_API void msl_match_destroy(msl_match *h);
+MSL_API int msl_match_sync(msl_match *h);
+MSL_API int msl_match_set_stream(msl_match *h, void *hip_stream);
+MSL_API int msl_match_by_projection(msl_match *h, int n_pairs, int cap, const msl_match_params *params,
+                                    const msl_keypoint *cur_kps, const float *cur_un_xy, const float *cur_uright,
+                                    const int32_t *cur_grid_cell, const uint8_t *cur_desc, const int32_t *n_cur,
+                                    const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
+                                    const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
+                                    const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out,
+                                    int32_t *nmatches, msl_mem out_mem);
+/* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:835-849) for n descriptor pairs (host arrays, synchronous; parity hook for the popcount path). */
+MSL_API int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out);
+/* Device-indexed convenience forms of the two calls above: a lazily created handle per device shared by all callers (serialised), always
+ * synchronous; device-resident inputs must be complete, or enqueued on the legacy default stream, when the call is made. */
 MSL_API int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params,
                                           const msl_keypoint *cur_kps, const float *cur_un_xy, const float *cur_uright,
                                           const int32_t *cur_grid_cell, const uint8_t *cur_desc, const int32_t *n_cur,
@@ -354,7 +364,6 @@ MSL_API int msl_match_by_projection_batch(int device, int n_pairs, int cap, cons
                                           const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
                                           const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out,
                                           int32_t *nmatches, msl_mem out_mem);
-/* ORBmatcher::DescriptorDistance for n descriptor pairs (host arrays; parity hook for the popcount path). */
 MSL_API int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out);
 
 /* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
@@ -372,33 +381,6 @@ MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]);
 MSL_API int msl_sf_sync(msl_sf *h);
 MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
 
-/* Debug accessors (host output, synchronous): superpixel seeds and the pixel->seed index map
- * as left by the last fuse call. */
-MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
-MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
-/* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
- * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
- * surfels before each keyframe; 13: some record keeps wide r, g, b; 14-15: spare). */
-MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
-/* n_words 32-bit words from offset_words of one of the compaction's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list;
- * host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
- * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
-/* Mean time (us) an event pair carried by a dispatch reports for an EMPTY kernel of `grid` single-wave workgroups on the map stream (n launches):
- * the measurement overhead contained in msl_sf_profile_read's per-kernel times (rocprofv3's kernel durations do not contain it). */
-MSL_API int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us);
-MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words);
-
-/* Test hook (host only): mse_out[i] = the MSE ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183) reports for stats[i], evaluated by the
- * scalar code (lanes = 0) or by the clustering's lock-step SIMD form with `lanes` (2, 4, 8, 16) candidates per group; MSL_ERR_INVALID if the CPU
- * lacks the instruction set that width is built for (4 and 8: AVX2, 16: AVX-512F). */
-MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out);
-/* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
-MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);
-
-#define MSL_SF_NKERNELS 12
-MSL_API int msl_sf_profile_enable(msl_sf *h, int mode);
-MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);
-MSL_API const char *msl_sf_kernel_name(int k);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,69 @@
+/*
+ * msl_debug.h -- test / measurement accessors of libmsl.so (NOT part of the drop-in boundary, which is msl.h).
+ *
+ * Used by tests/ (intermediate stages against the CPU oracle), bench.py (device counters, HIP-event timing of single kernels) and the
+ * experiment tools under tools/.  Same conventions as msl.h: extern "C", plain pointers, MSL_OK or a negative msl_status.
+ */
+#ifndef MSL_DEBUG_H
+#define MSL_DEBUG_H
+
+#include "msl.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- ORB extractor ---- */
+/* Debug accessors for the parity tests (host output, synchronous, after an extract call):
+ * pyramid level image of frame f (unpadded, tightly packed w*h), its blurred version, and the
+ * FAST candidates handed to the quadtree (x,y in level pixel coords, response), in order. */
+/* Experiment builds (-DMSL_OCT_STAMPS): n <= 200 64-bit words = (100 MHz device clock, shader clock) pairs the level-0 quadtree workgroup of frame 0
+ * parked at its phase boundaries; zeros otherwise. */
+MSL_API int msl_orb_debug_stamps(msl_orb *h, uint64_t *out, int n);
+MSL_API int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out);
+MSL_API int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out);
+MSL_API int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys /*3 ints each*/,
+                                     int cap, int *n_out);
+/* Per-kernel timing with HIP events on the handle's stream.  mode 0 = off, -1 = every kernel,
+ * otherwise a bit mask of kernel ids (bit k = time kernel k only, so a timed region can carry a
+ * single kernel's events).  msl_orb_profile_read returns accumulated milliseconds and launch
+ * counts per kernel since the last enable call. */
+#define MSL_ORB_NKERNELS 6
+MSL_API int msl_orb_profile_enable(msl_orb *h, int mode);
+MSL_API int msl_orb_profile_read(msl_orb *h, float *ms /*[MSL_ORB_NKERNELS]*/,
+                                 int32_t *launches /*[MSL_ORB_NKERNELS]*/);
+MSL_API const char *msl_orb_kernel_name(int k);
+
+/* ---- surfel fusion ---- */
+/* Debug accessors (host output, synchronous): superpixel seeds and the pixel->seed index map
+ * as left by the last fuse call. */
+MSL_API int msl_sf_debug_seeds(msl_sf *h, msl_seed *out /*(w/8)*(h/8)*/);
+MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/);
+/* The handle's 16 device counters after a sync (0: live surfels, 1-4/6: last keyframe's new / deleted / updated / before / after,
+ * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
+ * surfels before each keyframe; 13: some record keeps wide r, g, b; 14-15: spare). */
+MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]);
+/* n_words 32-bit words from offset_words of one of the compaction's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list;
+ * host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
+ * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
+/* Mean time (us) an event pair carried by a dispatch reports for an EMPTY kernel of `grid` single-wave workgroups on the map stream (n launches):
+ * the measurement overhead contained in msl_sf_profile_read's per-kernel times (rocprofv3's kernel durations do not contain it). */
+MSL_API int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us);
+MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words);
+
+/* Test hook (host only): mse_out[i] = the MSE ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183) reports for stats[i], evaluated by the
+ * scalar code (lanes = 0) or by the clustering's lock-step SIMD form with `lanes` (2, 4, 8, 16) candidates per group; MSL_ERR_INVALID if the CPU
+ * lacks the instruction set that width is built for (4 and 8: AVX2, 16: AVX-512F). */
+MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out);
+/* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
+MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);
+
+#define MSL_SF_NKERNELS 12
+MSL_API int msl_sf_profile_enable(msl_sf *h, int mode);
+MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);
+MSL_API const char *msl_sf_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSL_DEBUG_H */

@@ -82,12 +82,19 @@ SIGNATURES = {
     "msl_peac_block_stats": (_i, [_i, _vp, _sz, _sz, _i, _i, _i, _i, _f, _f, _f, _f, _f, _i, _i, C.c_double, C.c_double, _i, _vp, _vp, _i]),
     "msl_match_by_projection_batch": (_i, [_i, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),
     "msl_match_descriptor_distance": (_i, [_i, _vp, _vp, _i, _vp]),
+    "msl_match_create": (_vp, [_i]),
+    "msl_match_destroy": (None, [_vp]),
+    "msl_match_sync": (_i, [_vp]),
+    "msl_match_set_stream": (_i, [_vp, _vp]),
+    "msl_match_by_projection": (_i, [_vp, _i, _i] + [_vp] * 15 + [_i, _vp, _vp, _i]),
+    "msl_match_descriptor_distances": (_i, [_vp, _vp, _vp, _i, _vp]),
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
     "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
     "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),
     "msl_sf_last_counters": (_i, [_vp, _vp]),
     "msl_sf_sync": (_i, [_vp]),
     "msl_sf_set_stream": (_i, [_vp, _vp]),
+    "msl_orb_debug_stamps": (_i, [_vp, _vp, _i]),
     "msl_sf_debug_seeds": (_i, [_vp, _vp]),
     "msl_sf_debug_index": (_i, [_vp, _vp]),
     "msl_sf_debug_ctr": (_i, [_vp, _vp]),

@@ -41,11 +41,19 @@ bool PlaneDetection::readDepthImage(const cv::Mat depthImg, const cv::Mat &K, co
     fx_ = K.at<float>(0, 0); fy_ = K.at<float>(1, 1); cx_ = K.at<float>(0, 2); cy_ = K.at<float>(1, 2);
     depthMapFactor_ = depthMapFactor;
     depth16_ = depthImg;
-    int vertex_idx = 0;   // colours of the cloud vertices (every second pixel of every second row); the positions arrive with the extraction
+    // The public cloud is filled here as in the reference (:60-74), so a caller that reads cloud.vertices right after readDepthImage -- or never
+    // calls runPlaneDetection -- sees the vertices of THIS depth image.  80 k vertices of three double operations each: ~0.1 ms
+    // of host time; runPlaneDetection overwrites them with the device's (bit-identical) values.
+    int vertex_idx = 0;
     for (int i = 0; i < depthImg.rows; i += 2)
         for (int j = 0; j < depthImg.cols; j += 2) {
+            const double z = (double)(depthImg.at<unsigned short>(i, j)) * depthMapFactor;
+            if (z != z) { cloud.vertices[vertex_idx++] = VertexType(0, 0, z); continue; }     // _isnan(z), :63-66
+            const double x = ((double)j - K.at<float>(0, 2)) * z / K.at<float>(0, 0);
+            const double y = ((double)i - K.at<float>(1, 2)) * z / K.at<float>(1, 1);
             const cv::Vec3b c = color_img_.at<cv::Vec3b>(i, j);
-            cloud.verticesColour[vertex_idx++] = VertexColour(c[0], c[1], c[2]);
+            cloud.verticesColour[vertex_idx] = VertexColour(c[0], c[1], c[2]);
+            cloud.vertices[vertex_idx++] = VertexType(x, y, z);
         }
     return true;
 }

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "../../include/msl.h"
+#include "../../include/msl_debug.h"
 
 namespace msl {
 

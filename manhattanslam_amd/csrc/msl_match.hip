@@ -24,6 +24,7 @@
 #include "msl_common.h"
 
 #include <mutex>
+#include <new>
 
 using namespace msl;
 
@@ -332,11 +333,8 @@ __global__ void k_descriptor_distance(const uint8_t *a, const uint8_t *b, int n,
              __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
 }
 
-// grow-only scratch cached per device (a per-frame caller pays no hipMalloc)
+// grow-only device buffers owned by a handle (a per-frame caller pays no hipMalloc)
 struct Buf { void *p = nullptr; size_t cap = 0; };
-struct Scratch { Buf in[14], items, cellStart, mode, cand, candCnt, outMatch, outN; };
-Scratch g_scratch[16];
-std::mutex g_mutex;
 
 hipError_t grow(Buf &b, size_t need) {
     if (need <= b.cap) return hipSuccess;
@@ -349,25 +347,51 @@ hipError_t grow(Buf &b, size_t need) {
 
 }  // namespace
 
-extern "C" {
+// One matcher object = one ORBmatcher of the reference (src/ORBmatcher.cc:41): its own stream and its own scratch, used by one thread at a time;
+// the device is re-bound at every entry like the other handles.
+struct msl_match {
+    int device = 0;
+    hipStream_t stream = nullptr; bool ownStream = true;
+    Buf in[14], items, cellStart, mode, cand, candCnt, outMatch, outN;   // staged inputs (host-memory calls), scratch, staged outputs
+    Buf da, db, dout;                                                     // msl_match_descriptor_distance
+    bool attrSet = false;
+};
 
-int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps,
-                                  const float *cur_un_xy, const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc,
-                                  const int32_t *n_cur, const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
-                                  const int32_t *last_octave, const float *last_angle, const int32_t *n_last, const float *Tcw_cur,
-                                  const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
-    if (n_pairs < 1 || cap < 1 || cap > MAX_CAP || !params || !cur_kps || !cur_un_xy || !cur_uright || !cur_grid_cell || !cur_desc || !n_cur ||
+namespace {
+
+msl_match *g_default[16];      // the device-indexed convenience entry points share one lazily created handle per device
+std::mutex g_mutex;
+
+#define M_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_match: %s failed: %s", #expr, hipGetErrorString(e_)); return MSL_ERR_HIP; } } while (0)
+
+void free_handle(msl_match *h) {
+    Buf *all[] = {&h->items, &h->cellStart, &h->mode, &h->cand, &h->candCnt, &h->outMatch, &h->outN, &h->da, &h->db, &h->dout};
+    for (Buf *b : all) if (b->p) (void)hipFree(b->p);
+    for (Buf &b : h->in) if (b.p) (void)hipFree(b.p);
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+msl_match *default_handle(int device) {   // g_mutex held
+    msl_match *&h = g_default[device & 15];
+    if (!h) h = msl_match_create(device);
+    return h;
+}
+
+int run_projection(msl_match *h, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps, const float *cur_un_xy,
+                   const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc, const int32_t *n_cur, const float *last_xyz,
+                   const uint8_t *last_desc, const uint8_t *last_flags, const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
+                   const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
+    if (!h || n_pairs < 1 || cap < 1 || cap > MAX_CAP || !params || !cur_kps || !cur_un_xy || !cur_uright || !cur_grid_cell || !cur_desc || !n_cur ||
         !last_xyz || !last_desc || !last_flags || !last_octave || !last_angle || !n_last || !Tcw_cur || !Tcw_last || !match_out || !nmatches ||
         params->nlevels < 1 || params->nlevels > MSL_MATCH_MAX_LEVELS || !(params->maxX > params->minX) || !(params->maxY > params->minY) ||
         params->fx == 0) {
-        set_error("msl_match_by_projection_batch: invalid argument (cap <= %d, nlevels <= %d)", MAX_CAP, MSL_MATCH_MAX_LEVELS);
+        set_error("msl_match_by_projection: invalid argument (cap <= %d, nlevels <= %d)", MAX_CAP, MSL_MATCH_MAX_LEVELS);
         return MSL_ERR_INVALID;
     }
-    int rc = bind_device(device);
+    int rc = bind_device(h->device);
     if (rc != MSL_OK) return rc;
-#define M_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { set_error("msl_match_by_projection_batch: %s", hipGetErrorString(e_)); return MSL_ERR_HIP; } } while (0)
-    std::lock_guard<std::mutex> lock(g_mutex);
-    Scratch &sc = g_scratch[device & 15];
+    hipStream_t st = h->stream;
     const size_t n = (size_t)n_pairs * cap;
     MatchDev P{};
     P.nPairs = n_pairs; P.cap = cap; P.prm = *params;
@@ -381,9 +405,10 @@ int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_ma
     const void *dev[14];
     for (int i = 0; i < 14; i++) {
         if (mem == MSL_MEM_HOST) {
-            M_TRY(grow(sc.in[i], bytes[i]));
-            M_TRY(hipMemcpyAsync(sc.in[i].p, src[i], bytes[i], hipMemcpyHostToDevice, 0));
-            dev[i] = sc.in[i].p;
+            if (bytes[i] > h->in[i].cap) M_TRY(hipStreamSynchronize(st));   // an earlier asynchronous call may still read the buffer about to be replaced
+            M_TRY(grow(h->in[i], bytes[i]));
+            M_TRY(hipMemcpyAsync(h->in[i].p, src[i], bytes[i], hipMemcpyHostToDevice, st));
+            dev[i] = h->in[i].p;
         } else {
             dev[i] = src[i];
         }
@@ -392,49 +417,123 @@ int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_ma
     P.curDesc = (const uint8_t *)dev[4]; P.nCur = (const int32_t *)dev[5]; P.lastXyz = (const float *)dev[6]; P.lastDesc = (const uint8_t *)dev[7];
     P.lastFlags = (const uint8_t *)dev[8]; P.lastOctave = (const int32_t *)dev[9]; P.lastAngle = (const float *)dev[10];
     P.nLast = (const int32_t *)dev[11]; P.TcwCur = (const float *)dev[12]; P.TcwLast = (const float *)dev[13];
-    M_TRY(grow(sc.items, sizeof(unsigned short) * n)); M_TRY(grow(sc.cellStart, sizeof(unsigned) * (NCELLS + 1) * n_pairs));
-    M_TRY(grow(sc.mode, sizeof(int) * n_pairs)); M_TRY(grow(sc.cand, sizeof(unsigned) * CMAX * n)); M_TRY(grow(sc.candCnt, sizeof(unsigned) * n));
-    P.items = (unsigned short *)sc.items.p; P.cellStart = (unsigned *)sc.cellStart.p; P.mode = (int *)sc.mode.p; P.cand = (unsigned *)sc.cand.p;
-    P.candCnt = (unsigned *)sc.candCnt.p;
+    const size_t need[5] = {sizeof(unsigned short) * n, sizeof(unsigned) * (NCELLS + 1) * n_pairs, sizeof(int) * n_pairs, sizeof(unsigned) * CMAX * n, sizeof(unsigned) * n};
+    Buf *scr[5] = {&h->items, &h->cellStart, &h->mode, &h->cand, &h->candCnt};
+    for (int i = 0; i < 5; i++) {
+        if (need[i] > scr[i]->cap) M_TRY(hipStreamSynchronize(st));
+        M_TRY(grow(*scr[i], need[i]));
+    }
+    P.items = (unsigned short *)h->items.p; P.cellStart = (unsigned *)h->cellStart.p; P.mode = (int *)h->mode.p; P.cand = (unsigned *)h->cand.p;
+    P.candCnt = (unsigned *)h->candCnt.p;
     if (out_mem == MSL_MEM_HOST) {
-        M_TRY(grow(sc.outMatch, sizeof(int32_t) * n)); M_TRY(grow(sc.outN, sizeof(int32_t) * n_pairs));
-        P.matchOut = (int32_t *)sc.outMatch.p; P.nmatches = (int32_t *)sc.outN.p;
+        M_TRY(grow(h->outMatch, sizeof(int32_t) * n)); M_TRY(grow(h->outN, sizeof(int32_t) * n_pairs));   // (host-output calls end with a sync: nothing in flight reads these)
+        P.matchOut = (int32_t *)h->outMatch.p; P.nmatches = (int32_t *)h->outN.p;
     } else {
         P.matchOut = match_out; P.nmatches = nmatches;
     }
-    M_TRY(hipFuncSetAttribute((const void *)k_match_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * sizeof(unsigned) * MAX_CAP)));
-    hipLaunchKernelGGL(k_match_grid, dim3((unsigned)n_pairs), dim3(256), sizeof(unsigned short) * cap, 0, P);
-    hipLaunchKernelGGL(k_match_candidates, dim3((unsigned)((cap + 3) / 4), (unsigned)n_pairs), dim3(256), 0, 0, P);
-    hipLaunchKernelGGL(k_match_assign, dim3((unsigned)n_pairs), dim3(ASSIGN_NT), 3 * sizeof(unsigned) * cap, 0, P);
+    if (!h->attrSet) {
+        M_TRY(hipFuncSetAttribute((const void *)k_match_assign, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * sizeof(unsigned) * MAX_CAP)));
+        h->attrSet = true;
+    }
+    hipLaunchKernelGGL(k_match_grid, dim3((unsigned)n_pairs), dim3(256), sizeof(unsigned short) * cap, st, P);
+    hipLaunchKernelGGL(k_match_candidates, dim3((unsigned)((cap + 3) / 4), (unsigned)n_pairs), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_match_assign, dim3((unsigned)n_pairs), dim3(ASSIGN_NT), 3 * sizeof(unsigned) * cap, st, P);
     M_TRY(hipGetLastError());
     if (out_mem == MSL_MEM_HOST) {
-        M_TRY(hipMemcpyAsync(match_out, P.matchOut, sizeof(int32_t) * n, hipMemcpyDeviceToHost, 0));
-        M_TRY(hipMemcpyAsync(nmatches, P.nmatches, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, 0));
+        M_TRY(hipMemcpyAsync(match_out, P.matchOut, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        M_TRY(hipMemcpyAsync(nmatches, P.nmatches, sizeof(int32_t) * n_pairs, hipMemcpyDeviceToHost, st));
     }
-    M_TRY(hipStreamSynchronize(0));
+    if (out_mem == MSL_MEM_HOST || mem == MSL_MEM_HOST) M_TRY(hipStreamSynchronize(st));   // host buffers are the caller's again on return
     return MSL_OK;
 }
 
-int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) {
-    if (n < 0 || (n && (!a32 || !b32 || !dist_out))) { set_error("msl_match_descriptor_distance: invalid argument"); return MSL_ERR_INVALID; }
+int run_distance(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) {
+    if (!h || n < 0 || (n && (!a32 || !b32 || !dist_out))) { set_error("msl_match_descriptor_distance: invalid argument"); return MSL_ERR_INVALID; }
     if (n == 0) return MSL_OK;
-    int rc = bind_device(device);
+    int rc = bind_device(h->device);
     if (rc != MSL_OK) return rc;
-    uint8_t *da = nullptr, *db = nullptr; int32_t *dout = nullptr;
-    auto run = [&]() -> int {   // every exit path below frees the three buffers
-        M_TRY(hipMalloc(&da, (size_t)n * 32)); M_TRY(hipMalloc(&db, (size_t)n * 32)); M_TRY(hipMalloc(&dout, sizeof(int32_t) * n));
-        M_TRY(hipMemcpy(da, a32, (size_t)n * 32, hipMemcpyHostToDevice)); M_TRY(hipMemcpy(db, b32, (size_t)n * 32, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_descriptor_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, da, db, n, dout);
-        M_TRY(hipGetLastError());
-        M_TRY(hipMemcpy(dist_out, dout, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
-        return MSL_OK;
-    };
-    rc = run();
-    if (da) (void)hipFree(da);
-    if (db) (void)hipFree(db);
-    if (dout) (void)hipFree(dout);
-#undef M_TRY
+    hipStream_t st = h->stream;
+    M_TRY(grow(h->da, (size_t)n * 32)); M_TRY(grow(h->db, (size_t)n * 32)); M_TRY(grow(h->dout, sizeof(int32_t) * n));   // synchronous call: nothing in flight
+    M_TRY(hipMemcpyAsync(h->da.p, a32, (size_t)n * 32, hipMemcpyHostToDevice, st)); M_TRY(hipMemcpyAsync(h->db.p, b32, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_descriptor_distance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)h->da.p, (const uint8_t *)h->db.p, n, (int32_t *)h->dout.p);
+    M_TRY(hipGetLastError());
+    M_TRY(hipMemcpyAsync(dist_out, h->dout.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    M_TRY(hipStreamSynchronize(st));
+    return MSL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+msl_match *msl_match_create(int device) {
+    if (bind_device(device) != MSL_OK) return nullptr;
+    msl_match *h = new (std::nothrow) msl_match();
+    if (!h) { set_error("msl_match_create: out of memory"); return nullptr; }
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { set_error("msl_match_create: hipStreamCreate failed"); delete h; return nullptr; }
+    return h;
+}
+
+void msl_match_destroy(msl_match *h) {
+    if (!h) return;
+    (void)bind_device(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_handle(h);
+}
+
+int msl_match_set_stream(msl_match *h, void *hip_stream) {
+    if (!h) { set_error("msl_match_set_stream: null handle"); return MSL_ERR_INVALID; }
+    int rc = bind_device(h->device);
+    if (rc != MSL_OK) return rc;
+    M_TRY(hipStreamSynchronize(h->stream));
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream; h->ownStream = false;
+    return MSL_OK;
+}
+
+int msl_match_sync(msl_match *h) {
+    if (!h) { set_error("msl_match_sync: null handle"); return MSL_ERR_INVALID; }
+    int rc = bind_device(h->device);
+    if (rc != MSL_OK) return rc;
+    M_TRY(hipStreamSynchronize(h->stream));
+    return MSL_OK;
+}
+
+int msl_match_by_projection(msl_match *h, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps,
+                            const float *cur_un_xy, const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc,
+                            const int32_t *n_cur, const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
+                            const int32_t *last_octave, const float *last_angle, const int32_t *n_last, const float *Tcw_cur,
+                            const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
+    return run_projection(h, n_pairs, cap, params, cur_kps, cur_un_xy, cur_uright, cur_grid_cell, cur_desc, n_cur, last_xyz, last_desc, last_flags,
+                          last_octave, last_angle, n_last, Tcw_cur, Tcw_last, mem, match_out, nmatches, out_mem);
+}
+
+int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) { return run_distance(h, a32, b32, n, dist_out); }
+
+// Device-indexed convenience forms: one lazily created handle per device, serialised by a mutex, always synchronous.
+int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps,
+                                  const float *cur_un_xy, const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc,
+                                  const int32_t *n_cur, const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
+                                  const int32_t *last_octave, const float *last_angle, const int32_t *n_last, const float *Tcw_cur,
+                                  const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    msl_match *h = default_handle(device);
+    if (!h) return MSL_ERR_NO_DEVICE;
+    // device-resident inputs of this form are complete, or enqueued on the legacy default stream, when the call is made (as before the handle existed)
+    if (mem == MSL_MEM_DEVICE) { if (bind_device(device) == MSL_OK) (void)hipStreamSynchronize(0); }
+    int rc = run_projection(h, n_pairs, cap, params, cur_kps, cur_un_xy, cur_uright, cur_grid_cell, cur_desc, n_cur, last_xyz, last_desc, last_flags,
+                            last_octave, last_angle, n_last, Tcw_cur, Tcw_last, mem, match_out, nmatches, out_mem);
+    if (rc == MSL_OK) rc = msl_match_sync(h);
     return rc;
 }
+
+int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    msl_match *h = default_handle(device);
+    if (!h) return MSL_ERR_NO_DEVICE;
+    return run_distance(h, a32, b32, n, dist_out);
+}
+#undef M_TRY
 
 }  // extern "C"

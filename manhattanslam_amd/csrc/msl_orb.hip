@@ -76,7 +76,9 @@ struct OrbDev {
     msl_frame_params fp; float gridWInv, gridHInv;
     const float *depth; unsigned long long depthRowStride, depthFrameStride;   // bytes
     float *unXY, *depthOut, *uRight; int *gridCell;
-    int maxNode;   // k_octree: node-array length (dynamic LDS = OCT_NODE_BYTES * maxNode)
+    int maxNode;   // k_octree: node-array length
+    int octStop;   // experiment hook (MSL_OCT_STOP): leave k_octree after phase octStop (timing only, wrong results); 0 = run everything
+    int octLds;    // k_octree: dynamic LDS bytes = max(OCT_NODE_BYTES * maxNode, 8 * (cells of the largest level + 1))
 };
 
 __constant__ int8_t c_pattern[1024] = {
@@ -321,248 +323,426 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
     return c;
 }
 
-__global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
-    // Node arrays sized for THIS extractor's longest possible list (P.maxNode = max over levels of max(quota, 4 nIni) + 2, rounded up to 64; 66 bytes
-    // per node: 16.5 KB for 1000 features instead of a fixed 66 KB for MAXNODE = 1024), so that the frame-batched kernels of the other streams keep
-    // their LDS -- and with it their occupancy -- while this latency-bound kernel runs.
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
-    const int M = P.maxNode;
+// Experiment builds (-DMSL_OCT_STAMPS): the level-0 workgroup of frame 0 parks (100 MHz clock, shader clock) pairs at its phase boundaries behind
+// the error word; msl_orb_debug_stamps reads them.
+#ifdef MSL_OCT_STAMPS
+#define OCT_STAMP(P, level, frame, idx)                                                                                   \
+    do {                                                                                                                  \
+        const int i_ = (idx);                                                                                             \
+        if ((level) == 0 && (frame) == 0 && threadIdx.x == 0 && i_ < 100) {                                               \
+            unsigned long long *d_ = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>((P).err) + 128); \
+            d_[2 * i_] = __builtin_amdgcn_s_memrealtime(); d_[2 * i_ + 1] = __builtin_amdgcn_s_memtime();                 \
+        }                                                                                                                 \
+    } while (0)
+#else
+#define OCT_STAMP(P, level, frame, idx) do { } while (0)
+#endif
+// Where a workgroup keeps the level's candidate keys and their node ids while the list is subdivided.  REG: in registers (OCT_KPT per thread:
+// <= 8192 candidates per level, which covers every frame but synthetic noise) -- a key never moves, only its node id changes, so no round
+// touches memory for them; otherwise in the global keys / knode arrays as in rounds 1-3 (slower: every pass is a chain of L2 round trips).
+constexpr int OCT_KPT = 16;
+template <bool REG> struct OctKeys {
+    uint32_t key[REG ? OCT_KPT : 1];
+    unsigned node[REG ? OCT_KPT : 1], quad[REG ? OCT_KPT : 1];
+    uint32_t *gkeys; uint16_t *gnode; unsigned n; int tid;
+    unsigned per;   // REG: a thread owns the `per` CONSECUTIVE keys k = tid * per + j -- neighbours in FAST-cell order, i.e. mostly in the same node
+    // f(k, key, node&, quad&): quad is scratch that survives between two passes of one round (REG only; recomputed otherwise)
+    template <typename F> __device__ __forceinline__ void for_each(F f) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < OCT_KPT; j++) {
+                const unsigned k = (unsigned)tid * per + (unsigned)j;
+                if ((unsigned)j < per && k < n) f(k, key[j], node[j], quad[j]);
+            }
+        } else {
+            for (unsigned k = tid; k < n; k += OCT_NT) {
+                unsigned nd = gnode[k], q = 0xFFFFFFFFu;
+                const unsigned nd0 = nd;
+                f(k, gkeys[k], nd, q);
+                if (nd != nd0) gnode[k] = (uint16_t)nd;
+            }
+        }
+    }
+};
+
+template <bool REG>
+__device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, OctKeys<REG> &K, unsigned char *s_dyn, unsigned *s_wave, int *s_misc, int frame,
+                                            int level) {
+    const int M = P.maxNode, tid = threadIdx.x, N = G.quota;
+    const unsigned n = K.n;
     Rect *const s_rectB = reinterpret_cast<Rect *>(s_dyn);                         // [2][M]
     unsigned *const s_cntB = reinterpret_cast<unsigned *>(s_rectB + 2 * M);        // [2][M]
     unsigned *const s_cc = s_cntB + 2 * M;                                         // [4 M] child key counts
     short *const s_crankB = reinterpret_cast<short *>(s_cc + 4 * M);               // [2][M] creation rank among the nodes recorded for careful mode, -1 = none
-    unsigned short *const s_F = reinterpret_cast<unsigned short *>(s_crankB + 2 * M);   // [4 M] scan of "child exists"
-    unsigned short *const s_G = s_F + 4 * M;                                       // [4 M] scan of "child expandable"
-    unsigned short *const s_L = s_G + 4 * M;                                       // [M] scan of kept old nodes
+    unsigned *const s_FG = reinterpret_cast<unsigned *>(s_crankB + 2 * M);         // [4 M] scans of "child exists" (low half) and "child expandable" (high half)
+    unsigned short *const s_L = reinterpret_cast<unsigned short *>(s_FG + 4 * M);  // [M] scan of kept old nodes
     unsigned short *const s_order = s_L + M;                                       // [M] careful mode: sorted candidates
     unsigned short *const s_rankOf = s_order + M;                                  // [M] careful mode: node -> sorted rank (0xFFFF = not a candidate)
-    __shared__ unsigned s_wave[17];
-    __shared__ int s_misc[8];
-
-    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
-    const LevelDev &G = P.lv[level];
-    const int N = G.quota;
-    uint32_t *keys = P.keys + (size_t)frame * P.keysPerFrame + G.keyBase;
-    uint16_t *knode = P.knode + (size_t)frame * P.keysPerFrame + G.keyBase;
     int *nsel = P.nsel + frame * P.nlevels + level;
     uint32_t *sel = P.sel + ((size_t)frame * P.nlevels + level) * P.selCap;
 
-    // ---- gather the cell lists in cell order (vToDistributeKeys, :757-779) ----
+    const unsigned lane = (unsigned)tid & 63u;
+    // Histogram update by whole waves: ctr[q] += number of lanes that hold q (q = 0xFFFFFFFF: no item).  The keys arrive in FAST-cell order, so
+    // the lanes of a wave sit in the same one or two nodes round after round, and plain LDS atomics would send all 64 lanes to the same counter,
+    // which the LDS serialises (measured: 78 of the kernel's 124 us went into the full rounds).  Here the lanes that share a counter are found
+    // with a ballot and their leader issues ONE atomic with the count: as many steps as the wave has distinct counters.
+    auto hist_add = [&](unsigned *ctr, unsigned q) {
+        unsigned long long todo = __ballot(q != 0xFFFFFFFFu);
+        while (todo) {
+            const unsigned leader = (unsigned)__builtin_ctzll(todo);
+            const unsigned qq = (unsigned)__builtin_amdgcn_readlane((int)q, (int)leader);
+            const unsigned long long mm = __ballot(q == qq);
+            if (lane == leader) atomicAdd(&ctr[qq], (unsigned)__popcll(mm));
+            todo &= ~mm;
+        }
+    };
+    // f(k, key, node&, quad&) -> counter index or 0xFFFFFFFF, for every key.  REG: a thread's consecutive keys mostly share a counter, so it counts
+    // runs and issues one atomic per run (different lanes sit in different cells: few of them meet in a counter at the same time).
+    auto for_each_hist = [&](unsigned *ctr, auto f) {
+        if constexpr (REG) {
+            unsigned curQ = 0xFFFFFFFFu, curC = 0;
+#pragma unroll
+            for (int j = 0; j < OCT_KPT; j++) {
+                const unsigned k = (unsigned)tid * K.per + (unsigned)j;
+                if ((unsigned)j < K.per && k < n) {
+                    const unsigned q = f(k, K.key[j], K.node[j], K.quad[j]);
+                    if (q != curQ) {
+                        if (curQ != 0xFFFFFFFFu) atomicAdd(&ctr[curQ], curC);
+                        curQ = q; curC = 0;
+                    }
+                    curC++;
+                }
+            }
+            if (curQ != 0xFFFFFFFFu) atomicAdd(&ctr[curQ], curC);
+        } else {
+            for (unsigned k0 = (unsigned)tid - lane; k0 < n; k0 += OCT_NT) {
+                const unsigned k = k0 + lane;
+                unsigned q = 0xFFFFFFFFu;
+                if (k < n) {
+                    unsigned nd = K.gnode[k], qd = 0xFFFFFFFFu;
+                    const unsigned nd0 = nd;
+                    q = f(k, K.gkeys[k], nd, qd);
+                    if (nd != nd0) K.gnode[k] = (uint16_t)nd;
+                }
+                hist_add(ctr, q);
+            }
+        }
+    };
+
+    int stampNo = 2;
+    OCT_STAMP(P, level, frame, 1);
+    // ---- root nodes (:536-572) ----
+    int cur = 0, S = 0;
+    const int H = G.h - 32;
+    for (int i = tid; i < M; i += OCT_NT) { s_cntB[i] = 0; s_crankB[i] = -1; }
+    for (int j = tid; j < 4 * M; j += OCT_NT) s_cc[j] = 0;
+    __syncthreads();
+    for_each_hist(s_cntB, [&](unsigned, uint32_t key, unsigned &node, unsigned &) {
+        node = (unsigned)(int)((float)(key & 0xFFF) / G.hX);
+        return node;
+    });
+    __syncthreads();
+    if (tid == 0) {
+        int sN = 0;
+        for (int i = 0; i < G.nIni; i++) {
+            const unsigned c = s_cntB[i];
+            s_L[i] = (unsigned short)sN;
+            if (c) {
+                Rect r; r.x0 = (short)(int)(G.hX * (float)i); r.x1 = (short)(int)(G.hX * (float)(i + 1)); r.y0 = 0; r.y1 = (short)H;
+                s_rectB[M + sN] = r; s_cntB[M + sN] = c; s_crankB[M + sN] = -1;
+                sN++;
+            }
+        }
+        s_misc[0] = sN;
+    }
+    __syncthreads();
+    S = s_misc[0];
+    K.for_each([&](unsigned, uint32_t, unsigned &node, unsigned &) { node = s_L[node]; });
+    cur = 1;
+    __syncthreads();
+    if (P.octStop == 2) { if (tid == 0) *nsel = 0; return; }
+
+    // Child counts of the nodes that are being divided: s_cc[4 i + quadrant] += 1 for every key of a divided node i (s_cc is zero on entry).
+    auto count_children = [&](const Rect *rect, auto is_divided) {
+        for_each_hist(s_cc, [&](unsigned, uint32_t key, unsigned &node, unsigned &quad) {
+            quad = is_divided(node) ? (unsigned)(4 * node + quadrant(rect[node], key & 0xFFF, (key >> 12) & 0xFFF)) : 0xFFFFFFFFu;
+            return quad;
+        });
+    };
+
+    bool careful = false;
+    // ---- full rounds (:580-640).  Five barriers per round: the scans of "child exists" / "child expandable" / "old node kept" run as ONE pair of
+    // block scans over register values (each thread owns `per` consecutive child slots), the new node records are written by the thread that scanned
+    // them, and the counters of the next round are cleared while the keys move to their new nodes. ----
+    while (true) {
+        const int prevS = S;
+        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M);
+        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
+        OCT_STAMP(P, level, frame, stampNo++);
+        count_children(rect, [&](unsigned i) { return cnt[i] > 1; });
+        __syncthreads();
+        OCT_STAMP(P, level, frame, stampNo++);
+        const int per = (4 * S + OCT_NT - 1) / OCT_NT, j0 = tid * per;
+        unsigned sumFG = 0, sumL = 0;
+        for (int p = 0; p < per; p++) {
+            const int j = j0 + p;
+            if (j < 4 * S) {
+                const unsigned ci = cnt[j >> 2], c = ci > 1 ? s_cc[j] : 0;
+                sumFG += (c > 0 ? 1u : 0u) | (c > 1 ? 0x10000u : 0u);
+                sumL += ((j & 3) == 0 && ci == 1) ? 1u : 0u;
+            }
+        }
+        unsigned totFG, totL, exFG, exL;
+        block_excl_scan_pair(sumFG, sumL, s_wave, &totFG, &totL, exFG, exL);
+        OCT_STAMP(P, level, frame, stampNo++);
+        const int Ctot = (int)(totFG & 0xFFFFu), nToExpand = (int)(totFG >> 16), Ltot = (int)totL;
+        const int S2 = Ctot + Ltot;
+        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        for (int p = 0; p < per; p++) {
+            const int j = j0 + p;
+            if (j < 4 * S) {
+                const int i = j >> 2;
+                const unsigned ci = cnt[i], c = ci > 1 ? s_cc[j] : 0;
+                exFG += (c > 0 ? 1u : 0u) | (c > 1 ? 0x10000u : 0u);      // inclusive from here
+                s_FG[j] = exFG;
+                if (c) {
+                    const int pos = Ctot - (int)(exFG & 0xFFFFu);
+                    nrect[pos] = child_rect(rect[i], j & 3);
+                    ncnt[pos] = c;
+                    ncrank[pos] = c > 1 ? (short)((exFG >> 16) - 1) : (short)-1;
+                }
+                if ((j & 3) == 0) {
+                    exL += ci == 1 ? 1u : 0u;
+                    s_L[i] = (unsigned short)exL;
+                    if (ci == 1) { const int pos = Ctot + (int)exL - 1; nrect[pos] = rect[i]; ncnt[pos] = 1; ncrank[pos] = -1; }
+                }
+            }
+        }
+        __syncthreads();
+        OCT_STAMP(P, level, frame, stampNo++);
+        K.for_each([&](unsigned, uint32_t key, unsigned &node, unsigned &quad) {
+            const unsigned i = node;
+            if (cnt[i] > 1) {
+                const unsigned j = REG ? quad : (unsigned)(4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF));
+                node = (unsigned)(Ctot - (int)(s_FG[j] & 0xFFFFu));
+            } else {
+                node = (unsigned)(Ctot + s_L[i] - 1);
+            }
+        });
+        for (int j = tid; j < 4 * S2; j += OCT_NT) s_cc[j] = 0;
+        __syncthreads();
+        OCT_STAMP(P, level, frame, stampNo++);
+        cur ^= 1; S = S2;
+        if (S >= N || S == prevS) break;
+        if (S + 3 * nToExpand > N) { careful = true; break; }
+    }
+
+    if (P.octStop == 3) { if (tid == 0) *nsel = 0; return; }
+    // ---- careful mode (:641-700) ----
+    stampNo = 40;
+    while (careful) {
+        OCT_STAMP(P, level, frame, stampNo++);
+        const int prevS = S;
+        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M); short *crank = (s_crankB + cur * M);
+        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
+        count_children(rect, [&](unsigned i) { return crank[i] >= 0; });
+        OCT_STAMP(P, level, frame, stampNo++);
+        // rank of a candidate = number of candidates that sort before it: larger (size, creation rank) first.  The sort keys go to LDS first
+        // (0 = not a candidate; s_FG is free until the scan below) so that the comparison loop is branch-free and its loads pipeline: as a loop
+        // over cnt[] / crank[] with a short-circuit test it took 6.5 of the careful round's 12 us.
+        unsigned long long *const pk = reinterpret_cast<unsigned long long *>(s_FG);
+        for (int i = tid; i < S; i += OCT_NT) pk[i] = crank[i] >= 0 ? ((((unsigned long long)cnt[i] << 16) | (unsigned)crank[i]) + 1ull) : 0ull;
+        __syncthreads();
+        unsigned nMine = 0;
+        for (int i = tid; i < S; i += OCT_NT) {
+            const unsigned long long me = pk[i];
+            if (me == 0) { s_rankOf[i] = 0xFFFF; continue; }
+            int r = 0;
+#pragma unroll 8
+            for (int i2 = 0; i2 < S; i2++) r += pk[i2] > me ? 1 : 0;
+            s_order[r] = (unsigned short)i;
+            s_rankOf[i] = (unsigned short)r;
+            nMine++;
+        }
+        if (tid == 0) s_misc[2] = 0x7FFFFFFF;
+        unsigned mTot, exUnused;
+        exUnused = block_excl_scan(nMine, s_wave, &mTot);   // (its barriers also complete s_cc, s_order, s_rankOf)
+        (void)exUnused;
+        const int m = (int)mTot;
+        OCT_STAMP(P, level, frame, stampNo++);
+        if (m == 0) break;  // nothing to expand: size unchanged -> finish
+        // growth prefix in sorted order -> number of expansions J: the first r + 1 with S + (children of the first r + 1 expansions) - (r + 1) >= N
+        const int perR = (m + OCT_NT - 1) / OCT_NT, r0 = tid * perR;
+        unsigned sumG = 0;
+        for (int p = 0; p < perR; p++) {
+            const int r = r0 + p;
+            if (r < m) { const int i = s_order[r]; sumG += (s_cc[4 * i] > 0) + (s_cc[4 * i + 1] > 0) + (s_cc[4 * i + 2] > 0) + (s_cc[4 * i + 3] > 0); }
+        }
+        unsigned totG, exG;
+        exG = block_excl_scan(sumG, s_wave, &totG);
+        for (int p = 0; p < perR; p++) {
+            const int r = r0 + p;
+            if (r < m) {
+                const int i = s_order[r];
+                exG += (s_cc[4 * i] > 0) + (s_cc[4 * i + 1] > 0) + (s_cc[4 * i + 2] > 0) + (s_cc[4 * i + 3] > 0);
+                if (S + (int)exG - (r + 1) >= N) atomicMin(&s_misc[2], r + 1);
+            }
+        }
+        __syncthreads();
+        const int J = min(s_misc[2], m);
+        OCT_STAMP(P, level, frame, stampNo++);
+        // children of the J expanded nodes, flat index jj = 4 r + q in sorted order; kept nodes in their old order
+        const int perC = (4 * J + OCT_NT - 1) / OCT_NT, jj0 = tid * perC, perS = (S + OCT_NT - 1) / OCT_NT, i0 = tid * perS;
+        unsigned sumFG = 0, sumL = 0;
+        for (int p = 0; p < perC; p++) {
+            const int jj = jj0 + p;
+            if (jj < 4 * J) { const unsigned c = s_cc[4 * s_order[jj >> 2] + (jj & 3)]; sumFG += (c > 0 ? 1u : 0u) | (c > 1 ? 0x10000u : 0u); }
+        }
+        for (int p = 0; p < perS; p++) { const int i = i0 + p; if (i < S) sumL += !(s_rankOf[i] < J) ? 1u : 0u; }
+        unsigned totFG, totL, exFG, exL;
+        block_excl_scan_pair(sumFG, sumL, s_wave, &totFG, &totL, exFG, exL);
+        OCT_STAMP(P, level, frame, stampNo++);
+        const int Ctot = (int)(totFG & 0xFFFFu);
+        const int S2 = Ctot + (S - J);
+        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
+        for (int p = 0; p < perC; p++) {
+            const int jj = jj0 + p;
+            if (jj < 4 * J) {
+                const int i = s_order[jj >> 2];
+                const unsigned c = s_cc[4 * i + (jj & 3)];
+                exFG += (c > 0 ? 1u : 0u) | (c > 1 ? 0x10000u : 0u);
+                s_FG[jj] = exFG;
+                if (c) {
+                    const int pos = Ctot - (int)(exFG & 0xFFFFu);
+                    nrect[pos] = child_rect(rect[i], jj & 3);
+                    ncnt[pos] = c;
+                    ncrank[pos] = c > 1 ? (short)((exFG >> 16) - 1) : (short)-1;
+                }
+            }
+        }
+        for (int p = 0; p < perS; p++) {
+            const int i = i0 + p;
+            if (i < S) {
+                const bool keep = !(s_rankOf[i] < J);
+                exL += keep ? 1u : 0u;
+                s_L[i] = (unsigned short)exL;
+                if (keep) { const int pos = Ctot + (int)exL - 1; nrect[pos] = rect[i]; ncnt[pos] = cnt[i]; ncrank[pos] = -1; }
+            }
+        }
+        __syncthreads();
+        K.for_each([&](unsigned, uint32_t key, unsigned &node, unsigned &quad) {
+            const unsigned i = node;
+            const int r = s_rankOf[i];
+            if (r < J) {
+                const unsigned q = REG ? (quad & 3u) : (unsigned)quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF);
+                node = (unsigned)(Ctot - (int)(s_FG[4 * r + q] & 0xFFFFu));
+            } else {
+                node = (unsigned)(Ctot + s_L[i] - 1);
+            }
+        });
+        __syncthreads();   // every key has read s_rankOf / s_FG / s_L / the old s_cc: they may be overwritten
+        OCT_STAMP(P, level, frame, stampNo++);
+        for (int j = tid; j < 4 * max(S, S2); j += OCT_NT) s_cc[j] = 0;
+        cur ^= 1; S = S2;
+        if (S >= N || S == prevS) break;
+        __syncthreads();
+    }
+
+    __syncthreads();
+    if (P.octStop == 4) { if (tid == 0) *nsel = 0; return; }
+    OCT_STAMP(P, level, frame, 80);
+    // ---- keep the best key of every node (:703-718) ----
+    unsigned *best = s_cc;
+    for (int i = tid; i < S; i += OCT_NT) best[i] = 0;
+    __syncthreads();
+    K.for_each([&](unsigned k, uint32_t key, unsigned &node, unsigned &) { atomicMax(&best[node], (key & 0xFF000000u) | (0xFFFFFFu - k)); });   // (final lists are long: few lanes share a node)
+    __syncthreads();
+    if (S > P.selCap) { if (tid == 0) { atomicExch(P.err, 2); *nsel = 0; } return; }
+    // the winner's key: (score, index) identifies it; its thread hands it over (REG) or it is read back (global)
+    if constexpr (REG) {
+        K.for_each([&](unsigned k, uint32_t key, unsigned &node, unsigned &) {
+            if ((best[node] & 0xFFFFFFu) == 0xFFFFFFu - k) sel[node] = key;
+        });
+    } else {
+        for (int i = tid; i < S; i += OCT_NT) sel[i] = K.gkeys[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
+    }
+    if (tid == 0) *nsel = S;
+    OCT_STAMP(P, level, frame, 81);
+}
+
+__global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
+    // Node arrays sized for THIS extractor's longest possible list (P.maxNode = max over levels of max(quota, 4 nIni) + 2, rounded up to 64, plus
+    // one block of slack; 66 bytes per node: 21 KB for 1000 features instead of a fixed 66 KB for MAXNODE = 1024), so that the frame-batched kernels
+    // of the other streams keep their LDS -- and with it their occupancy -- while this latency-bound kernel runs.  The same memory first holds
+    // the exclusive scan of the level's per-cell candidate counts (P.octLds covers both uses).
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+    __shared__ unsigned s_wave[33];   // (block_excl_scan_pair keeps two rows of 16 wave totals)
+    __shared__ int s_misc[8];
+    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    OCT_STAMP(P, level, frame, 0);
+    const LevelDev &G = P.lv[level];
+    uint32_t *keys = P.keys + (size_t)frame * P.keysPerFrame + G.keyBase;
+    uint16_t *knode = P.knode + (size_t)frame * P.keysPerFrame + G.keyBase;
+
+    // ---- the cell lists in cell order (vToDistributeKeys, :757-779): key slot k belongs to the cell c with off[c] <= k < off[c + 1] ----
     const uint32_t *cellCnt = P.cellCnt + (size_t)frame * P.cellsPerFrame + G.cellBase;
     const uint32_t *cellKeys = P.cellKeys + (size_t)frame * P.keysPerFrame;
+    unsigned *const s_off = reinterpret_cast<unsigned *>(s_dyn);     // [nCells + 1] exclusive scan of the cells' candidate counts
+    unsigned *const s_koff = s_off + (G.nCells + 1);                 // [nCells] where each cell's list starts in cellKeys (a geometry constant)
     unsigned n = 0;
     {
         unsigned carry = 0;
         for (int c0 = 0; c0 < G.nCells; c0 += OCT_NT) {
             const int c = c0 + tid;
             const unsigned cnt = c < G.nCells ? cellCnt[c] : 0;
+            const unsigned ko = c < G.nCells ? P.cells[G.cellBase + c].keyOff : 0;   // (in flight together with the count)
             unsigned tot;
             const unsigned off = carry + block_excl_scan(cnt, s_wave, &tot);
-            if (cnt) {
-                const uint32_t *src = cellKeys + P.cells[G.cellBase + c].keyOff;
-                for (unsigned i = 0; i < cnt; i++) keys[off + i] = src[i];
-            }
+            if (c < G.nCells) { s_off[c] = off; s_koff[c] = ko; }
             carry += tot;
         }
         n = carry;
+        if (tid == 0) s_off[G.nCells] = n;
     }
     if (tid == 0) P.ncand[frame * P.nlevels + level] = (int)n;
     __syncthreads();
-    if (n == 0) { if (tid == 0) *nsel = 0; return; }
-
-    // ---- root nodes (:536-572) ----
-    int cur = 0, S = 0;
-    const int H = G.h - 32;
-    for (int i = tid; i < M; i += OCT_NT) { s_cntB[i] = 0; s_crankB[i] = -1; }
-    __syncthreads();
-    for (unsigned k = tid; k < n; k += OCT_NT) {
-        const unsigned key = keys[k];
-        const int ini = (int)((float)(key & 0xFFF) / G.hX);
-        atomicAdd(&s_cntB[ini], 1u);
-        knode[k] = (uint16_t)ini;
+    if (n == 0) { if (tid == 0) P.nsel[frame * P.nlevels + level] = 0; return; }
+    auto cell_of = [&](unsigned k) -> int {   // largest c with off[c] <= k (empty cells share their successor's offset: the search skips them)
+        int lo = 0, hi = G.nCells;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= k) lo = mid; else hi = mid; }
+        return lo;
+    };
+    if (n <= (unsigned)OCT_KPT * OCT_NT) {
+        OctKeys<true> K;
+        K.n = n; K.tid = tid; K.gkeys = keys; K.gnode = knode; K.per = (n + OCT_NT - 1) / OCT_NT;
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < OCT_KPT; j++) {
+            const unsigned k = (unsigned)tid * K.per + (unsigned)j;
+            K.key[j] = 0; K.node[j] = 0; K.quad[j] = 0xFFFFFFFFu;
+            if ((unsigned)j < K.per && k < n) {
+                // one search for the thread's first key, then a walk: its keys are consecutive, so they sit in one or two cells, and their loads
+                // leave together instead of each waiting for its own search and cell record
+                if (j == 0) c = cell_of(k);
+                else while (k >= s_off[c + 1]) c++;
+                K.key[j] = cellKeys[s_koff[c] + (k - s_off[c])];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < OCT_KPT; j++) {
+            const unsigned k = (unsigned)tid * K.per + (unsigned)j;
+            if ((unsigned)j < K.per && k < n) keys[k] = K.key[j];     // (the global copy is what msl_orb_debug_candidates reads)
+        }
+        __syncthreads();   // s_off is dead from here on: the node arrays take its place
+        if (P.octStop == 1) { if (tid == 0) P.nsel[frame * P.nlevels + level] = 0; return; }
+        octree_body<true>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
+    } else {
+        OctKeys<false> K;
+        K.n = n; K.tid = tid; K.gkeys = keys; K.gnode = knode; K.per = 0;
+        for (unsigned k = tid; k < n; k += OCT_NT) { const int c = cell_of(k); keys[k] = cellKeys[s_koff[c] + (k - s_off[c])]; knode[k] = 0; }
+        __syncthreads();
+        octree_body<false>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
     }
-    __syncthreads();
-    if (tid == 0) {
-        int s = 0;
-        for (int i = 0; i < G.nIni; i++) {
-            const unsigned c = s_cntB[i];
-            s_L[i] = (unsigned short)s;
-            if (c) {
-                Rect r; r.x0 = (short)(int)(G.hX * (float)i); r.x1 = (short)(int)(G.hX * (float)(i + 1)); r.y0 = 0; r.y1 = (short)H;
-                s_rectB[M + s] = r; s_cntB[M + s] = c; s_crankB[M + s] = -1;
-                s++;
-            }
-        }
-        s_misc[0] = s;
-    }
-    __syncthreads();
-    S = s_misc[0];
-    for (unsigned k = tid; k < n; k += OCT_NT) knode[k] = s_L[knode[k]];
-    cur = 1;
-    __syncthreads();
-
-    bool careful = false;
-    // ---- full rounds (:580-640) ----
-    while (true) {
-        const int prevS = S;
-        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M);
-        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
-        for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
-        __syncthreads();
-        for (unsigned k = tid; k < n; k += OCT_NT) {
-            const int i = knode[k];
-            if (cnt[i] > 1) {
-                const unsigned key = keys[k];
-                atomicAdd(&s_cc[4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF)], 1u);
-            }
-        }
-        __syncthreads();
-        for (int j = tid; j < 4 * S; j += OCT_NT) {
-            const unsigned c = cnt[j >> 2] > 1 ? s_cc[j] : 0;
-            s_F[j] = c > 0; s_G[j] = c > 1;
-        }
-        for (int i = tid; i < S; i += OCT_NT) s_L[i] = cnt[i] == 1;
-        __syncthreads();
-        block_scan_array_incl(s_F, 4 * S, s_wave);
-        block_scan_array_incl(s_G, 4 * S, s_wave);
-        block_scan_array_incl(s_L, S, s_wave);
-        const int Ctot = s_F[4 * S - 1], nToExpand = s_G[4 * S - 1], Ltot = s_L[S - 1];
-        const int S2 = Ctot + Ltot;
-        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
-        for (int j = tid; j < 4 * S; j += OCT_NT) {
-            const unsigned c = cnt[j >> 2] > 1 ? s_cc[j] : 0;
-            if (c) {
-                const int pos = Ctot - s_F[j];
-                nrect[pos] = child_rect(rect[j >> 2], j & 3);
-                ncnt[pos] = c;
-                ncrank[pos] = c > 1 ? (short)(s_G[j] - 1) : (short)-1;
-            }
-        }
-        for (int i = tid; i < S; i += OCT_NT)
-            if (cnt[i] == 1) {
-                const int pos = Ctot + s_L[i] - 1;
-                nrect[pos] = rect[i]; ncnt[pos] = 1; ncrank[pos] = -1;
-            }
-        for (unsigned k = tid; k < n; k += OCT_NT) {
-            const int i = knode[k];
-            if (cnt[i] > 1) {
-                const unsigned key = keys[k];
-                const int j = 4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF);
-                knode[k] = (uint16_t)(Ctot - s_F[j]);
-            } else {
-                knode[k] = (uint16_t)(Ctot + s_L[i] - 1);
-            }
-        }
-        __syncthreads();
-        cur ^= 1; S = S2;
-        if (S >= N || S == prevS) break;
-        if (S + 3 * nToExpand > N) { careful = true; break; }
-    }
-
-    // ---- careful mode (:641-700) ----
-    while (careful) {
-        const int prevS = S;
-        Rect *rect = (s_rectB + cur * M); unsigned *cnt = (s_cntB + cur * M); short *crank = (s_crankB + cur * M);
-        Rect *nrect = (s_rectB + (cur ^ 1) * M); unsigned *ncnt = (s_cntB + (cur ^ 1) * M); short *ncrank = (s_crankB + (cur ^ 1) * M);
-        for (int j = tid; j < 4 * S; j += OCT_NT) s_cc[j] = 0;
-        for (int i = tid; i < S; i += OCT_NT) s_rankOf[i] = 0xFFFF;
-        __syncthreads();
-        for (unsigned k = tid; k < n; k += OCT_NT) {
-            const int i = knode[k];
-            if (crank[i] >= 0) {
-                const unsigned key = keys[k];
-                atomicAdd(&s_cc[4 * i + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF)], 1u);
-            }
-        }
-        __syncthreads();
-        // rank = number of candidates that sort before: larger (size, creation rank) first
-        int m = 0;
-        for (int i = tid; i < S; i += OCT_NT) {
-            if (crank[i] < 0) continue;
-            const unsigned long long me = ((unsigned long long)cnt[i] << 16) | (unsigned)crank[i];
-            int r = 0;
-            for (int i2 = 0; i2 < S; i2++)
-                if (crank[i2] >= 0 && (((unsigned long long)cnt[i2] << 16) | (unsigned)crank[i2]) > me) r++;
-            s_order[r] = (unsigned short)i;
-            s_rankOf[i] = (unsigned short)r;
-        }
-        if (tid == 0) s_misc[1] = 0;
-        __syncthreads();
-        {
-            int local = 0;
-            for (int i = tid; i < S; i += OCT_NT) local += crank[i] >= 0;
-            if (local) atomicAdd(&s_misc[1], local);
-        }
-        __syncthreads();
-        m = s_misc[1];
-        if (m == 0) break;  // nothing to expand: size unchanged -> finish
-        // growth prefix in sorted order -> number of expansions J
-        for (int r = tid; r < m; r += OCT_NT) {
-            const int i = s_order[r];
-            s_L[r] = (unsigned short)((s_cc[4 * i] > 0) + (s_cc[4 * i + 1] > 0) + (s_cc[4 * i + 2] > 0) + (s_cc[4 * i + 3] > 0));
-        }
-        if (tid == 0) s_misc[2] = m;
-        __syncthreads();
-        block_scan_array_incl(s_L, m, s_wave);   // s_L[r] = sum of child counts of the first r+1 expansions
-        for (int r = tid; r < m; r += OCT_NT)
-            if (S + (int)s_L[r] - (r + 1) >= N) atomicMin(&s_misc[2], r + 1);
-        __syncthreads();
-        const int J = s_misc[2];
-        // children of the J expanded nodes, flat index jj = 4*r + q in sorted order
-        for (int jj = tid; jj < 4 * J; jj += OCT_NT) {
-            const unsigned c = s_cc[4 * s_order[jj >> 2] + (jj & 3)];
-            s_F[jj] = c > 0; s_G[jj] = c > 1;
-        }
-        __syncthreads();
-        for (int i = tid; i < S; i += OCT_NT) s_L[i] = !(s_rankOf[i] < J);
-        __syncthreads();
-        block_scan_array_incl(s_F, 4 * J, s_wave);
-        block_scan_array_incl(s_G, 4 * J, s_wave);
-        block_scan_array_incl(s_L, S, s_wave);
-        const int Ctot = s_F[4 * J - 1];
-        const int S2 = Ctot + (S - J);
-        if (S2 > M) { if (tid == 0) { atomicExch(P.err, 1); *nsel = 0; } return; }
-        for (int jj = tid; jj < 4 * J; jj += OCT_NT) {
-            const int i = s_order[jj >> 2];
-            const unsigned c = s_cc[4 * i + (jj & 3)];
-            if (c) {
-                const int pos = Ctot - s_F[jj];
-                nrect[pos] = child_rect(rect[i], jj & 3);
-                ncnt[pos] = c;
-                ncrank[pos] = c > 1 ? (short)(s_G[jj] - 1) : (short)-1;
-            }
-        }
-        for (int i = tid; i < S; i += OCT_NT)
-            if (!(s_rankOf[i] < J)) {
-                const int pos = Ctot + s_L[i] - 1;
-                nrect[pos] = rect[i]; ncnt[pos] = cnt[i]; ncrank[pos] = -1;
-            }
-        for (unsigned k = tid; k < n; k += OCT_NT) {
-            const int i = knode[k];
-            const int r = s_rankOf[i];
-            if (r < J) {
-                const unsigned key = keys[k];
-                const int jj = 4 * r + quadrant(rect[i], key & 0xFFF, (key >> 12) & 0xFFF);
-                knode[k] = (uint16_t)(Ctot - s_F[jj]);
-            } else {
-                knode[k] = (uint16_t)(Ctot + s_L[i] - 1);
-            }
-        }
-        __syncthreads();
-        cur ^= 1; S = S2;
-        if (S >= N || S == prevS) break;
-    }
-
-    // ---- keep the best key of every node (:703-718) ----
-    unsigned *best = s_cc;
-    for (int i = tid; i < S; i += OCT_NT) best[i] = 0;
-    __syncthreads();
-    for (unsigned k = tid; k < n; k += OCT_NT)
-        atomicMax(&best[knode[k]], (keys[k] & 0xFF000000u) | (0xFFFFFFu - k));
-    __syncthreads();
-    if (S > P.selCap) { if (tid == 0) { atomicExch(P.err, 2); *nsel = 0; } return; }
-    for (int i = tid; i < S; i += OCT_NT) sel[i] = keys[0xFFFFFFu - (best[i] & 0xFFFFFFu)];
-    if (tid == 0) *nsel = S;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -859,6 +1039,7 @@ const char *kKernelNames[MSL_ORB_NKERNELS] = {"k_pyramid", "k_fast", "k_octree",
 struct msl_orb {
     int device = 0;
     int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, maxW = 0, maxH = 0, maxBatch = 0;
+    int outCap = 0;   // keypoints per frame the outputs are sized for: fixed by the creation geometry (msl_orb_capacity)
     double scaleFactor = 0;
     std::vector<float> scale, invScale, sigma2, invSigma2;
     std::vector<int> perLevel;
@@ -903,7 +1084,7 @@ int build_geometry(msl_orb *h, int W, int H) {
     std::vector<ResizeTap> taps;
     size_t pyrOff = 0, blurOff = 0;
     unsigned keyOff = 0;
-    int tileBase = 0, maxQuota = 0, maxList = 0;
+    int tileBase = 0, maxQuota = 0, maxList = 0, needCap = 0, maxSel = 0;
     for (int l = 0; l < L; l++) {
         LevelDev &G = D.lv[l];
         const float s = h->invScale[l];
@@ -957,6 +1138,9 @@ int build_geometry(msl_orb *h, int W, int H) {
         // one-by-one phase stops at the first length >= quota and every expansion adds <= 3
         if (std::max(G.quota, 4 * G.nIni) + 2 > MAXNODE) { set_error("per-level quota %d exceeds %d", G.quota, MAXNODE - 2); return MSL_ERR_INVALID; }
         maxList = std::max(maxList, std::max(G.quota, 4 * G.nIni) + 2);
+        // keypoints this level can return: quota + 2 from the one-by-one phase (:691-696), or the <= 4 nIni nodes of the first full round when
+        // that already reaches the quota (wide images with a small budget: nIni = round(width / height) roots, :536-552)
+        needCap += std::max(G.quota + 2, 4 * G.nIni); maxSel = std::max(maxSel, std::max(G.quota + 2, 4 * G.nIni));
         // blur tiles
         G.tilesX = (G.w + BT_W - 1) / BT_W; G.tilesY = (G.h + BT_H - 1) / BT_H;
         G.tileBase = tileBase; tileBase += G.tilesX * G.tilesY;
@@ -1036,11 +1220,23 @@ int build_geometry(msl_orb *h, int W, int H) {
     }
     D.cellsPerFrame = (int)cells.size();
     D.keysPerFrame = (int)keyOff;
-    D.selCap = maxQuota + 2;
-    D.maxNode = (maxList + 63) & ~63;
-    if ((size_t)OCT_NODE_BYTES * D.maxNode > 32 * 1024)   // (a large feature budget: more dynamic LDS than a launch gets by default)
-        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, OCT_NODE_BYTES * D.maxNode));
-    D.outCap = h->nfeatures + 2 * L;
+    D.selCap = maxSel;
+    D.maxNode = ((maxList + 63) & ~63) + 64;   // the analytic bound, rounded up, plus one 64-node block of slack (4 KB): an overrun would zero a whole level (P.err)
+    {
+        int maxCells = 0;
+        for (int l = 0; l < L; l++) maxCells = std::max(maxCells, D.lv[l].nCells);
+        D.octLds = (int)((std::max<size_t>((size_t)OCT_NODE_BYTES * D.maxNode, 2 * sizeof(unsigned) * (size_t)(maxCells + 1)) + 15) & ~(size_t)15);
+    }
+    { const char *e = getenv("MSL_OCT_STOP"); D.octStop = e ? atoi(e) : 0; }
+    if (D.octLds > 32 * 1024)   // (a large feature budget: more dynamic LDS than a launch gets by default)
+        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, D.octLds));
+    if (h->outCap == 0) h->outCap = std::max(h->nfeatures + 2 * L, needCap);   // creation: the handle's capacity follows its (max_width, max_height) geometry
+    if (needCap > h->outCap) {
+        set_error("frame %dx%d can return %d keypoints (aspect ratio: %d quadtree roots), the extractor was created for %d; create it with this frame size", W, H,
+                  needCap, D.lv[0].nIni, h->outCap);
+        return MSL_ERR_INVALID;
+    }
+    D.outCap = h->outCap;
     D.blurTiles = tileBase;
     D.pyrStride = (pyrOff + 255) & ~(size_t)255;
     D.blurStride = (blurOff + 255) & ~(size_t)255;
@@ -1115,7 +1311,7 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     hipLaunchKernelGGL(k_fast, dim3(P.cellsPerFrame, n), dim3(256), 0, s, P);
     h->prof.end(s);
     h->prof.begin(KID_OCTREE, s);
-    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), (size_t)OCT_NODE_BYTES * P.maxNode, s, P);
+    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), (size_t)P.octLds, s, P);
     h->prof.end(s);
     h->prof.begin(KID_BLUR, s);
     hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);
@@ -1190,7 +1386,8 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
     int prLo = 0, prHi = 0;   // frame-batched throughput work: lowest priority, so latency-critical streams of the process go first
     (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prLo) != hipSuccess ||
-        hipMalloc(&h->d_err, sizeof(int)) != hipSuccess || hipMemset(h->d_err, 0, sizeof(int)) != hipSuccess ||
+        hipMalloc(&h->d_err, 2048) != hipSuccess || hipMemset(h->d_err, 0, 2048) != hipSuccess ||   // [0] deferred error; from byte 128: 200 device-clock stamps of experiment builds
+        
         hipHostMalloc(&h->h_err, sizeof(int)) != hipSuccess) {
         set_error("msl_orb_create: HIP resource allocation failed");
         msl_orb_destroy(h);
@@ -1233,7 +1430,7 @@ int msl_orb_features_per_level(const msl_orb *h, int32_t *out) {
     for (int i = 0; i < h->nlevels; i++) out[i] = h->perLevel[i];
     return MSL_OK;
 }
-int msl_orb_capacity(const msl_orb *h) { return h ? h->nfeatures + 2 * h->nlevels : MSL_ERR_INVALID; }
+int msl_orb_capacity(const msl_orb *h) { return h ? h->outCap : MSL_ERR_INVALID; }
 int msl_orb_levels(const msl_orb *h) { return h ? h->nlevels : MSL_ERR_INVALID; }
 
 int msl_orb_set_stream(msl_orb *h, void *hip_stream) {
@@ -1266,7 +1463,7 @@ int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int wid
                   height, n_frames, h->maxW, h->maxH, h->maxBatch);
         return MSL_ERR_INVALID;
     }
-    const int outCap = h->nfeatures + 2 * h->nlevels;
+    const int outCap = h->outCap;
     if (cap < outCap) { set_error("msl_orb_extract_batch: cap %d < required %d", cap, outCap); return MSL_ERR_CAPACITY; }
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = build_geometry(h, width, height);
@@ -1356,7 +1553,7 @@ int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *de
         set_error("msl_orb_extract_frame_batch: invalid argument (call msl_frame_image_bounds first?)");
         return MSL_ERR_INVALID;
     }
-    const int outCap = h->nfeatures + 2 * h->nlevels;
+    const int outCap = h->outCap;
     if (cap < outCap) { set_error("msl_orb_extract_frame_batch: cap %d < required %d", cap, outCap); return MSL_ERR_CAPACITY; }
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = build_geometry(h, width, height);
@@ -1403,6 +1600,14 @@ int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *de
     MSL_HIP_TRY(hipMemcpy2DAsync(uright_out, sizeof(float) * cap, h->d_uRight, sizeof(float) * outCap, sizeof(float) * outCap, n_frames, kind, h->stream));
     MSL_HIP_TRY(hipMemcpy2DAsync(grid_cell, sizeof(int) * cap, h->d_gridCell, sizeof(int) * outCap, sizeof(int) * outCap, n_frames, kind, h->stream));
     if (out_mem == MSL_MEM_HOST) return check_device_error(h);
+    return MSL_OK;
+}
+
+int msl_orb_debug_stamps(msl_orb *h, uint64_t *out, int n) {
+    if (!h || !out || n < 0 || n > 200) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamSynchronize(h->stream));
+    MSL_HIP_TRY(hipMemcpy(out, reinterpret_cast<unsigned char *>(h->d_err) + 128, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
     return MSL_OK;
 }
 

@@ -546,9 +546,12 @@ __attribute__((always_inline)) inline void plane_mse_lanes(const double *in, dou
     const D sc = one / r[9];
     D a00 = r[3] - r[0] * r[0] * sc, a10 = r[6] - r[0] * r[1] * sc, a20 = r[8] - r[0] * r[2] * sc;
     D a11 = r[4] - r[1] * r[1] * sc, a21 = r[7] - r[1] * r[2] * sc, a22 = r[5] - r[2] * r[2] * sc;
-    auto vabs = [](D v) { return __builtin_elementwise_abs(v); };
-    auto vmax = [](D a, D b) { return __builtin_elementwise_max(a, b); };   // fmax: a NaN operand is ignored
-    auto vsqrt = [](D v) { return __builtin_elementwise_sqrt(v); };
+    // The helpers take and return 256- to 1024-bit vectors by value, and a lambda's call operator does not inherit the target("avx2" / "avx512f")
+    // attribute of the wrapper this template is inlined into: if the inliner ever declined, the call would cross an ABI boundary between feature
+    // sets (-Wpsabi) and could silently change the bits.  always_inline removes the dependence on heuristics; the build adds -Werror=psabi.
+    auto vabs = [](D v) __attribute__((always_inline)) { return __builtin_elementwise_abs(v); };
+    auto vmax = [](D a, D b) __attribute__((always_inline)) { return __builtin_elementwise_max(a, b); };   // fmax: a NaN operand is ignored
+    auto vsqrt = [](D v) __attribute__((always_inline)) { return __builtin_elementwise_sqrt(v); };
     D scale = vmax(vmax(vmax(vabs(a00), vabs(a10)), vmax(vabs(a11), vabs(a20))), vmax(vabs(a21), vabs(a22)));
     scale = MSL_SEL(scale == zero, one, scale);
     a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
@@ -561,7 +564,7 @@ __attribute__((always_inline)) inline void plane_mse_lanes(const double *in, dou
     D sb0 = MSL_SEL(small, a10, beta), sb1 = MSL_SEL(small, a21, a21 - m01 * qq);
     M end = itwo, start = izero, iter = izero, active = ~izero;
     // Givens rotation that annihilates z against x: the three scalar cases share one division, one square root and one reciprocal
-    auto givens = [&](D x, D z, D &c, D &sn) {
+    auto givens = [&](D x, D z, D &c, D &sn) __attribute__((always_inline)) {
         const M big = vabs(x) > vabs(z);
         const D num = MSL_SEL(big, z, x), den = MSL_SEL(big, x, z);
         const D t = num / den;

@@ -1805,8 +1805,12 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     load_surfel(M, i, h, e);
     dst[i] = e;
 }
-__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount) {
-    if (threadIdx.x == 0) { *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0; }
+// wide: -1 = leave the wide-rgb flag ctr[13] alone (upload: k_aos_to_soa has just set it if needed), 0 / 1 = the restored snapshot's flag
+__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount, int wide) {
+    if (threadIdx.x == 0) {
+        *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0;
+        if (wide >= 0) ctr[13] = wide;
+    }
 }
 
 __global__ void k_empty(int grid_dummy) { (void)grid_dummy; }
@@ -1850,6 +1854,7 @@ struct msl_sf {
     float *d_mapStore = nullptr; size_t mapCap = 0;
     size_t liveBound = 0;        // host-side upper bound of the live count: last known count + nseeds per keyframe enqueued since
     size_t liveKnown = 0;        // the most recent live count the host has seen (exact at that time; only a hint for k_fuse's speculative loads)
+    unsigned long long liveKnownKf = 0;   // ... and the number of keyframes that had been enqueued when it was exact: an older snapshot never replaces a newer one
     // asynchronous refresh of that bound: after every batch the live count is copied to pinned memory behind an event; a later call picks
     // up whatever has arrived, so the bound follows the real count a couple of batches late instead of forcing a pipeline drain
     // every capacity / nseeds keyframes
@@ -1982,7 +1987,7 @@ int read_ctr(msl_sf *h) {
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
     h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
-    h->liveKnown = h->liveBound;
+    h->liveKnown = h->liveBound; h->liveKnownKf = h->kfEnq;
     for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;   // (their events have fired: the stream is idle)
     return MSL_OK;
 }
@@ -2031,7 +2036,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
                 h->snapBusy[i] = false;
                 const size_t cand = (size_t)h->h_snap[i] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
                 if (cand < h->liveBound) h->liveBound = cand;
-                h->liveKnown = (size_t)h->h_snap[i];
+                if (h->snapKf[i] >= h->liveKnownKf) { h->liveKnown = (size_t)h->h_snap[i]; h->liveKnownKf = h->snapKf[i]; }   // completed snapshots are visited in array order, not age order
             }
         if (h->liveBound + need > h->mapCap) {
             int rc = read_ctr(h);
@@ -2319,9 +2324,9 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
         MSL_HIP_TRY(hipMemcpyAsync(h->d_aos, host, sizeof(msl_surfel) * n, hipMemcpyHostToDevice, s));
         LAUNCH(SK_CONVERT, s, k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), h->dev.map, h->d_aos, (long long)n);
     }
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2, -1);
     MSL_HIP_TRY(hipStreamSynchronize(s));
-    h->liveBound = n; h->liveKnown = n;
+    h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq;
     drop_live_snapshots(h);   // a count recorded before the upload would otherwise lower the bound below n
     return MSL_OK;
 }
@@ -2368,9 +2373,11 @@ int msl_sf_map_restore(msl_sf *h) {
             MSL_HIP_TRY(hipMemcpyAsync(h->dev.map.rgbWide, h->d_snapStore + 13 * h->snapCap, sizeof(int) * 3 * n, hipMemcpyDeviceToDevice, s));
         }
     }
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2);
+    // the restored map has exactly the snapshot's wide-rgb state: without the flag a later snapshot would skip rgbWide and a restore of THAT
+    // one would bring COLD_WIDE records back without their exact ints
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2, h->snapWide ? 1 : 0);
     MSL_HIP_TRY(hipGetLastError());
-    h->liveBound = n; h->liveKnown = n;
+    h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq;
     drop_live_snapshots(h);
     return MSL_OK;
 }
@@ -2490,7 +2497,7 @@ int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     hipLaunchKernelGGL(k_aos_to_soa_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->dev.map, h->d_aos, (long long)n, h->d_ctr);
     hipLaunchKernelGGL(k_add_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n);
     MSL_HIP_TRY(hipStreamSynchronize(s));
-    h->liveBound = cur + n; h->liveKnown = cur + n;
+    h->liveBound = cur + n; h->liveKnown = cur + n; h->liveKnownKf = h->kfEnq;
     return MSL_OK;
 }
 

@@ -17,7 +17,44 @@ def match_params(frame_params, scale_factors, th, check_orientation=True):
     return p
 
 
-def search_by_projection_batch(params, cur, last, Tcw_cur, Tcw_last, device=0):
+class Matcher:
+    """One msl_match handle (= one ORBmatcher object, src/ORBmatcher.cc:41): own stream, own cached device buffers."""
+
+    def __init__(self, device=0):
+        self.h = lib.msl_match_create(device)
+        if not self.h:
+            from ._lib import MslError
+            raise MslError(lib.msl_last_error().decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.msl_match_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        check(lib.msl_match_sync(self.h), "msl_match_sync")
+
+    def set_stream(self, hip_stream):
+        check(lib.msl_match_set_stream(self.h, hip_stream), "msl_match_set_stream")
+
+    def search_by_projection_batch(self, params, cur, last, Tcw_cur, Tcw_last):
+        return search_by_projection_batch(params, cur, last, Tcw_cur, Tcw_last, handle=self)
+
+    def search_by_projection_device(self, params, n_pairs, cap, arrays, match_out, nmatches):
+        """Device-resident inputs and outputs (torch tensors / device pointers in msl.h's argument order): asynchronous on the handle's stream."""
+        check(lib.msl_match_by_projection(self.h, n_pairs, cap, ptr(params), *[ptr(a) for a in arrays], 1, ptr(match_out), ptr(nmatches), 1), "msl_match_by_projection")
+
+    def descriptor_distance(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32); b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+        out = np.zeros(len(a), np.int32)
+        check(lib.msl_match_descriptor_distances(self.h, ptr(a), ptr(b), len(a), ptr(out)), "msl_match_descriptor_distances")
+        return out
+
+
+def search_by_projection_batch(params, cur, last, Tcw_cur, Tcw_last, device=0, handle=None):
     """cur / last: lists (one entry per pair) of dicts with the arrays msl.h names:
          cur:  kps (KEYPOINT_DTYPE), un_xy (N,2) f32, uright (N,) f32, grid_cell (N,) i32, desc (N,32) u8
          last: xyz (M,3) f32, desc (M,32) u8, flags (M,) u8, octave (M,) i32, angle (M,) f32
@@ -38,9 +75,12 @@ def search_by_projection_batch(params, cur, last, Tcw_cur, Tcw_last, device=0):
     tc = np.ascontiguousarray(np.asarray(Tcw_cur, np.float32)[:, :3, :4].reshape(B, 12))
     tl = np.ascontiguousarray(np.asarray(Tcw_last, np.float32)[:, :3, :4].reshape(B, 12))
     match = np.zeros((B, cap), np.int32); nm = np.zeros(B, np.int32)
-    check(lib.msl_match_by_projection_batch(device, B, cap, ptr(params), ptr(kps), ptr(un), ptr(ur), ptr(cell), ptr(cdesc), ptr(ncur), ptr(xyz),
-                                            ptr(ldesc), ptr(flags), ptr(octv), ptr(ang), ptr(nlast), ptr(tc), ptr(tl), MSL_MEM_HOST, ptr(match),
-                                            ptr(nm), MSL_MEM_HOST), "msl_match_by_projection_batch")
+    args = (B, cap, ptr(params), ptr(kps), ptr(un), ptr(ur), ptr(cell), ptr(cdesc), ptr(ncur), ptr(xyz), ptr(ldesc), ptr(flags), ptr(octv), ptr(ang),
+            ptr(nlast), ptr(tc), ptr(tl), MSL_MEM_HOST, ptr(match), ptr(nm), MSL_MEM_HOST)
+    if handle is not None:
+        check(lib.msl_match_by_projection(handle.h, *args), "msl_match_by_projection")
+    else:
+        check(lib.msl_match_by_projection_batch(device, *args), "msl_match_by_projection_batch")
     return [match[f, :ncur[f]].copy() for f in range(B)], nm
 
 

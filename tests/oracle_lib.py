@@ -114,7 +114,7 @@ class OracleOrb:
     def __init__(self, o, nfeatures, scale, nlevels, ini, mn):
         self.o = o
         self.nlevels = nlevels
-        self.cap = nfeatures + 2 * nlevels
+        self.cap = nfeatures + 2 * nlevels + 64 * nlevels      # wide frames: a level may return its first round's 4 * nIni nodes
         self.h = o.dll.mslo_orb_create(nfeatures, scale, nlevels, ini, mn)
 
     def __del__(self):

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/msl.h declares; no compute calls (no GPU needed)."""
+"""The C-ABI library loads and exports every symbol include/msl.h (the drop-in boundary) and include/msl_debug.h (test / measurement
+accessors) declare; no compute calls (no GPU needed)."""
 import ctypes as C
 import os
 import re
@@ -9,19 +10,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "msl.h")).read()
+def _declared(header="msl.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"MSL_API[^;(]*?\b(msl_\w+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():
     from manhattanslam_amd import _lib
-    names = _declared()
-    assert len(names) >= 35
+    api, dbg = _declared("msl.h"), _declared("msl_debug.h")
+    assert len(api) >= 40 and len(dbg) >= 14
+    # the drop-in header carries no debug / profiling / scratch-peek entry points, the debug header nothing else
+    assert not [n for n in api if "debug" in n or "profile" in n or "kernel_name" in n], api
+    assert all("debug" in n or "profile" in n or "kernel_name" in n for n in dbg), dbg
+    names = sorted(api + dbg)
     dll = C.CDLL(_lib.LIB_PATH)
     for n in names:
-        assert hasattr(dll, n), f"{n} declared in include/msl.h but not exported by libmsl.so"
+        assert hasattr(dll, n), f"{n} declared in include/ but not exported by libmsl.so"
     assert sorted(_lib.SIGNATURES) == names, set(names) ^ set(_lib.SIGNATURES)
 
 

@@ -21,19 +21,20 @@ def test_adapter_translation_unit_compiles(tu):
 
 
 def test_msl_h_is_valid_c11():
-    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
-                        os.path.join(ROOT, "include", "msl.h")], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for hdr in ("msl.h", "msl_debug.h"):
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                            os.path.join(ROOT, "include", hdr)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_c_host_links_against_libmsl(tmp_path):
     """A C translation unit that takes the address of every msl.h entry point links against libmsl.so (no GPU needed)."""
     import re
-    hdr = open(os.path.join(ROOT, "include", "msl.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "msl.h")).read() + open(os.path.join(ROOT, "include", "msl_debug.h")).read()
     names = sorted(set(re.findall(r"MSL_API[^;(]*?\b(msl_\w+)\s*\(", hdr)))
-    assert len(names) > 40
+    assert len(names) > 55
     src = tmp_path / "link_all.c"
-    src.write_text('#include "msl.h"\n#include <stdio.h>\nint main(void) {\n  const void *p[] = {' +
+    src.write_text('#include "msl_debug.h"\n#include <stdio.h>\nint main(void) {\n  const void *p[] = {' +
                    ", ".join(f"(const void *)&{n}" for n in names) +
                    '};\n  printf("%zu\\n", sizeof(p) / sizeof(p[0]));\n  return p[0] == 0;\n}\n')
     exe = tmp_path / "link_all"

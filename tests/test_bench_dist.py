@@ -93,6 +93,20 @@ def test_bench_eight_ranks_bind_distinct_devices_and_sequences():
     assert line["value"] == round(frames / 0.045, 1)               # rank 7 is the slowest fabricated rank: 10 + 5 * 7 ms
 
 
+def test_eight_ranks_with_two_sequences_per_gpu():
+    """--sequences-per-gpu 2 on the 8-GPU shape: rank r runs the global sequences 2 r and 2 r + 1 (16 distinct seed sets over the node), binds
+    device r, and the frame count of the gathered records doubles."""
+    rc, line, err = _run_bench("--gpus", "8", "--config", "5", "--dry-run", "--steps", "2", "--sequences-per-gpu", "2")
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 8 and line["sequences_per_gpu"] == 2
+    b = line["binding_per_rank"]
+    assert [x["device"] for x in b] == list(range(8)) and all(x["sequences"] == 2 for x in b)
+    assert line["global_sequences_per_rank"] == [[2 * r, 2 * r + 1] for r in range(8)]
+    assert [x["frame_seed"] for x in b] == [7 + 1000 * 2 * r for r in range(8)]         # first sequence of every rank: no seed shared between ranks
+    frames = sum(c[0] for c in line["counters_per_rank"])
+    assert frames == 8 * 2 * 2 * line["config"]["frames_per_pass"] * line["config"]["passes_per_step"]
+
+
 def test_pmc_traffic_is_quoted_only_for_the_profiled_kernel_sources(tmp_path, monkeypatch):
     """roofline.traffic comes from the committed PMC summary only while the kernel sources still hash to the value stored in it."""
     import json

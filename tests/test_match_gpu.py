@@ -68,3 +68,47 @@ def test_matching_consumes_orb_frame_outputs(oracle):
     want, n = oracle_lib.search_by_projection(p, cur, last, Tc, Tl)
     assert nm[0] == n and np.array_equal(got[0], want)
     assert n > 300      # the shifted frame really is re-found
+
+
+def test_matcher_handles_own_stream_and_buffers(oracle):
+    """msl_match handles (one per ORBmatcher object): two handles used alternately with calls of different sizes (their cached buffers grow
+    independently), the host form and the device-resident asynchronous form on the handle's own stream, all equal to the oracle."""
+    import torch
+    from manhattanslam_amd import match, MATCH_PARAMS_DTYPE
+    from manhattanslam_amd.match import Matcher
+    from tests import oracle_lib
+    p = ms.params(None, 15, True, dtype=MATCH_PARAMS_DTYPE)
+    m1, m2 = Matcher(), Matcher()
+    for rnd, (nc, nl) in enumerate(((300, 280), (1016, 1000), (120, 500))):
+        pairs = [ms.random_pair(200 + 10 * rnd + j, p, n_cur=nc, n_last=nl, tz=0.3 * (j - 1)) for j in range(3)]
+        cur = [q[0] for q in pairs]; last = [q[1] for q in pairs]; Tc = np.stack([q[2] for q in pairs]); Tl = np.stack([q[3] for q in pairs])
+        for m in (m1, m2):
+            got, nm = m.search_by_projection_batch(p, cur, last, Tc, Tl)
+            for f in range(3):
+                want, n = oracle_lib.search_by_projection(p, cur[f], last[f], Tc[f], Tl[f])
+                assert nm[f] == n and np.array_equal(got[f], want), (rnd, f)
+    # device-resident form: packed [pairs][cap] arrays as torch tensors, asynchronous until msl_match_sync
+    B, cap = 3, 1016
+    from manhattanslam_amd._lib import KEYPOINT_DTYPE
+    kps = np.zeros((B, cap), KEYPOINT_DTYPE); un = np.zeros((B, cap, 2), np.float32); ur = np.zeros((B, cap), np.float32); cell = np.full((B, cap), -1, np.int32)
+    cd = np.zeros((B, cap, 32), np.uint8); ncur = np.zeros(B, np.int32); xyz = np.zeros((B, cap, 3), np.float32); ld = np.zeros((B, cap, 32), np.uint8)
+    fl = np.zeros((B, cap), np.uint8); oc = np.zeros((B, cap), np.int32); an = np.zeros((B, cap), np.float32); nlast = np.zeros(B, np.int32)
+    pairs = [ms.random_pair(300 + j, p, n_cur=900 + 50 * j, n_last=850, tz=0.0) for j in range(B)]
+    for f, (c, l, _, _) in enumerate(pairs):
+        n, m = len(c["kps"]), len(l["xyz"])
+        ncur[f], nlast[f] = n, m
+        kps[f, :n] = c["kps"]; un[f, :n] = c["un_xy"]; ur[f, :n] = c["uright"]; cell[f, :n] = c["grid_cell"]; cd[f, :n] = c["desc"]
+        xyz[f, :m] = l["xyz"]; ld[f, :m] = l["desc"]; fl[f, :m] = l["flags"]; oc[f, :m] = l["octave"]; an[f, :m] = l["angle"]
+    tc = np.stack([q[2][:3, :4].reshape(12) for q in pairs]).astype(np.float32); tl = np.stack([q[3][:3, :4].reshape(12) for q in pairs]).astype(np.float32)
+    dev = [torch.from_numpy(a.view(np.uint8) if a.dtype == KEYPOINT_DTYPE else a).cuda() for a in (kps, un, ur, cell, cd, ncur, xyz, ld, fl, oc, an, nlast, tc, tl)]
+    out = torch.full((B, cap), -7, dtype=torch.int32, device="cuda"); nm = torch.zeros(B, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    m1.search_by_projection_device(p, B, cap, dev, out, nm)
+    m1.sync()
+    out, nm = out.cpu().numpy(), nm.cpu().numpy()
+    for f, (c, l, Tc_, Tl_) in enumerate(pairs):
+        want, n = oracle_lib.search_by_projection(p, c, l, Tc_, Tl_)
+        assert nm[f] == n and np.array_equal(out[f, :len(want)], want), f
+    a = np.random.default_rng(1).integers(0, 256, (77, 32), dtype=np.uint8)
+    assert np.array_equal(m2.descriptor_distance(a, a[::-1].copy()), oracle_lib.descriptor_distance(a, a[::-1].copy()))
+    m1.close(); m2.close()

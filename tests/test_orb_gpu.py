@@ -133,6 +133,25 @@ def test_feature_budgets_size_the_quadtree(oracle):
         ex.close()
 
 
+@pytest.mark.parametrize("w,h,nf,levels,scale", [(640, 160, 137, 4, 1.2), (1280, 200, 1000, 5, 1.2), (640, 480, 60, 12, 1.1), (960, 200, 2000, 3, 1.5),
+                                                 (400, 304, 24, 1, 1.2), (1279, 333, 777, 8, 1.2), (1600, 230, 300, 6, 1.2)])
+def test_quadtree_node_bound_over_geometries(oracle, w, h, nf, levels, scale):
+    """The quadtree's node arrays are sized analytically (max(quota, 4 nIni) + 2 per level): wide images (nIni = round(width / height) up to 8 root
+    nodes; tall ones have nIni = 0, which the reference itself cannot handle), tiny and large budgets, 1 to 12 levels, low thresholds so that every
+    level reaches its quota.  1600 x 230 with 300 features returns MORE than nfeatures + 2 levels keypoints (the first quadtree round alone makes
+    up to 4 nIni nodes per level): the extractor's capacity follows its creation geometry.  An overrun would zero a level (device error); the
+    outputs must be the oracle's, bit for bit."""
+    from manhattanslam_amd import ORBextractor, synth
+    k = max(-(-w // 640), -(-h // 480))
+    img = synth.orb_frame(300 + w + nf, 640 * k, 480 * k)[:h, :w].copy()          # the generator makes 4:3 frames: crop one
+    ex = ORBextractor(nf, scale, levels, 9, 5, max_width=w, max_height=h)
+    ko, do = oracle.orb_create(nf, scale, levels, 9, 5).extract(img)
+    kg, dg = ex(img)          # raises on a device-side bound error
+    _assert_same(kg, dg, ko, do)
+    assert len(kg) >= min(nf, 20) and ex.capacity >= max(len(kg), nf + 2 * levels)
+    ex.close()
+
+
 def test_device_resident_batch(oracle):
     """Asynchronous batch path with inputs and outputs resident in HBM (the bench.py path)."""
     import torch
