@@ -1056,6 +1056,9 @@ struct msl_orb {
     uint32_t *d_sel = nullptr; int *d_nsel = nullptr, *d_ncand = nullptr;
     msl_keypoint *d_kps = nullptr; uint8_t *d_desc = nullptr; int *d_nout = nullptr; int *d_err = nullptr;
     int *h_err = nullptr;  // pinned
+    uint8_t *d_outBlock = nullptr; size_t outBlockBytes = 0, outKpsOff = 0, outDescOff = 0;   // [nout[B] | kps[B][cap] | desc[B][cap]] in one allocation
+    uint8_t *h_pinIn = nullptr, *h_pinOut = nullptr; size_t pinInBytes = 0, pinOutBytes = 0;   // pinned staging of the single-frame drop-in call
+    hipStream_t sideStream = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr;             // single-frame calls: the blur runs beside FAST + quadtree
     float *d_depthIn = nullptr; size_t depthInCap = 0;     // staged depth frames (host input)
     float *d_unXY = nullptr, *d_depthOut = nullptr, *d_uRight = nullptr; int *d_gridCell = nullptr; bool frameBufs = false;
     int lastFrames = 0;
@@ -1067,7 +1070,7 @@ namespace {
 void free_geometry(msl_orb *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_in); F(h->d_pyr); F(h->d_blur); F(h->d_cells); F(h->d_taps); F(h->d_pyrRanges); F(h->d_cellCnt); F(h->d_cellKeys);
-    F(h->d_keys); F(h->d_knode); F(h->d_sel); F(h->d_nsel); F(h->d_ncand); F(h->d_kps); F(h->d_desc); F(h->d_nout);
+    F(h->d_keys); F(h->d_knode); F(h->d_sel); F(h->d_nsel); F(h->d_ncand); F(h->d_outBlock); h->d_kps = nullptr; h->d_desc = nullptr; h->d_nout = nullptr;
     h->geomW = h->geomH = 0;
 }
 
@@ -1260,9 +1263,14 @@ int build_geometry(msl_orb *h, int W, int H) {
     MSL_HIP_TRY(hipMalloc(&h->d_sel, sizeof(uint32_t) * (size_t)D.selCap * L * B));
     MSL_HIP_TRY(hipMalloc(&h->d_nsel, sizeof(int) * L * B));
     MSL_HIP_TRY(hipMalloc(&h->d_ncand, sizeof(int) * L * B));
-    MSL_HIP_TRY(hipMalloc(&h->d_kps, sizeof(msl_keypoint) * (size_t)D.outCap * B));
-    MSL_HIP_TRY(hipMalloc(&h->d_desc, (size_t)32 * D.outCap * B));
-    MSL_HIP_TRY(hipMalloc(&h->d_nout, sizeof(int) * B));
+    // outputs of a call in ONE allocation, counts first: the single-frame drop-in call fetches everything with one copy
+    h->outKpsOff = (sizeof(int) * (size_t)B + 255) & ~(size_t)255;
+    h->outDescOff = h->outKpsOff + ((sizeof(msl_keypoint) * (size_t)D.outCap * B + 255) & ~(size_t)255);
+    h->outBlockBytes = h->outDescOff + (size_t)32 * D.outCap * B;
+    MSL_HIP_TRY(hipMalloc(&h->d_outBlock, h->outBlockBytes));
+    h->d_nout = reinterpret_cast<int *>(h->d_outBlock);
+    h->d_kps = reinterpret_cast<msl_keypoint *>(h->d_outBlock + h->outKpsOff);
+    h->d_desc = h->d_outBlock + h->outDescOff;
     MSL_HIP_TRY(hipMemcpy(h->d_cells, cells.data(), sizeof(CellDev) * cells.size(), hipMemcpyHostToDevice));
     if (!taps.empty())
         MSL_HIP_TRY(hipMemcpy(h->d_taps, taps.data(), sizeof(ResizeTap) * taps.size(), hipMemcpyHostToDevice));
@@ -1307,15 +1315,28 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
             h->prof.end(s);
         }
     }
+    // One frame cannot fill the GPU and every kernel is a dependent launch: the blur (needs the pyramid only) then runs on a side stream beside
+    // FAST + quadtree instead of behind them.  Batched calls keep one stream: their kernels fill the GPU and the order keeps each frame's data warm.
+    const bool fork = n == 1 && h->sideStream && !h->prof.on;
+    if (fork) {
+        MSL_HIP_TRY(hipEventRecord(h->evFork, s));
+        MSL_HIP_TRY(hipStreamWaitEvent(h->sideStream, h->evFork, 0));
+        hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, h->sideStream, P);
+        MSL_HIP_TRY(hipEventRecord(h->evJoin, h->sideStream));
+    }
     h->prof.begin(KID_FAST, s);
     hipLaunchKernelGGL(k_fast, dim3(P.cellsPerFrame, n), dim3(256), 0, s, P);
     h->prof.end(s);
     h->prof.begin(KID_OCTREE, s);
     hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), (size_t)P.octLds, s, P);
     h->prof.end(s);
-    h->prof.begin(KID_BLUR, s);
-    hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);
-    h->prof.end(s);
+    if (fork) {
+        MSL_HIP_TRY(hipStreamWaitEvent(s, h->evJoin, 0));
+    } else {
+        h->prof.begin(KID_BLUR, s);
+        hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);
+        h->prof.end(s);
+    }
     h->prof.begin(KID_DESCRIBE, s);
     hipLaunchKernelGGL(k_describe, dim3((P.selCap + 3) / 4, L, n), dim3(256), 0, s, P);
     h->prof.end(s);
@@ -1387,8 +1408,9 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
     (void)hipDeviceGetStreamPriorityRange(&prLo, &prHi);
     if (hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prLo) != hipSuccess ||
         hipMalloc(&h->d_err, 2048) != hipSuccess || hipMemset(h->d_err, 0, 2048) != hipSuccess ||   // [0] deferred error; from byte 128: 200 device-clock stamps of experiment builds
-        
-        hipHostMalloc(&h->h_err, sizeof(int)) != hipSuccess) {
+        hipHostMalloc(&h->h_err, sizeof(int)) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->sideStream, hipStreamNonBlocking, prLo) != hipSuccess ||
+        hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) {
         set_error("msl_orb_create: HIP resource allocation failed");
         msl_orb_destroy(h);
         return nullptr;
@@ -1406,11 +1428,16 @@ void msl_orb_destroy(msl_orb *h) {
     free_geometry(h);
     if (h->d_err) (void)hipFree(h->d_err);
     if (h->h_err) (void)hipHostFree(h->h_err);
+    if (h->h_pinIn) (void)hipHostFree(h->h_pinIn);
+    if (h->h_pinOut) (void)hipHostFree(h->h_pinOut);
     if (h->d_depthIn) (void)hipFree(h->d_depthIn);
     if (h->d_unXY) (void)hipFree(h->d_unXY);
     if (h->d_depthOut) (void)hipFree(h->d_depthOut);
     if (h->d_uRight) (void)hipFree(h->d_uRight);
     if (h->d_gridCell) (void)hipFree(h->d_gridCell);
+    if (h->sideStream) { (void)hipStreamSynchronize(h->sideStream); (void)hipStreamDestroy(h->sideStream); }
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->stream && h->ownStream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1497,9 +1524,65 @@ int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int wid
     return MSL_OK;
 }
 
+// The reference's call pattern: one frame per call, host buffers in and out, the result needed before the caller goes on (src/Frame.cc:100,
+// 175-177).  Latency is everything here, so this form avoids every pageable-memory transfer: the frame goes through a pinned staging buffer
+// (one CPU copy, one DMA), the counts, keypoints and descriptors come back as ONE copy of the output block into pinned memory next to the
+// error word, and a single stream synchronisation ends the call (the batch form issues four device-to-host copies into pageable memory).
+static int extract_one_host(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride, msl_keypoint *kps, uint8_t *desc32, int cap, int *n_out) {
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc = build_geometry(h, width, height);
+    if (rc != MSL_OK) return rc;
+    const int outCap = h->outCap;
+    if (cap < outCap) { set_error("msl_orb_extract: cap %d < required %d", cap, outCap); return MSL_ERR_CAPACITY; }
+    const size_t inBytes = h->inPitch * (size_t)height;
+    // frame 0's share of the output block: counts (all B of them: a few bytes), its keypoints and -- B == 1 only -- its descriptors contiguous
+    const size_t outBytes = h->maxBatch == 1 ? h->outBlockBytes : 0;
+    if (inBytes > h->pinInBytes) {
+        if (h->h_pinIn) (void)hipHostFree(h->h_pinIn);
+        h->h_pinIn = nullptr; h->pinInBytes = 0;
+        MSL_HIP_TRY(hipHostMalloc(&h->h_pinIn, inBytes));
+        h->pinInBytes = inBytes;
+    }
+    const size_t needOut = h->outKpsOff + sizeof(msl_keypoint) * (size_t)outCap + (size_t)32 * outCap + 256;
+    if (needOut > h->pinOutBytes) {
+        if (h->h_pinOut) (void)hipHostFree(h->h_pinOut);
+        h->h_pinOut = nullptr; h->pinOutBytes = 0;
+        MSL_HIP_TRY(hipHostMalloc(&h->h_pinOut, needOut));
+        h->pinOutBytes = needOut;
+    }
+    hipStream_t s = h->stream;
+    h->prof.begin(KID_COPY, s);
+    // (one copy: splitting it so that the DMA of the first half overlaps the CPU copy of the second measured 6 us SLOWER -- an enqueue costs more than it hides)
+    if (stride == h->inPitch) memcpy(h->h_pinIn, gray, stride * (size_t)(height - 1) + width);
+    else for (int y = 0; y < height; y++) memcpy(h->h_pinIn + (size_t)y * h->inPitch, gray + (size_t)y * stride, (size_t)width);
+    MSL_HIP_TRY(hipMemcpyAsync(h->d_in, h->h_pinIn, inBytes, hipMemcpyHostToDevice, s));
+    h->prof.end(s);
+    rc = launch_pipeline(h, h->d_in, h->inPitch, inBytes, 1, h->d_kps, h->d_desc, h->d_nout);
+    if (rc != MSL_OK) return rc;
+    const size_t kpsBytes = sizeof(msl_keypoint) * (size_t)outCap, descBytes = (size_t)32 * outCap;
+    uint8_t *hk = h->h_pinOut + h->outKpsOff, *hd = hk + ((kpsBytes + 255) & ~(size_t)255);
+    if (outBytes) {   // a one-frame handle: counts | keypoints | descriptors are one contiguous block
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_pinOut, h->d_outBlock, outBytes, hipMemcpyDeviceToHost, s));
+        hd = h->h_pinOut + h->outDescOff;
+    } else {
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_pinOut, h->d_nout, sizeof(int), hipMemcpyDeviceToHost, s));
+        MSL_HIP_TRY(hipMemcpyAsync(hk, h->d_kps, kpsBytes, hipMemcpyDeviceToHost, s));
+        MSL_HIP_TRY(hipMemcpyAsync(hd, h->d_desc, descBytes, hipMemcpyDeviceToHost, s));
+    }
+    rc = check_device_error(h);   // error word into pinned memory, then the call's only synchronisation
+    if (rc != MSL_OK) { *n_out = 0; return rc; }
+    const int n = *reinterpret_cast<const int *>(h->h_pinOut);
+    memcpy(kps, hk, sizeof(msl_keypoint) * (size_t)n);
+    memcpy(desc32, hd, (size_t)32 * n);
+    *n_out = n;
+    return MSL_OK;
+}
+
 int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride, msl_keypoint *kps,
                     uint8_t *desc32, int cap, int *n_out) {
     if (!n_out) { set_error("msl_orb_extract: n_out is NULL"); return MSL_ERR_INVALID; }
+    if (h && gray && width > 0 && height > 0 && width <= h->maxW && height <= h->maxH && stride >= (size_t)width && kps && desc32)
+        return extract_one_host(h, gray, width, height, stride, kps, desc32, cap, n_out);
     int32_t n = 0;
     const int rc = msl_orb_extract_batch(h, gray, 1, width, height, stride, stride * (size_t)height, MSL_MEM_HOST, kps, desc32,
                                          cap, &n, MSL_MEM_HOST);
