@@ -679,6 +679,10 @@ def dropin_shapes(grays, depths, member, poses, smap, W, H, intr, do_orb, do_sf,
             s2.fuseInitializeMap(1 + i, grays[(1 + i) % len(grays)], depths[(1 + i) % len(grays)], member, poses[(1 + i) % len(grays)], local)
         out["msl_sf_fuse_host_vector_ms"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
         out["msl_sf_fuse_host_vector_surfels"] = len(local)
+        t0 = time.perf_counter()
+        for i in range(n):   # the same calls with MSL_SF_LOCAL_UNCHANGED: nobody touched `local` since the previous call, so nothing is uploaded
+            s2.fuseInitializeMap(4 + i, grays[(4 + i) % len(grays)], depths[(4 + i) % len(grays)], member, poses[(4 + i) % len(grays)], local, local_unchanged=True)
+        out["msl_sf_fuse_host_vector_unchanged_hint_ms"] = round((time.perf_counter() - t0) * 1e3 / n, 3)
         s2.close()
     out["note"] = "synchronous drop-in entry points with host buffers (PCIe in and out included); one frame / one keyframe per call"
     return out

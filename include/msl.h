@@ -177,6 +177,17 @@ MSL_API int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray,
                         size_t member_stride, const float pose_colmajor[16], msl_surfel *local,
                         size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new);
 
+/* The same with hints.  MSL_SF_LOCAL_UNCHANGED: local[0 .. n_local) is byte for byte what the previous msl_sf_fuse / msl_sf_fuse_ex call on this
+ * handle left there (a caller that keeps the new surfels in a list of their own, or that has not run SurfelMapping::fuseMap's refill yet); the
+ * library then fuses into the device copy of that call instead of uploading 56 bytes per surfel again.  The hint is ignored -- a full upload
+ * happens -- when the length differs or any other map operation touched the handle in between.  Both forms send back only the stretches of
+ * `local` that hold surfels this keyframe updated or deleted (per 256-surfel sub-block), not the whole vector. */
+#define MSL_SF_LOCAL_UNCHANGED 1u
+MSL_API int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride,
+                           const float *depth, size_t depth_stride, const int32_t *member,
+                           size_t member_stride, const float pose_colmajor[16], msl_surfel *local,
+                           size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags);
+
 /* Device-resident map mode: the live surfel map stays in HBM between keyframes. */
 MSL_API int msl_sf_map_reserve(msl_sf *h, size_t capacity);
 MSL_API int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "msl_sf_create": (_vp, [_i, _i, _f, _f, _f, _f, _f, _f, _i]),
     "msl_sf_destroy": (None, [_vp]),
     "msl_sf_fuse": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "msl_sf_fuse_ex": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, C.c_uint]),
     "msl_sf_map_reserve": (_i, [_vp, _sz]),
     "msl_sf_map_upload": (_i, [_vp, _vp, _sz]),
     "msl_sf_map_download": (_i, [_vp, _vp, _sz, _vp]),

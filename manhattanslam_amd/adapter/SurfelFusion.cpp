@@ -25,11 +25,15 @@ void SurfelFusion::fuseInitializeMap(const int referenceFrameIndex, const cv::Ma
     const size_t cap = (size_t)(imageWidth / 8) * (imageHeight / 8);
     newSurfels.resize(cap);                                       // :289 clears it; at most one surfel per superpixel
     size_t nNew = 0;
-    check(msl_sf_fuse(mHandle, referenceFrameIndex, inputImage.data, inputImage.step, inputDepth.ptr<float>(), inputDepth.step,
-                      inputPlaneMembershipImg.ptr<int32_t>(), inputPlaneMembershipImg.step, pose.data() /* column-major */,
-                      reinterpret_cast<msl_surfel *>(localSurfels.data()), localSurfels.size(),
-                      reinterpret_cast<msl_surfel *>(newSurfels.data()), cap, &nNew),
-          "msl_sf_fuse");
+    // A caller that has not touched localSurfels since the previous call may say so (localSurfelsUnchangedSinceLastCall(): one-shot, an
+    // extension the reference does not have): the 56 bytes per surfel are then not uploaded again.  Only touched stretches come back either way.
+    const unsigned flags = mLocalUnchanged ? MSL_SF_LOCAL_UNCHANGED : 0u;
+    mLocalUnchanged = false;
+    check(msl_sf_fuse_ex(mHandle, referenceFrameIndex, inputImage.data, inputImage.step, inputDepth.ptr<float>(), inputDepth.step,
+                         inputPlaneMembershipImg.ptr<int32_t>(), inputPlaneMembershipImg.step, pose.data() /* column-major */,
+                         reinterpret_cast<msl_surfel *>(localSurfels.data()), localSurfels.size(),
+                         reinterpret_cast<msl_surfel *>(newSurfels.data()), cap, &nNew, flags),
+          "msl_sf_fuse_ex");
     newSurfels.resize(nNew);
 }
 

@@ -38,10 +38,12 @@ public:
     // Waits for the enqueued keyframes and throws if a device-side bound was exceeded (errors of the asynchronous
     // resident calls are deferred to the next sync).
     void sync();
+    void localSurfelsUnchangedSinceLastCall() { mLocalUnchanged = true; }   // hint for the NEXT fuseInitializeMap (MSL_SF_LOCAL_UNCHANGED)
     msl_sf *handle() const { return mHandle; }   // for adapter/SurfelMapping.cpp (map maintenance on the resident map)
 
 private:
     msl_sf *mHandle;
+    bool mLocalUnchanged = false;
     int imageWidth, imageHeight;
 };
 

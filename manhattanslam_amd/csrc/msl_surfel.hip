@@ -1813,6 +1813,29 @@ __global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount, int 
     }
 }
 
+// Host-vector mode, sparse case: the records this keyframe touched (updated: lastUpdate == ref; deleted: updateTimes == 0) of the sub-blocks that
+// report any, as a compact list {index, reference-layout record}.  One wave per sub-block; slots by one atomic per wave.
+__global__ __launch_bounds__(64) void k_collect_changed(SfDev P, int ref, long long n, unsigned *count, unsigned *idxOut, msl_surfel *recOut, unsigned capOut) {
+    const long long sb = blockIdx.x;
+    if (!(P.blockSums[sb] | P.blockUpd[sb])) return;
+    const unsigned lane = threadIdx.x;
+    for (int k = 0; k < SUB_ITEMS / 64; k++) {
+        const long long i = sb * SUB_ITEMS + k * 64 + lane;
+        HotRec h; h.updateTimes = 1; h.lastUpdate = ref - 1;
+        if (i < n) h = P.map.hot[i];
+        const bool ch = i < n && (h.updateTimes == 0 || h.lastUpdate == ref);
+        const unsigned long long m = __ballot(ch);
+        if (!m) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ch) {
+            const unsigned j = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (j < capOut) { msl_surfel e; load_surfel(P.map, i, h, e); recOut[j] = e; idxOut[j] = (unsigned)i; }
+        }
+    }
+}
+
 __global__ void k_empty(int grid_dummy) { (void)grid_dummy; }
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1864,6 +1887,10 @@ struct msl_sf {
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     float *d_snapStore = nullptr; size_t snapCap = 0, snapN = 0; bool snapValid = false, snapWide = false;   // msl_sf_map_snapshot / _restore
+    // host-vector mode (msl_sf_fuse_ex): the device map equals the caller's vector as the last call left it
+    bool mirrorValid = false; size_t mirrorN = 0;
+    unsigned *h_blk = nullptr; size_t blkCap = 0;   // pinned: per-sub-block deleted / updated counts of the call's k_fuse launch
+    uint8_t *h_list = nullptr; size_t listCap = 0;  // pinned: {count | indices | records} of the sparse download
     KernelProfiler prof;
 };
 
@@ -2027,6 +2054,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         return MSL_ERR_INVALID;
     }
     if (compact) {
+        h->mirrorValid = false;   // the resident map moves on without the host-vector caller
         // The reference's mvLocalSurfels is an unbounded std::vector (include/Map.h:130): grow the resident map before a batch could
         // overflow it.  Every keyframe adds at most nseeds surfels, so the host only needs an upper bound of the live count; the
         // exact count is read back (one sync) only when that bound reaches the capacity.
@@ -2254,6 +2282,8 @@ void msl_sf_destroy(msl_sf *h) {
     F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos); F(h->d_snapStore);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_snap) (void)hipHostFree(h->h_snap);
+    if (h->h_blk) (void)hipHostFree(h->h_blk);
+    if (h->h_list) (void)hipHostFree(h->h_list);
     for (int i = 0; i < msl_sf::NSNAP; i++) if (h->snapEv[i]) (void)hipEventDestroy(h->snapEv[i]);
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); if (h->evH2D[i]) (void)hipEventDestroy(h->evH2D[i]); }
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
@@ -2309,6 +2339,7 @@ static int ensure_aos(msl_sf *h, size_t n) {
 
 int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     if (!h || (n && !host)) return MSL_ERR_INVALID;
+    h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
@@ -2357,6 +2388,7 @@ int msl_sf_map_snapshot(msl_sf *h) {
 
 int msl_sf_map_restore(msl_sf *h) {
     if (!h || !h->snapValid) { set_error("msl_sf_map_restore: no snapshot"); return MSL_ERR_INVALID; }
+    h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
     const size_t n = h->snapN;
     if (n + (size_t)h->dev.nseeds > h->mapCap) {   // the map was reallocated smaller than the snapshot (upload of a small map): grow again
@@ -2412,6 +2444,7 @@ int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) 
 
 static int map_select(msl_sf *h, int mode, int arg, bool mark, msl_surfel *out, size_t cap, size_t *n_out, const char *what) {
     if (!h || !n_out) { set_error("%s: invalid argument", what); return MSL_ERR_INVALID; }
+    if (mark) h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);                       // waits for both streams
     if (rc != MSL_OK) return rc;
@@ -2481,6 +2514,7 @@ int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactiv
 
 int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     if (!h || (n && !surfels)) { set_error("msl_sf_map_append: invalid argument"); return MSL_ERR_INVALID; }
+    h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
@@ -2529,30 +2563,117 @@ int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) {
     return check_err(h);
 }
 
-int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
-                const int32_t *member, size_t member_stride, const float pose_colmajor[16], msl_surfel *local, size_t n_local,
-                msl_surfel *new_out, size_t new_cap, size_t *n_new) {
+// Host-vector mode.  The caller's vector is the map for this call; what travels is kept to what has to:
+//   in : the whole vector (56 B per surfel) -- unless MSL_SF_LOCAL_UNCHANGED says it still is what the previous call on this handle left there, in
+//        which case the device copy of that call is used as it stands (checked: same length, no other map operation on the handle in between);
+//   out: only the stretches of the vector that hold surfels this keyframe touched.  k_fuse leaves a deleted and an updated count per 256-surfel
+//        sub-block; sub-blocks with neither are byte-identical to the caller's copy and are not sent back (runs of touched sub-blocks travel as
+//        one copy each, small gaps bridged; more than 64 runs collapse into fewer by bridging larger gaps).
+int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
+                   const int32_t *member, size_t member_stride, const float pose_colmajor[16], msl_surfel *local, size_t n_local,
+                   msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags) {
     if (!h || !pose_colmajor || !n_new || (n_local && !local)) { set_error("msl_sf_fuse: invalid argument"); return MSL_ERR_INVALID; }
     if (new_cap < (size_t)h->dev.nseeds || !new_out) { set_error("msl_sf_fuse: new_cap must be >= (w/8)*(h/8) = %d", h->dev.nseeds); return MSL_ERR_CAPACITY; }
-    int rc = msl_sf_map_upload(h, local, n_local);   // the caller's vector is the map for this call
-    if (rc != MSL_OK) return rc;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    int rc;
+    const bool reuse = (flags & MSL_SF_LOCAL_UNCHANGED) && h->mirrorValid && h->mirrorN == n_local;
+    if (reuse) {
+        // the device map is the caller's vector already: only the per-call counters start over
+        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr, (long long)n_local, h->d_tickets + 2, -1);
+        h->liveBound = n_local; h->liveKnown = n_local; h->liveKnownKf = h->kfEnq;
+    } else {
+        rc = msl_sf_map_upload(h, local, n_local);
+        if (rc != MSL_OK) return rc;
+    }
+    h->mirrorValid = false;   // (until this call has completed)
     const int32_t ref = referenceFrameIndex;
     rc = run_batch(h, 1, &ref, gray, gray_stride, 0, depth, depth_stride, 0, member, member_stride, 0, MSL_MEM_HOST, pose_colmajor, false);
     if (rc != MSL_OK) return rc;
-    rc = read_ctr(h);
+    hipStream_t s = h->mapStream;
+    const size_t nblk = (n_local + SUB_ITEMS - 1) / SUB_ITEMS;
+    if (nblk > h->blkCap) {
+        if (h->h_blk) (void)hipHostFree(h->h_blk);
+    if (h->h_list) (void)hipHostFree(h->h_list);
+        h->h_blk = nullptr; h->blkCap = 0;
+        MSL_HIP_TRY(hipHostMalloc(&h->h_blk, sizeof(unsigned) * 2 * (nblk + 1024)));
+        h->blkCap = nblk + 1024;
+    }
+    if (nblk) {
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk, h->dev.blockSums, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk + h->blkCap, h->dev.blockUpd, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
+    }
+    rc = read_ctr(h);   // the call's first synchronisation: counters and the per-sub-block counts are on the host
     if (rc != MSL_OK) return rc;
     rc = check_err(h);
     if (rc != MSL_OK) return rc;
     const size_t K = (size_t)h->h_ctr[1];
     *n_new = K;
-    hipStream_t s = h->mapStream;
-    if (n_local) {
+    // what was touched, and where
+    struct Run { size_t b0, b1; };
+    std::vector<Run> runs;
+    size_t touched = 0, runSurfels = 0;
+    for (size_t b = 0; b < nblk; b++) touched += (size_t)h->h_blk[b] + h->h_blk[h->blkCap + b];
+    for (size_t gapMax = 4; ; gapMax *= 4) {
+        runs.clear();
+        for (size_t b = 0; b < nblk; b++) {
+            if (!(h->h_blk[b] | h->h_blk[h->blkCap + b])) continue;
+            if (!runs.empty() && b - runs.back().b1 <= gapMax) runs.back().b1 = b + 1;
+            else runs.push_back({b, b + 1});
+        }
+        if (runs.size() <= 64) break;
+    }
+    for (const Run &r : runs) runSurfels += std::min(r.b1 * SUB_ITEMS, n_local) - r.b0 * SUB_ITEMS;
+    // Two ways back.  Runs of touched sub-blocks copied straight into the caller's vector (~45 GB/s), or -- when few surfels in many sub-blocks
+    // changed (a map in no particular order) -- a compact {index, record} list scattered by the CPU (~6 ns per record on top of its 60 bytes).
+    const size_t listLimit = n_local / 8;
+    const double costRuns = 56.0 * (double)runSurfels / 45e9, costList = (double)touched * (60.0 / 45e9 + 6e-9);
+    if (touched && touched <= listLimit && costList < costRuns) {
+        const size_t need = 256 + (sizeof(unsigned) + sizeof(msl_surfel)) * listLimit;
+        if (need > h->listCap) {
+            if (h->h_list) (void)hipHostFree(h->h_list);
+            h->h_list = nullptr; h->listCap = 0;
+            MSL_HIP_TRY(hipHostMalloc(&h->h_list, need));
+            h->listCap = need;
+        }
+        // device side: the count sits in tickets[3], indices in delList, records in the AoS buffer (both >= n_local entries)
+        unsigned *d_count = h->d_tickets + 3;
+        MSL_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned), s));
+        hipLaunchKernelGGL(k_collect_changed, dim3((unsigned)nblk), dim3(64), 0, s, h->dev, (int)ref, (long long)n_local, d_count, h->dev.delList, h->d_aos, (unsigned)listLimit);
+        unsigned *hc = reinterpret_cast<unsigned *>(h->h_list);
+        unsigned *hi = reinterpret_cast<unsigned *>(h->h_list + 256);
+        msl_surfel *hr = reinterpret_cast<msl_surfel *>(h->h_list + 256 + sizeof(unsigned) * listLimit);
+        MSL_HIP_TRY(hipMemcpyAsync(hc, d_count, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        MSL_HIP_TRY(hipStreamSynchronize(s));
+        // (the list may be longer than `touched`: a surfel that carried lastUpdate == ref before the call is listed as well -- harmless, its
+        // record is unchanged -- so the length is read first; a list beyond the staging size falls back to the runs)
+        const size_t cnt = *hc;
+        if (cnt <= listLimit) {
+            MSL_HIP_TRY(hipMemcpyAsync(hi, h->dev.delList, sizeof(unsigned) * cnt, hipMemcpyDeviceToHost, s));
+            MSL_HIP_TRY(hipMemcpyAsync(hr, h->d_aos, sizeof(msl_surfel) * cnt, hipMemcpyDeviceToHost, s));
+            if (K) MSL_HIP_TRY(hipMemcpyAsync(new_out, h->d_new, sizeof(msl_surfel) * K, hipMemcpyDeviceToHost, s));
+            MSL_HIP_TRY(hipStreamSynchronize(s));
+            for (size_t j = 0; j < cnt; j++) local[hi[j]] = hr[j];
+            h->mirrorValid = true; h->mirrorN = n_local;
+            return MSL_OK;
+        }
+    }
+    if (nblk && !runs.empty())
         LAUNCH(SK_CONVERT, s, k_soa_to_aos, dim3((unsigned)((n_local + 255) / 256)), dim3(256), h->dev.map, h->d_aos, (long long)n_local);
-        MSL_HIP_TRY(hipMemcpyAsync(local, h->d_aos, sizeof(msl_surfel) * n_local, hipMemcpyDeviceToHost, s));
+    for (const Run &r : runs) {
+        const size_t i0 = r.b0 * SUB_ITEMS, i1 = std::min(r.b1 * SUB_ITEMS, n_local);
+        MSL_HIP_TRY(hipMemcpyAsync(local + i0, h->d_aos + i0, sizeof(msl_surfel) * (i1 - i0), hipMemcpyDeviceToHost, s));
     }
     if (K) MSL_HIP_TRY(hipMemcpyAsync(new_out, h->d_new, sizeof(msl_surfel) * K, hipMemcpyDeviceToHost, s));
     MSL_HIP_TRY(hipStreamSynchronize(s));
+    h->mirrorValid = true; h->mirrorN = n_local;
     return MSL_OK;
+}
+
+int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
+                const int32_t *member, size_t member_stride, const float pose_colmajor[16], msl_surfel *local, size_t n_local,
+                msl_surfel *new_out, size_t new_cap, size_t *n_new) {
+    return msl_sf_fuse_ex(h, referenceFrameIndex, gray, gray_stride, depth, depth_stride, member, member_stride, pose_colmajor, local, n_local, new_out,
+                          new_cap, n_new, 0u);
 }
 
 int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {

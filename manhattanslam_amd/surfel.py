@@ -35,8 +35,9 @@ class SurfelFusion:
     __del__ = close
 
     # ---- SurfelFusion::fuseInitializeMap, host-vector mode ----
-    def fuseInitializeMap(self, referenceFrameIndex, inputImage, inputDepth, inputPlaneMembershipImg, pose, localSurfels):
-        """Updates `localSurfels` (structured SURFEL_DTYPE array) in place and returns the new surfels."""
+    def fuseInitializeMap(self, referenceFrameIndex, inputImage, inputDepth, inputPlaneMembershipImg, pose, localSurfels, local_unchanged=False):
+        """Updates `localSurfels` (structured SURFEL_DTYPE array) in place and returns the new surfels.  local_unchanged=True: the array is
+        byte for byte what the previous call on this handle left in it (MSL_SF_LOCAL_UNCHANGED: no upload)."""
         g = inputImage if inputImage.strides[1] == 1 else np.ascontiguousarray(inputImage)
         d = inputDepth if inputDepth.strides[1] == 4 else np.ascontiguousarray(inputDepth)
         m = inputPlaneMembershipImg if inputPlaneMembershipImg.strides[1] == 4 else np.ascontiguousarray(inputPlaneMembershipImg)
@@ -45,9 +46,9 @@ class SurfelFusion:
         new = np.zeros(self.nseeds, SURFEL_DTYPE)
         n_new = C.c_size_t(0)
         p = _pose16(pose)
-        check(lib.msl_sf_fuse(self._h, int(referenceFrameIndex), ptr(g), g.strides[0], ptr(d), d.strides[0], ptr(m), m.strides[0],
-                              ptr(p), ptr(localSurfels) if len(localSurfels) else None, len(localSurfels), ptr(new), len(new),
-                              C.byref(n_new)), "msl_sf_fuse")
+        check(lib.msl_sf_fuse_ex(self._h, int(referenceFrameIndex), ptr(g), g.strides[0], ptr(d), d.strides[0], ptr(m), m.strides[0],
+                                 ptr(p), ptr(localSurfels) if len(localSurfels) else None, len(localSurfels), ptr(new), len(new),
+                                 C.byref(n_new), 1 if local_unchanged else 0), "msl_sf_fuse_ex")
         return new[:n_new.value].copy()
 
     # ---- device-resident map ----

@@ -650,3 +650,56 @@ def test_sizes_that_are_not_multiples_of_eight(oracle, w, h):
         o.fuse_map(3 + k, f[0], f[1], f[2], f[3])
     assert_surfels_close(g.map_download(), o.map_get(), "resident map")
     g.close()
+
+
+def test_host_vector_unchanged_hint_and_touched_range_download(oracle):
+    """msl_sf_fuse_ex: with MSL_SF_LOCAL_UNCHANGED the caller's vector is not uploaded again (the device copy of the previous call is fused into),
+    and only the stretches of the vector that hold surfels the keyframe touched come back.  Four keyframes in a row on one vector, the hint given
+    from the second on, against the oracle; then the caller edits the vector (no hint: full upload), then a hint with a changed length (ignored)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map_dense(300000, ref=0, k_lo=-150, k_hi=214, min_update_times=1, flip=0.02, floating=0.01).astype(SURFEL_DTYPE)
+    far = np.arange(len(m)) >= 200000
+    m["px"][far] += 100.0; m["pz"][far] += 100.0        # a third of the map is out of range for good: its sub-blocks are never sent back
+    m["updateTimes"][far] = 9
+    lg, lo = m.copy(), m.copy()
+    for k in range(4):
+        gray, depth, member, pose = synth.surfel_frame(2 * k, variant="B" if k == 1 else "A")
+        lo, no = o.fuse(k, gray, depth, member, pose, lo)
+        ng = g.fuseInitializeMap(k, gray, depth, member, pose, lg, local_unchanged=k > 0)
+        assert_surfels_close(lg, lo, f"local after keyframe {k}")
+        assert_surfels_close(ng, no, f"new after keyframe {k}")
+        assert lg[far].tobytes() == m[far].tobytes()
+    assert (lg["lastUpdate"] == 3).sum() > 20000
+    # the caller edits its vector: no hint -> the edit is seen
+    lg["pz"][:1000] += 50.0; lo["pz"][:1000] += 50.0
+    gray, depth, member, pose = synth.surfel_frame(9)
+    lo, no = o.fuse(4, gray, depth, member, pose, lo)
+    ng = g.fuseInitializeMap(4, gray, depth, member, pose, lg)
+    assert_surfels_close(lg, lo, "after an edit, no hint")
+    # a hint that cannot hold (the vector grew): ignored, full upload
+    extra = synth.surfel_map(5000, ref=4, seed=3).astype(SURFEL_DTYPE)
+    lg = np.concatenate([lg, extra]); lo = np.concatenate([lo, extra])
+    gray, depth, member, pose = synth.surfel_frame(11)
+    lo, no = o.fuse(5, gray, depth, member, pose, lo)
+    ng = g.fuseInitializeMap(5, gray, depth, member, pose, lg, local_unchanged=True)
+    assert_surfels_close(lg, lo, "grown vector with a stale hint")
+    assert_surfels_close(ng, no, "new")
+    g.close()
+
+
+def test_host_vector_sparse_change_list(oracle):
+    """msl_sf_fuse_ex's other way back: a map in no particular order (every sub-block touched, few surfels each) returns a compact
+    {index, record} list instead of whole stretches; also with surfels that carried lastUpdate == ref before the call (listed, unchanged)."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(400000, ref=1, min_update_times=5).astype(SURFEL_DTYPE)      # area-uniform room map: ~6 % in view, lastUpdate in -7..1
+    lg, lo = m.copy(), m.copy()
+    for k in (1, 2, 3):
+        gray, depth, member, pose = synth.surfel_frame(k)
+        lo, no = o.fuse(k, gray, depth, member, pose, lo)
+        ng = g.fuseInitializeMap(k, gray, depth, member, pose, lg, local_unchanged=k > 1)
+        assert_surfels_close(lg, lo, f"local after keyframe {k}")
+        assert_surfels_close(ng, no, f"new after keyframe {k}")
+    assert 5000 < (lg["lastUpdate"] == 3).sum() < 50000
+    g.close()
