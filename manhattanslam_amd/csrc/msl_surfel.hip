@@ -129,6 +129,14 @@ struct SfDev {
     const float *colX, *rowY;    // [W+1], [H+1]: (u - cx) / fx and (v - cy) / fy of the integer pixel coordinates (back_project)
     int pxStride;                // per-slot stride of the per-pixel arrays: npx rounded up to 64 (16-byte vector accesses stay aligned); last, so that
                                  // the kernel-argument offsets of everything above are those the map-stage kernels were tuned with
+    // Overlap of compaction j with fusion j + 1 (run_batch).  The per-keyframe hand-over data (delU, delUCount, blockSums, blockUpd above) rotate
+    // through three slots, j % 3; the fields below point at what keyframe j - 1 left and at where live counts are published.
+    int fuseMode;                      // k_fuse: 0 = every sub-block; 1 = only the sub-blocks compaction j - 1 cannot touch; 2 = only the others
+    const unsigned *prevBlockSums;     // deleted slots per sub-block of keyframe j - 1 (a sub-block with any gets a new surfel or a tail element)
+    const unsigned *prevDelUCount;     // D of keyframe j - 1: the tail moves of compaction j - 1 start at n - D at the earliest
+    const long long *nPubPrev;         // live count before compaction j - 1 (= after compaction j - 2)
+    long long *nPubOut;                // k_compact: the live count after this keyframe; k_fuse mode 0: the live count it found (for the next keyframe's mode 1)
+    unsigned *resetDelUCount;          // k_compact: the hand-over count of the slot keyframe j + 2 will use
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -1247,11 +1255,34 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
     // plus a margin, not its upper bound (which runs up to 1.5 x ahead between count snapshots).  Sub-blocks below nSubHint load at once; above
     // it the wave reads the live count first and leaves if there is nothing for it.  Capacity is a multiple of 4096 and every sub-block that
     // loads speculatively lies below it, so the 16-byte loads stay in bounds.
+    // Modes 1 / 2 (compaction j - 1 runs beside this launch, run_batch): a sub-block is SAFE when compaction j - 1 neither reads nor writes it --
+    // it held no deleted slot after keyframe j - 1 (no new surfel or tail element lands in it) and it ends below n - D (the tail moves take
+    // their sources from [n - (D - K), n), new surfels are appended from n on).  Mode 1 fuses the safe sub-blocks with the live count as it was
+    // before that compaction (all of them lie below it whatever the compaction does); mode 2, launched behind the compaction, the others.
+    const int mode = P.fuseMode;
+    long long nBefore = 0, safeEnd = 0;
+    if (mode) {
+        nBefore = *P.nPubPrev;
+        safeEnd = nBefore - (long long)*P.prevDelUCount;
+    }
+    if (mode == 0 && blockIdx.x == 0 && lane == 0) *P.nPubOut = P.ctr[0];   // what the next keyframe's mode-1 launch takes as its live count
     for (long long sb = (long long)G - 1 - (long long)blockIdx.x;; sb += G) {
 #ifdef MSL_FUSE_STAMPS   // instrumented experiment builds (tools/fuse_stamps.py): 100 MHz device-clock stamps of every wave in srcOf[]
         const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (sb >= nSubHint && sb * SUB_ITEMS >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        if (mode == 1) {
+            if ((sb + 1) * SUB_ITEMS > safeEnd) return;   // this sub-block and the ones the wave would visit next (+G) belong to the mode-2 launch
+        } else if (sb >= nSubHint && sb * SUB_ITEMS >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        unsigned prevDeleted = 0;
+        if (mode == 2) {   // nearly every wave of this launch leaves here: decide before loading anything
+            const bool unsafe = (sb + 1) * SUB_ITEMS > safeEnd || P.prevBlockSums[sb] != 0;
+            if (!unsafe) {
+                if ((sb + G) * SUB_ITEMS >= P.ctr[0]) return;
+                continue;
+            }
+        } else if (mode == 1) {
+            prevDeleted = P.prevBlockSums[sb];   // requested together with the hot records (the few unsafe sub-blocks waste their loads)
+        }
         const long long c0 = sb * SUB_ITEMS, i0 = c0 + 4 * lane;
         uint4 q[5];
         {
@@ -1259,7 +1290,8 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
 #pragma unroll
             for (int e = 0; e < 5; e++) q[e] = hp[e];
         }
-        const long long n = P.ctr[0];
+        if (prevDeleted) continue;   // mode 1: compaction j - 1 puts a surfel into this sub-block; the mode-2 launch fuses it
+        const long long n = mode == 1 ? nBefore : P.ctr[0];
         const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
                                 q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
         int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
@@ -1682,7 +1714,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
         P.ctr[8] += K; P.ctr[9] += D; P.ctr[10] += s_upd; P.ctr[11] += 1; P.ctr[12] += n;
         if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
     }
-    if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }
+    if (!place) { if (threadIdx.x == 0) { *P.nPubOut = mode == 1 ? n : nAfter; *P.resetDelUCount = 0; } return; }
     const long long t0 = threadIdx.x, stride = blockDim.x;
     if (D > K) {
         const long long R = D - K, nFinal = n - R;
@@ -1714,7 +1746,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
         }
     }
-    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
+    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.nPubOut = nAfter; *P.resetDelUCount = 0; }   // publish the new live count, re-arm the hand-over list keyframe j + 2 will use
 #ifdef MSL_FUSE_STAMPS
     if (threadIdx.x == 0 && (P.ctr[11] & 255) == MSL_FUSE_STAMPS + 1) {
         cst[4] = __builtin_amdgcn_s_memrealtime();
@@ -1806,9 +1838,10 @@ __global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, l
     dst[i] = e;
 }
 // wide: -1 = leave the wide-rgb flag ctr[13] alone (upload: k_aos_to_soa has just set it if needed), 0 / 1 = the restored snapshot's flag
-__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount, int wide) {
+__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount, int wide) {   // delUCount: the three rotating hand-over counters; ctr[16..18]: the published live counts
     if (threadIdx.x == 0) {
-        *delUCount = 0; ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0;
+        delUCount[0] = 0; delUCount[1] = 0; delUCount[2] = 0; ctr[16] = n; ctr[17] = n; ctr[18] = n;
+        ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0;
         if (wide >= 0) ctr[13] = wide;
     }
 }
@@ -1854,6 +1887,9 @@ struct msl_sf {
     SfDev dev{};
     int maxBatch = 1;              // keyframes per batch; slots = 2 * maxBatch (double-buffered sets)
     hipStream_t preStream = nullptr, mapStream = nullptr; bool ownStreams = true;
+    // overlap of compaction j with fusion j + 1: the compaction chain runs on its own stream; kfSerial numbers the keyframes of the handle
+    hipStream_t cmpStream = nullptr; std::vector<hipEvent_t> evFuse, evTail; hipEvent_t evCmp = nullptr;
+    unsigned long long kfSerial = 0; size_t blkStride = 0; int lastPar = 0;
     hipStream_t copyStream = nullptr;   // host-image mode: the H2D copies of slot set i + 1 run beside the superpixel kernels of set i
     hipEvent_t evH2D[2] = {nullptr, nullptr};
     hipEvent_t evPre[2] = {nullptr, nullptr}, evMap[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
@@ -1917,6 +1953,7 @@ int sync_all(msl_sf *h) {
     if (h->ownStreams && h->copyStream) MSL_HIP_TRY(hipStreamSynchronize(h->copyStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
+    if (h->cmpStream) MSL_HIP_TRY(hipStreamSynchronize(h->cmpStream));   // (every batch ends with the map stream waiting for it: normally idle already)
     return MSL_OK;
 }
 
@@ -1926,10 +1963,11 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr;
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * 16 * cap));
-        MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));   // >= 1024 entries: the compaction reads its first tile unconditionally
-        MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
-        MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 2052)));
-        MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * (cap / SUB_ITEMS + 4100)));
+        const size_t bst = cap / SUB_ITEMS + 4100;   // per slot; >= 1024 / 4096 padding entries: the compaction reads its first tiles unconditionally
+        MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * 3 * bst));   // three rotating slots each (keyframe j % 3)
+        MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * 3 * bst));
+        MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * 3 * bst));
+        MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * 3 * bst));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMemset(ndl, 0, sizeof(unsigned) * 256));   // (instrumented builds accumulate section counters in its first words)
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
@@ -1955,6 +1993,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
         (void)hipFree(h->d_mapStore); (void)hipFree(h->d_blockSums); (void)hipFree(h->d_blockUpd); (void)hipFree(h->d_delList); (void)hipFree(h->d_srcOf);
     }
     h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->mapCap = cap;
+    h->blkStride = cap / SUB_ITEMS + 4100;
     set_map_ptrs(h);
     return MSL_OK;
 }
@@ -2191,14 +2230,69 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     const size_t known = std::min(h->liveKnown, boundLive);
     const int nSubGrid = (int)std::max<size_t>(1, (std::min(known + 2 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS);
     const int nSubHint = (int)(known / SUB_ITEMS);
+    // Optional overlap (MSL_SF_OVERLAP=1; resident mode, own streams): keyframe f's fusion does not wait for keyframe f - 1's compaction.  The
+    // compaction only touches sub-blocks that held a deleted slot and the end of the array, so
+    //   map stream : fuse_0 (all) | fuse_1 (safe sub-blocks) | [tail_1 done] fuse_2 (safe) | [tail_2 done] fuse_3 (safe) ...
+    //   cmp stream : [fuse_0 done] compact_0, tail_1 (the other sub-blocks of keyframe 1) | [fuse_1 done] compact_1, tail_2 | ...
+    // and on paper a keyframe costs max(fusion, compaction + tail) instead of their sum.  What fuse_f needs of keyframe f - 1 (deleted-slot counts
+    // per sub-block, D, the live count before compaction f - 1) rotates through three slots, so that nothing it reads is written while it runs.
+    // All resident-map parity tests pass in this mode (identical maps, counters and new-surfel lists).  It is OFF by default because it measured
+    // SLOWER on MI355X / ROCm 7.2: SurfelFusion alone 19.2 k keyframes/s against 21.3 k (dense map), 23.2 k against 26.2 k (sparse map) -- the two
+    // cross-stream event dependencies per keyframe cost more than the two in-stream dependent launches they replace (k_fuse itself is unchanged,
+    // 26.8 us per event pair in both modes; GPU_MAX_HW_QUEUES = 8 / 16, the compaction stream's priority and device-scope release events made no
+    // difference).  Kept, tested and documented as a measured dead end for the stream-level form of the idea.
+    static const bool overlapOn = getenv("MSL_SF_OVERLAP") && !strcmp(getenv("MSL_SF_OVERLAP"), "1");
+    const bool ov = overlapOn && compact && h->ownStreams && sp != sm && n > 1;
+    if (ov && !h->cmpStream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        const char *pe = getenv("MSL_SF_CMP_PRIO");   // experiment hook: 0 = default priority, 1 = highest (default), 2 = lowest
+        const int pr = pe && pe[0] == '0' ? 0 : (pe && pe[0] == '2' ? lo : hi);
+        MSL_HIP_TRY(hipStreamCreateWithPriority(&h->cmpStream, hipStreamNonBlocking, pr));
+        MSL_HIP_TRY(hipEventCreateWithFlags(&h->evCmp, hipEventDisableTiming | hipEventReleaseToDevice));
+    }
+    if (ov)
+        while ((int)h->evFuse.size() < n) {
+            hipEvent_t a, b;
+            // device-scope release: the events order kernels of two streams of this GPU, nothing the host reads
+            MSL_HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming | hipEventReleaseToDevice)); MSL_HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventReleaseToDevice));
+            h->evFuse.push_back(a); h->evTail.push_back(b);
+        }
+    hipStream_t sc = ov ? h->cmpStream : sm;
     for (int f = 0; f < n; f++) {
+        // slot rotation: this keyframe's hand-over data in slot j % 3, what keyframe j - 1 left in (j - 1) % 3, live counts published in ctr[16 + slot]
+        const unsigned long long j = h->kfSerial + (unsigned long long)f;
+        const int par = (int)(j % 3), prev = (int)((j + 2) % 3), next = (int)((j + 1) % 3);
+        P.blockSums = D.blockSums + (size_t)par * h->blkStride; P.blockUpd = D.blockUpd + (size_t)par * h->blkStride;
+        P.delU = D.delU + (size_t)par * LIST_D; P.delUCount = h->d_tickets + 4 + par;
+        P.prevBlockSums = D.blockSums + (size_t)prev * h->blkStride; P.prevDelUCount = h->d_tickets + 4 + prev;
+        P.nPubPrev = h->d_ctr + 16 + next;             // n before compaction j - 1 = after compaction j - 2, slot (j - 2) % 3 = (j + 1) % 3
+        P.resetDelUCount = h->d_tickets + 4 + prev;    // slot (j + 2) % 3 = (j - 1) % 3: keyframe j + 2's; its last readers (fusion j) are done when compaction j runs
+        h->lastPar = par;
+        if (ov && f > 0) {
+            P.fuseMode = 2; P.nPubOut = h->d_ctr + 16 + par;
+            hipLaunchKernelGGL(k_fuse, dim3((unsigned)nSubGrid), dim3(64), 0, sc, P, f, h->h_frames[slot0 + f], nSubHint);   // tail_f: behind compaction f - 1
+            MSL_HIP_TRY(hipEventRecord(h->evTail[f], sc));
+            if (f > 1) MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evTail[f - 1], 0));   // fuse_f reads what tail_{f-1} wrote (deleted counts of keyframe f - 1)
+            P.fuseMode = 1;
+        } else {
+            P.fuseMode = 0;
+        }
+        P.nPubOut = P.fuseMode == 0 ? h->d_ctr + 16 + prev : h->d_ctr + 16 + par;   // mode 0 publishes the count it found where keyframe j + 1's mode 1 looks ((j + 1 - 2) % 3)
         LAUNCH(SK_FUSE, sm, k_fuse, dim3((unsigned)nSubGrid), dim3(64), P, f, h->h_frames[slot0 + f], nSubHint);
-        LAUNCH(SK_COMPACT, sm, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
+        if (ov) {
+            MSL_HIP_TRY(hipEventRecord(h->evFuse[f], sm));
+            MSL_HIP_TRY(hipStreamWaitEvent(sc, h->evFuse[f], 0));
+        }
+        P.nPubOut = h->d_ctr + 16 + par;
+        LAUNCH(SK_COMPACT, sc, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
+        if (ov && f == n - 1) { MSL_HIP_TRY(hipEventRecord(h->evCmp, sc)); MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evCmp, 0)); }
         if (f == n / 2) {   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
             hipEvent_t ea, eb;   // (the pair's first event completes with the previous command, so every event time contains the dependent-launch gap)
             if (h->prof.kernel_pair(SK_NEW, &ea, &eb)) hipExtLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, sm, ea, eb, 0, 0);
         }
     }
+    h->kfSerial += (unsigned long long)n;
     if (sp != sm) { MSL_HIP_TRY(hipEventRecord(h->evMap[set], sm)); h->evMapValid[set] = true; }
     if (compact && h->h_snap) {   // snapshot of the live count after this batch (picked up by a later call, never waited for)
         const int i = h->snapNext;
@@ -2243,14 +2337,14 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         ok = hipEventCreateWithFlags(&h->evPre[i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&h->evMap[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->evCopy[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&h->evH2D[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 16) == hipSuccess;
-    ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 16) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 32) == hipSuccess;   // 16 counters (read_ctr) + [16..18] the published live counts
+    ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 32) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_snap, sizeof(long long) * msl_sf::NSNAP) == hipSuccess;
     for (int i = 0; i < msl_sf::NSNAP && ok; i++) ok = hipEventCreateWithFlags(&h->snapEv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 4) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 4) == hipSuccess;
-    ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 8) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 8) == hipSuccess;   // [0..1] tickets, [3] change-list length, [4..6] the rotating hand-over counts
+    ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D * 3) == hipSuccess;
     {   // (u - cx) / fx and (v - cy) / fy of every integer pixel coordinate: the float expression of back_project
         // (src/SurfelFusion.cpp:80-85) evaluated once here instead of six divisions per pixel in kb_seed_plane
         std::vector<float> tab((size_t)width + 1 + height + 1);
@@ -2264,7 +2358,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         h->propLds = hipFuncSetAttribute((const void *)kb_prop_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * PROP_LDS_MAX_SEEDS)) == hipSuccess;
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 16);
-    D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 2;
+    D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 4;
+    D.fuseMode = 0; D.prevBlockSums = nullptr; D.prevDelUCount = h->d_tickets + 4; D.nPubPrev = h->d_ctr + 16; D.nPubOut = h->d_ctr + 16; D.resetDelUCount = h->d_tickets + 4;
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
     return h;
@@ -2288,6 +2383,10 @@ void msl_sf_destroy(msl_sf *h) {
     for (int i = 0; i < 2; i++) { if (h->evPre[i]) (void)hipEventDestroy(h->evPre[i]); if (h->evMap[i]) (void)hipEventDestroy(h->evMap[i]); if (h->evCopy[i]) (void)hipEventDestroy(h->evCopy[i]); if (h->evH2D[i]) (void)hipEventDestroy(h->evH2D[i]); }
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
+    if (h->cmpStream) { (void)hipStreamSynchronize(h->cmpStream); (void)hipStreamDestroy(h->cmpStream); }
+    for (hipEvent_t e : h->evFuse) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->evTail) (void)hipEventDestroy(e);
+    if (h->evCmp) (void)hipEventDestroy(h->evCmp);
     delete h;
 }
 
@@ -2355,7 +2454,7 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
         MSL_HIP_TRY(hipMemcpyAsync(h->d_aos, host, sizeof(msl_surfel) * n, hipMemcpyHostToDevice, s));
         LAUNCH(SK_CONVERT, s, k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), h->dev.map, h->d_aos, (long long)n);
     }
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2, -1);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 4, -1);
     MSL_HIP_TRY(hipStreamSynchronize(s));
     h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq;
     drop_live_snapshots(h);   // a count recorded before the upload would otherwise lower the bound below n
@@ -2407,7 +2506,7 @@ int msl_sf_map_restore(msl_sf *h) {
     }
     // the restored map has exactly the snapshot's wide-rgb state: without the flag a later snapshot would skip rgbWide and a restore of THAT
     // one would bring COLD_WIDE records back without their exact ints
-    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 2, h->snapWide ? 1 : 0);
+    hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, s, h->d_ctr, (long long)n, h->d_tickets + 4, h->snapWide ? 1 : 0);
     MSL_HIP_TRY(hipGetLastError());
     h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq;
     drop_live_snapshots(h);
@@ -2579,7 +2678,7 @@ int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size
     const bool reuse = (flags & MSL_SF_LOCAL_UNCHANGED) && h->mirrorValid && h->mirrorN == n_local;
     if (reuse) {
         // the device map is the caller's vector already: only the per-call counters start over
-        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr, (long long)n_local, h->d_tickets + 2, -1);
+        hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, h->mapStream, h->d_ctr, (long long)n_local, h->d_tickets + 4, -1);
         h->liveBound = n_local; h->liveKnown = n_local; h->liveKnownKf = h->kfEnq;
     } else {
         rc = msl_sf_map_upload(h, local, n_local);
@@ -2599,8 +2698,9 @@ int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size
         h->blkCap = nblk + 1024;
     }
     if (nblk) {
-        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk, h->dev.blockSums, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
-        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk + h->blkCap, h->dev.blockUpd, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
+        // (the keyframe's per-sub-block counts sit in the rotating slot run_batch used: lastPar)
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk, h->dev.blockSums + (size_t)h->lastPar * h->blkStride, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
+        MSL_HIP_TRY(hipMemcpyAsync(h->h_blk + h->blkCap, h->dev.blockUpd + (size_t)h->lastPar * h->blkStride, sizeof(unsigned) * nblk, hipMemcpyDeviceToHost, s));
     }
     rc = read_ctr(h);   // the call's first synchronisation: counters and the per-sub-block counts are on the host
     if (rc != MSL_OK) return rc;
@@ -2638,7 +2738,9 @@ int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size
         // device side: the count sits in tickets[3], indices in delList, records in the AoS buffer (both >= n_local entries)
         unsigned *d_count = h->d_tickets + 3;
         MSL_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned), s));
-        hipLaunchKernelGGL(k_collect_changed, dim3((unsigned)nblk), dim3(64), 0, s, h->dev, (int)ref, (long long)n_local, d_count, h->dev.delList, h->d_aos, (unsigned)listLimit);
+        SfDev Pc = h->dev;
+        Pc.blockSums = h->dev.blockSums + (size_t)h->lastPar * h->blkStride; Pc.blockUpd = h->dev.blockUpd + (size_t)h->lastPar * h->blkStride;
+        hipLaunchKernelGGL(k_collect_changed, dim3((unsigned)nblk), dim3(64), 0, s, Pc, (int)ref, (long long)n_local, d_count, h->dev.delList, h->d_aos, (unsigned)listLimit);
         unsigned *hc = reinterpret_cast<unsigned *>(h->h_list);
         unsigned *hi = reinterpret_cast<unsigned *>(h->h_list + 256);
         msl_surfel *hr = reinterpret_cast<msl_surfel *>(h->h_list + 256 + sizeof(unsigned) * listLimit);

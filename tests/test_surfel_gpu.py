@@ -703,3 +703,20 @@ def test_host_vector_sparse_change_list(oracle):
         assert_surfels_close(ng, no, f"new after keyframe {k}")
     assert 5000 < (lg["lastUpdate"] == 3).sum() < 50000
     g.close()
+
+
+def test_overlapped_map_stage_gives_identical_maps():
+    """MSL_SF_OVERLAP=1 (off by default: it measured slower): compaction j on its own stream beside fusion j + 1, which skips
+    the sub-blocks that compaction can touch and leaves them to a launch behind it.  The flag is read once per process, so the batched /
+    resident parity tests run again in a child process with it set: same maps, counters and new-surfel lists as the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSL_SF_OVERLAP="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_surfel_gpu.py"), os.path.join(root, "tests", "test_clutter_gpu.py"),
+                        "-k", "batched or full_size or grows or resident_sequence or snapshot or outgrows or dense_in_view or keyframe_every or compaction"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
