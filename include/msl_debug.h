@@ -54,6 +54,10 @@ MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint
 /* Test hook (host only): mse_out[i] = the MSE ahc::PlaneSeg::Stats::compute (AHCPlaneSeg.hpp:148-183) reports for stats[i], evaluated by the
  * scalar code (lanes = 0) or by the clustering's lock-step SIMD form with `lanes` (2, 4, 8, 16) candidates per group; MSL_ERR_INVALID if the CPU
  * lacks the instruction set that width is built for (4 and 8: AVX2, 16: AVX-512F). */
+/* Test hook: 1 if msl_peac_membership_batch / msl_peac_extract_batch would cluster a call of n_frames keyframes on the device, 0 if on the host workers
+ * (the automatic rule: more than eight frames per worker this process may use, the worker count being divided by LOCAL_WORLD_SIZE; MSL_PEAC_CLUSTER
+ * = host / device overrides).  Frames whose node data does not fit the LDS take the host path regardless. */
+MSL_API int msl_debug_peac_cluster_on_device(int n_frames);
 MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out);
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);

@@ -77,7 +77,6 @@ struct OrbDev {
     const float *depth; unsigned long long depthRowStride, depthFrameStride;   // bytes
     float *unXY, *depthOut, *uRight; int *gridCell;
     int maxNode;   // k_octree: node-array length
-    int octStop;   // experiment hook (MSL_OCT_STOP): leave k_octree after phase octStop (timing only, wrong results); 0 = run everything
     int octLds;    // k_octree: dynamic LDS bytes = max(OCT_NODE_BYTES * maxNode, 8 * (cells of the largest level + 1))
 };
 
@@ -460,7 +459,6 @@ __device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, 
     K.for_each([&](unsigned, uint32_t, unsigned &node, unsigned &) { node = s_L[node]; });
     cur = 1;
     __syncthreads();
-    if (P.octStop == 2) { if (tid == 0) *nsel = 0; return; }
 
     // Child counts of the nodes that are being divided: s_cc[4 i + quadrant] += 1 for every key of a divided node i (s_cc is zero on entry).
     auto count_children = [&](const Rect *rect, auto is_divided) {
@@ -537,7 +535,6 @@ __device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, 
         if (S + 3 * nToExpand > N) { careful = true; break; }
     }
 
-    if (P.octStop == 3) { if (tid == 0) *nsel = 0; return; }
     // ---- careful mode (:641-700) ----
     stampNo = 40;
     while (careful) {
@@ -649,7 +646,6 @@ __device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, 
     }
 
     __syncthreads();
-    if (P.octStop == 4) { if (tid == 0) *nsel = 0; return; }
     OCT_STAMP(P, level, frame, 80);
     // ---- keep the best key of every node (:703-718) ----
     unsigned *best = s_cc;
@@ -734,7 +730,6 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
             if ((unsigned)j < K.per && k < n) keys[k] = K.key[j];     // (the global copy is what msl_orb_debug_candidates reads)
         }
         __syncthreads();   // s_off is dead from here on: the node arrays take its place
-        if (P.octStop == 1) { if (tid == 0) P.nsel[frame * P.nlevels + level] = 0; return; }
         octree_body<true>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
     } else {
         OctKeys<false> K;
@@ -1230,7 +1225,6 @@ int build_geometry(msl_orb *h, int W, int H) {
         for (int l = 0; l < L; l++) maxCells = std::max(maxCells, D.lv[l].nCells);
         D.octLds = (int)((std::max<size_t>((size_t)OCT_NODE_BYTES * D.maxNode, 2 * sizeof(unsigned) * (size_t)(maxCells + 1)) + 15) & ~(size_t)15);
     }
-    { const char *e = getenv("MSL_OCT_STOP"); D.octStop = e ? atoi(e) : 0; }
     if (D.octLds > 32 * 1024)   // (a large feature budget: more dynamic LDS than a launch gets by default)
         MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, D.octLds));
     if (h->outCap == 0) h->outCap = std::max(h->nfeatures + 2 * L, needCap);   // creation: the handle's capacity follows its (max_width, max_height) geometry

@@ -1390,9 +1390,7 @@ int membership_impl(int device, const uint16_t *depth, size_t depth_stride_bytes
         // auto: the device clusters any number of frames in the time of one (~13-20 ms, one latency-bound wave per frame), a host worker needs ~2 ms
         // per frame (candidate merges evaluated 16 at a time, plane_mse_lanes): the device wins once a call holds more than about eight frames per
         // usable CPU (measured: 64 frames on 16 workers, host 25.5 k frames/s of configuration 4 against 22.9 k with the device clustering).
-        const char *mode = getenv("MSL_PEAC_CLUSTER");
-        const bool forceHost = mode && !strcmp(mode, "host"), forceDev = mode && !strcmp(mode, "device");
-        const bool wantDevice = forceDev || (!forceHost && n_frames > 8 * SegPool::get().workers());
+        const bool wantDevice = msl_debug_peac_cluster_on_device(n_frames) != 0;
         if (ldsBytes <= 150 * 1024 && wantDevice) {
             Scratch &sc = g_scratch[device & 15];
             const int maxE = 4 * (int)nBlocks;
@@ -1505,6 +1503,17 @@ int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t
                                     const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
     return msl_peac_extract_from_blocks(blocks, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, fx, fy, cx, cy, depth_map_factor, params,
                                         membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
+}
+
+// Where a call of n_frames keyframes clusters: 1 = on the device (one wave per frame, ~13-20 ms per call whatever the number of frames), 0 = on
+// the host workers (~2 ms per frame and worker).  The device wins once a call holds more than about eight frames per worker this process may
+// use -- and the worker count is the CPU budget divided by LOCAL_WORLD_SIZE, so the 8 ranks of a node (2 workers each on a 16-CPU allowance)
+// take the device path for config 4's 128-keyframe calls instead of collapsing onto shared host cores.  MSL_PEAC_CLUSTER=host / device forces one side.
+int msl_debug_peac_cluster_on_device(int n_frames) {
+    const char *mode = getenv("MSL_PEAC_CLUSTER");
+    if (mode && !strcmp(mode, "host")) return 0;
+    if (mode && !strcmp(mode, "device")) return 1;
+    return n_frames > 8 * SegPool::get().workers() ? 1 : 0;
 }
 
 int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) {

@@ -1679,7 +1679,8 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
         }
         for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
-        if (u) atomicAdd(&s_upd, u);
+        u = wave_incl_scan(u);                                   // one LDS atomic per wave instead of 256 on one address
+        if ((threadIdx.x & 63) == 63 && u) atomicAdd(&s_upd, u);
     }
     // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
     const long long K = Ku;

@@ -65,3 +65,18 @@ for name, (seed, nc, nl, tz, cluster) in {"a": (101, 1000, 950, 0.3, True), "b":
     gm[f"{name}_input_sha256"] = hashlib.sha256(c["desc"].tobytes() + l["desc"].tobytes() + l["xyz"].tobytes()).hexdigest()
 np.savez_compressed(os.path.join(OUT, "match_pairs.npz"), th=15.0, **gm)
 print("match golden:", int(gm["a_nmatches"]), int(gm["b_nmatches"]), "matches")
+# Round 4: the furnished room (curved objects, depth edges, z^2 noise, dropout) -- SurfelFusion on a mostly-in-view map, and the plane extractor
+Ic = synth.TUM1
+scn = synth.clutter_scene()
+kc = 40
+grayc, depthc, memberc, posec, _ = synth.clutter_frame(kc, scene=scn)
+localc = synth.surfel_map_dense(10000, ref=kc, scene=scn, k_lo=kc - 25, k_hi=kc + 35, flip=0.05, floating=0.02, min_update_times=1).astype(oracle_lib.SURFEL_DTYPE)
+sfc = oracle_lib.OracleSurfel(640, 480, Ic["fx"], Ic["fy"], Ic["cx"], Ic["cy"], 30.0, 0.5)
+loc, noc = sfc.fuse(kc, grayc, depthc, memberc, posec, localc)
+chg = np.flatnonzero((loc.view(np.uint8).reshape(len(loc), -1) != localc.view(np.uint8).reshape(len(loc), -1)).any(1))
+memc, nplc, _ = oracle_lib.peac_run(synth.depth_u16(depthc), Ic["fx"], Ic["fy"], Ic["cx"], Ic["cy"], np.float32(1.0 / 5000.0))
+np.savez_compressed(os.path.join(OUT, "clutter_640x480.npz"), frame=kc, n_local=len(localc), depth_sha256=hashlib.sha256(depthc.tobytes()).hexdigest(),
+                    gray_sha256=hashlib.sha256(grayc.tobytes()).hexdigest(), map_sha256=hashlib.sha256(localc.tobytes()).hexdigest(),
+                    new_surfels=noc, changed_index=chg.astype(np.int32), changed_surfels=loc[chg], seeds=sfc.seeds(),
+                    index_sha256=hashlib.sha256(sfc.index().tobytes()).hexdigest(), peac_membership=memc.astype(np.int8), peac_nplanes=nplc)
+print("clutter golden:", len(noc), "new,", len(chg), "changed surfels,", nplc, "planes, membership range", memc.min(), memc.max())

@@ -84,3 +84,30 @@ def test_match_golden_bit_exact():
     got, nm = match.search_by_projection_batch(p, cur, last, np.stack(Tc), np.stack(Tl))
     for f, name in enumerate(("a", "b")):
         assert nm[f] == int(g[f"{name}_nmatches"]) and np.array_equal(got[f], g[f"{name}_matches"]), name
+
+
+def test_clutter_golden_within_tolerance():
+    """The furnished-room golden vector (tests/golden/clutter_640x480.npz): SurfelFusion within 1e-4, the plane extractor's membership identical."""
+    from manhattanslam_amd import SurfelFusion, peac, synth, SURFEL_DTYPE
+    from tests.test_surfel_gpu import assert_surfels_close, assert_seeds_close
+    g = np.load(os.path.join(GOLD, "clutter_640x480.npz"))
+    k = int(g["frame"])
+    sc = synth.clutter_scene()
+    gray, depth, member, pose, _ = synth.clutter_frame(k, scene=sc)
+    assert hashlib.sha256(depth.tobytes()).hexdigest() == str(g["depth_sha256"])
+    local = synth.surfel_map_dense(int(g["n_local"]), ref=k, scene=sc, k_lo=k - 25, k_hi=k + 35, flip=0.05, floating=0.02, min_update_times=1).astype(SURFEL_DTYPE)
+    I = synth.TUM1
+    sf = SurfelFusion(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+    before = local.copy()
+    new = sf.fuseInitializeMap(k, gray, depth, member, pose, local)
+    assert_surfels_close(new, g["new_surfels"].view(SURFEL_DTYPE), "new")
+    ci = g["changed_index"]
+    assert_surfels_close(local[ci], g["changed_surfels"].view(SURFEL_DTYPE), "changed")
+    untouched = np.setdiff1d(np.arange(len(local)), ci)
+    assert local[untouched].tobytes() == before[untouched].tobytes()
+    from tests.oracle_lib import SEED_DTYPE
+    assert_seeds_close(sf.debug_seeds(), g["seeds"].view(SEED_DTYPE))
+    assert hashlib.sha256(sf.debug_index().tobytes()).hexdigest() == str(g["index_sha256"])
+    sf.close()
+    mem, n = peac.plane_membership(synth.depth_u16(depth), I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+    assert n[0] == int(g["peac_nplanes"]) and np.array_equal(mem[0], g["peac_membership"].astype(np.int32))

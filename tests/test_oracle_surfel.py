@@ -192,3 +192,25 @@ def test_used_seed_always_owns_its_centre_pixel(seed):
     assert len(used) > 100
     cy, cx = (used // (w // 8)) * 8 + 4, (used % (w // 8)) * 8 + 4
     assert np.array_equal(index[cy, cx], used)
+
+
+def test_golden_clutter():
+    """Committed golden vector of the furnished room (round 4): seeds, index map, changed / new surfels of SurfelFusion on a mostly-in-view map,
+    and the plane extractor's membership image on the same depth frame."""
+    from tests import oracle_lib
+    g = np.load(os.path.join(GOLD, "clutter_640x480.npz"))
+    k = int(g["frame"])
+    sc = synth.clutter_scene()
+    gray, depth, member, pose, _ = synth.clutter_frame(k, scene=sc)
+    assert hashlib.sha256(depth.tobytes()).hexdigest() == str(g["depth_sha256"]) and hashlib.sha256(gray.tobytes()).hexdigest() == str(g["gray_sha256"])
+    local = synth.surfel_map_dense(int(g["n_local"]), ref=k, scene=sc, k_lo=k - 25, k_hi=k + 35, flip=0.05, floating=0.02, min_update_times=1).astype(SURFEL_DTYPE)
+    assert hashlib.sha256(local.tobytes()).hexdigest() == str(g["map_sha256"])
+    sf = _mk()
+    lo, no = sf.fuse(k, gray, depth, member, pose, local)
+    assert no.tobytes() == g["new_surfels"].tobytes()
+    assert lo[g["changed_index"]].tobytes() == g["changed_surfels"].tobytes()
+    assert sf.seeds().tobytes() == g["seeds"].tobytes()
+    assert hashlib.sha256(sf.index().tobytes()).hexdigest() == str(g["index_sha256"])
+    I = synth.TUM1
+    mem, npl, _ = oracle_lib.peac_run(synth.depth_u16(depth), I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
+    assert npl == int(g["peac_nplanes"]) and np.array_equal(mem, g["peac_membership"].astype(np.int32))

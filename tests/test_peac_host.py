@@ -190,6 +190,34 @@ def test_worker_budget_is_divided_among_local_ranks(oracle):
     assert workers(LOCAL_WORLD_SIZE="8", MSL_PEAC_THREADS="3")[0] == 3
 
 
+def test_eight_ranks_on_a_shared_cpu_allowance_cluster_on_the_device():
+    """BASELINE config 4 on the 8-GPU node: every rank's automatic choice for its 128-keyframe calls.  With the GPU box's allowance (16 usable
+    CPUs shared by 8 ranks: 2 workers each) the rule `more than eight frames per worker` sends all ranks to the device path, so the plane
+    extractor does not collapse onto shared host cores; a rank with the whole allowance to itself and a small call
+    stays on the host, where a lone frame clusters faster (1.8 ms)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from manhattanslam_amd._lib import lib\nprint('CHOICE', lib.msl_debug_peac_cluster_on_device(128), lib.msl_debug_peac_cluster_on_device(1))\n"
+
+    def choice(**envs):
+        env = {k: v for k, v in os.environ.items() if k not in ("MSL_PEAC_THREADS", "LOCAL_WORLD_SIZE", "MSL_PEAC_CLUSTER")}
+        env.update(envs)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        a, b = [ln for ln in r.stdout.splitlines() if ln.startswith("CHOICE")][0].split()[1:]
+        return int(a), int(b)
+
+    cpus = len(os.sched_getaffinity(0))
+    for rank in range(8):      # what torch.distributed.run gives each of the 8 ranks of the node
+        assert choice(LOCAL_WORLD_SIZE="8", LOCAL_RANK=str(rank), MSL_PEAC_THREADS="2") == (1, 0)   # 2 workers: 128 > 16 -> device; 1 frame -> host
+    if cpus // 8 * 8 < 128:
+        assert choice(LOCAL_WORLD_SIZE="8")[0] == 1           # this machine's own CPU count divided by 8 ranks
+    assert choice(MSL_PEAC_THREADS="64") == (0, 0)            # one rank with 64 workers: 128 <= 512 -> host
+    assert choice(MSL_PEAC_CLUSTER="device", MSL_PEAC_THREADS="64") == (1, 1) and choice(MSL_PEAC_CLUSTER="host", MSL_PEAC_THREADS="1") == (0, 0)
+
+
 def _stats_of_points(pts):
     from manhattanslam_amd import PEAC_STATS_DTYPE
     s = np.zeros((), PEAC_STATS_DTYPE)
