@@ -76,6 +76,7 @@ struct OrbDev {
     msl_frame_params fp; float gridWInv, gridHInv;
     const float *depth; unsigned long long depthRowStride, depthFrameStride;   // bytes
     float *unXY, *depthOut, *uRight; int *gridCell;
+    int nFrames;   // frames of this launch sequence (the kernels run 1-D, XCD-aware grids: xcd_item)
     int maxNode;   // k_octree: node-array length
     int octLds;    // k_octree: dynamic LDS bytes = max(OCT_NODE_BYTES * maxNode, 8 * (cells of the largest level + 1))
 };
@@ -94,6 +95,20 @@ __device__ __forceinline__ const uint8_t *level_ptr(const OrbDev &P, int frame, 
 // k_resize: level l from level l-1.  One thread per output pixel; taps come from host-built tables
 // so the coefficient arithmetic (double -> float -> cvRound) is the host's.
 // ---------------------------------------------------------------------------------------------
+// XCD-aware block -> (item, frame) mapping for the frame-batched kernels.  Workgroup g of a launch runs on XCD g % 8 (dispatch order; used for
+// speed only) and every XCD has its own 4 MB L2.  With blockIdx.y = frame each frame's workgroups were spread over all eight L2s, so every
+// pyramid line was fetched from HBM / Infinity Cache up to eight times (FAST cell rows of 36 bytes, blur tiles, descriptor patches: 15.2 MB per
+// frame against 1.9 MB of algorithmic reads in round 3).  Launch a 1-D grid of xcd_grid1(nx * ny) workgroups instead: XCD x gets the contiguous
+// run of virtual indices [x C, (x + 1) C), C = ceil(nx ny / 8), i.e. whole frames (and inside a frame neighbouring cells / tiles) share one L2.
+__device__ __forceinline__ bool xcd_item(int nx, int ny, int &x, int &y) {
+    const unsigned g = blockIdx.x, C = gridDim.x >> 3;
+    const unsigned v = (g & 7u) * C + (g >> 3);
+    if (v >= (unsigned)nx * (unsigned)ny) return false;
+    x = (int)(v % (unsigned)nx); y = (int)(v / (unsigned)nx);
+    return true;
+}
+inline unsigned xcd_grid1(long long items) { return (unsigned)(8 * ((items + 7) / 8)); }
+
 __global__ __launch_bounds__(256) void k_resize(OrbDev P, int l) {
     const int frame = blockIdx.z;
     const LevelDev &D = P.lv[l];
@@ -121,7 +136,9 @@ __global__ __launch_bounds__(256) void k_resize(OrbDev P, int l) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
     extern __shared__ uint8_t s_pyr[];
-    const int frame = blockIdx.y, ti = blockIdx.x % P.pyrTX, tj = blockIdx.x / P.pyrTX;
+    int tileI, frame;
+    if (!xcd_item(P.pyrTX * P.pyrTY, P.nFrames, tileI, frame)) return;
+    const int ti = tileI % P.pyrTX, tj = tileI / P.pyrTX;
     const int L = P.nlevels;
     PyrRange rx = P.pyrX[ti], ry = P.pyrY[tj];   // level 0: the input region
     int sx0 = rx.needLo, sy0 = ry.needLo, sw = rx.needHi - rx.needLo, sh = ry.needHi - ry.needLo;
@@ -207,10 +224,11 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
     __shared__ unsigned s_wave[17];
     __shared__ unsigned s_cnt[3];
 
-    const int frame = blockIdx.y;
-    const CellDev C = P.cells[blockIdx.x];
+    int cellI, frame;
+    if (!xcd_item(P.cellsPerFrame, P.nFrames, cellI, frame)) return;
+    const CellDev C = P.cells[cellI];
     const int tid = threadIdx.x;
-    uint32_t *cnt_out = P.cellCnt + (size_t)frame * P.cellsPerFrame + blockIdx.x;
+    uint32_t *cnt_out = P.cellCnt + (size_t)frame * P.cellsPerFrame + cellI;
     const int cw = C.cw, ch = C.ch;
     if (cw <= 0 || ch <= 0) { if (tid == 0) *cnt_out = 0; return; }
     int pitch;
@@ -674,7 +692,9 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ unsigned s_wave[33];   // (block_excl_scan_pair keeps two rows of 16 wave totals)
     __shared__ int s_misc[8];
-    const int level = blockIdx.x, frame = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int level, frame;
+    if (!xcd_item(P.nlevels, P.nFrames, level, frame)) return;
     OCT_STAMP(P, level, frame, 0);
     const LevelDev &G = P.lv[level];
     uint32_t *keys = P.keys + (size_t)frame * P.keysPerFrame + G.keyBase;
@@ -767,11 +787,13 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
     constexpr int IP = BT_W + 8;                                   // staged bytes per row: x = tx0 - 4 .. tx0 + 67
     __shared__ __attribute__((aligned(16))) uint8_t s_in[(BT_H + 6) * IP];
     __shared__ __attribute__((aligned(16))) unsigned short s_row[(BT_H + 6) * BT_W];
-    const int frame = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    int tileI, frame;
+    if (!xcd_item(P.blurTiles, P.nFrames, tileI, frame)) return;
     int l = 0;
-    while (l + 1 < P.nlevels && (int)blockIdx.x >= P.lv[l + 1].tileBase) l++;
+    while (l + 1 < P.nlevels && tileI >= P.lv[l + 1].tileBase) l++;
     const LevelDev &D = P.lv[l];
-    const int t = blockIdx.x - D.tileBase;
+    const int t = tileI - D.tileBase;
     const int tx0 = (t % D.tilesX) * BT_W, ty0 = (t / D.tilesX) * BT_H;
     int pitch;
     const uint8_t *img = level_ptr(P, frame, l, pitch);
@@ -906,11 +928,14 @@ __device__ __forceinline__ void undistort_point(const msl_frame_params &p, float
 }
 
 __global__ __launch_bounds__(256) void k_describe(OrbDev P) {
-    const int frame = blockIdx.z, level = blockIdx.y;
+    int item, frame;
+    const int perLevel = (P.selCap + 3) / 4;
+    if (!xcd_item(perLevel * P.nlevels, P.nFrames, item, frame)) return;
+    const int level = item / perLevel, blockX = item % perLevel;
     const int lane = threadIdx.x & 63;
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int idx = blockX * 4 + (threadIdx.x >> 6);
     const int *nsel = P.nsel + frame * P.nlevels;
-    if (blockIdx.x == 0 && level == 0 && threadIdx.x == 0) {
+    if (blockX == 0 && level == 0 && threadIdx.x == 0) {
         int tot = 0;
         for (int l = 0; l < P.nlevels; l++) tot += nsel[l];
         P.nout[frame] = min(tot, P.outCap);
@@ -1287,6 +1312,7 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     P.in = d_gray; P.inRowStride = rowStride; P.inFrameStride = frameStride;
     P.kps = d_kps; P.desc = d_desc; P.nout = d_nout;
     P.frameOn = ep ? 1 : 0;
+    P.nFrames = n;
     if (ep) {
         P.fp = ep->fp;
         P.gridWInv = (float)MSL_FRAME_GRID_COLS / (float)(ep->fp.maxX - ep->fp.minX);   // src/Frame.cc:137-138
@@ -1299,7 +1325,7 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     static const bool perLevel = getenv("MSL_ORB_PYRAMID") && !strcmp(getenv("MSL_ORB_PYRAMID"), "levels");
     if (P.pyrTX && !perLevel) {
         h->prof.begin(KID_RESIZE, s);
-        hipLaunchKernelGGL(k_pyramid, dim3((unsigned)(P.pyrTX * P.pyrTY), (unsigned)n), dim3(256), h->pyrLds, s, P);
+        hipLaunchKernelGGL(k_pyramid, dim3(xcd_grid1((long long)P.pyrTX * P.pyrTY * n)), dim3(256), h->pyrLds, s, P);
         h->prof.end(s);
     } else {
         for (int l = 1; l < L; l++) {
@@ -1315,24 +1341,24 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     if (fork) {
         MSL_HIP_TRY(hipEventRecord(h->evFork, s));
         MSL_HIP_TRY(hipStreamWaitEvent(h->sideStream, h->evFork, 0));
-        hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, h->sideStream, P);
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid1((long long)P.blurTiles * n)), dim3(256), 0, h->sideStream, P);
         MSL_HIP_TRY(hipEventRecord(h->evJoin, h->sideStream));
     }
     h->prof.begin(KID_FAST, s);
-    hipLaunchKernelGGL(k_fast, dim3(P.cellsPerFrame, n), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_fast, dim3(xcd_grid1((long long)P.cellsPerFrame * n)), dim3(256), 0, s, P);
     h->prof.end(s);
     h->prof.begin(KID_OCTREE, s);
-    hipLaunchKernelGGL(k_octree, dim3(L, n), dim3(OCT_NT), (size_t)P.octLds, s, P);
+    hipLaunchKernelGGL(k_octree, dim3(xcd_grid1((long long)L * n)), dim3(OCT_NT), (size_t)P.octLds, s, P);
     h->prof.end(s);
     if (fork) {
         MSL_HIP_TRY(hipStreamWaitEvent(s, h->evJoin, 0));
     } else {
         h->prof.begin(KID_BLUR, s);
-        hipLaunchKernelGGL(k_blur, dim3(P.blurTiles, n), dim3(256), 0, s, P);
+        hipLaunchKernelGGL(k_blur, dim3(xcd_grid1((long long)P.blurTiles * n)), dim3(256), 0, s, P);
         h->prof.end(s);
     }
     h->prof.begin(KID_DESCRIBE, s);
-    hipLaunchKernelGGL(k_describe, dim3((P.selCap + 3) / 4, L, n), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(k_describe, dim3(xcd_grid1((long long)((P.selCap + 3) / 4) * L * n)), dim3(256), 0, s, P);
     h->prof.end(s);
     MSL_HIP_TRY(hipGetLastError());
     h->lastFrames = n;
