@@ -16,6 +16,8 @@
 
 #include "msl_common.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -357,10 +359,12 @@ __device__ __forceinline__ Rect child_rect(const Rect r, int q) {
 // Where a workgroup keeps the level's candidate keys and their node ids while the list is subdivided.  REG: in registers (OCT_KPT per thread:
 // <= 8192 candidates per level, which covers every frame but synthetic noise) -- a key never moves, only its node id changes, so no round
 // touches memory for them; otherwise in the global keys / knode arrays as in rounds 1-3 (slower: every pass is a chain of L2 round trips).
-constexpr int OCT_KPT = 16;
-template <bool REG> struct OctKeys {
-    uint32_t key[REG ? OCT_KPT : 1];
-    unsigned node[REG ? OCT_KPT : 1], quad[REG ? OCT_KPT : 1];
+// KPT = keys per thread held in registers (16: <= 8192 candidates per level, 32: <= 16384 -- level 0 of a 1280 x 960 frame has ~14 k); 0 = global arrays.
+template <int KPT> struct OctKeys {
+    static constexpr bool REG = KPT > 0;
+    static constexpr int OCT_KPT = KPT > 0 ? KPT : 1;
+    uint32_t key[OCT_KPT];
+    unsigned node[OCT_KPT], quad[OCT_KPT];
     uint32_t *gkeys; uint16_t *gnode; unsigned n; int tid;
     unsigned per;   // REG: a thread owns the `per` CONSECUTIVE keys k = tid * per + j -- neighbours in FAST-cell order, i.e. mostly in the same node
     // f(k, key, node&, quad&): quad is scratch that survives between two passes of one round (REG only; recomputed otherwise)
@@ -382,9 +386,11 @@ template <bool REG> struct OctKeys {
     }
 };
 
-template <bool REG>
-__device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, OctKeys<REG> &K, unsigned char *s_dyn, unsigned *s_wave, int *s_misc, int frame,
+template <int KPT>
+__device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, OctKeys<KPT> &K, unsigned char *s_dyn, unsigned *s_wave, int *s_misc, int frame,
                                             int level) {
+    constexpr bool REG = KPT > 0;
+    constexpr int OCT_KPT = KPT > 0 ? KPT : 1;
     const int M = P.maxNode, tid = threadIdx.x, N = G.quota;
     const unsigned n = K.n;
     Rect *const s_rectB = reinterpret_cast<Rect *>(s_dyn);                         // [2][M]
@@ -684,6 +690,9 @@ __device__ __forceinline__ void octree_body(const OrbDev &P, const LevelDev &G, 
     OCT_STAMP(P, level, frame, 81);
 }
 
+// MAXKPT: the largest register-resident form this instantiation carries.  The 32-keys-per-thread form needs 239 VGPRs (a 512-thread workgroup then
+// fills its CU's register files), so launches for ordinary frame sizes use k_octree<16> (133 VGPRs) and only large frames k_octree<32>.
+template <int MAXKPT>
 __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
     // Node arrays sized for THIS extractor's longest possible list (P.maxNode = max over levels of max(quota, 4 nIni) + 2, rounded up to 64, plus
     // one block of slack; 66 bytes per node: 21 KB for 1000 features instead of a fixed 66 KB for MAXNODE = 1024), so that the frame-batched kernels
@@ -728,8 +737,9 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
         while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= k) lo = mid; else hi = mid; }
         return lo;
     };
-    if (n <= (unsigned)OCT_KPT * OCT_NT) {
-        OctKeys<true> K;
+    auto run_in_registers = [&](auto kptTag) {
+        constexpr int OCT_KPT = decltype(kptTag)::value;
+        OctKeys<OCT_KPT> K;
         K.n = n; K.tid = tid; K.gkeys = keys; K.gnode = knode; K.per = (n + OCT_NT - 1) / OCT_NT;
         int c = 0;
 #pragma unroll
@@ -750,13 +760,18 @@ __global__ __launch_bounds__(OCT_NT) void k_octree(OrbDev P) {
             if ((unsigned)j < K.per && k < n) keys[k] = K.key[j];     // (the global copy is what msl_orb_debug_candidates reads)
         }
         __syncthreads();   // s_off is dead from here on: the node arrays take its place
-        octree_body<true>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
+        octree_body<OCT_KPT>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
+    };
+    if (n <= 16u * OCT_NT) {
+        run_in_registers(std::integral_constant<int, 16>{});
+    } else if (MAXKPT >= 32 && n <= 32u * OCT_NT) {   // level 0 of a 1280 x 960 frame: ~14 k candidates
+        if constexpr (MAXKPT >= 32) run_in_registers(std::integral_constant<int, 32>{});
     } else {
-        OctKeys<false> K;
+        OctKeys<0> K;
         K.n = n; K.tid = tid; K.gkeys = keys; K.gnode = knode; K.per = 0;
         for (unsigned k = tid; k < n; k += OCT_NT) { const int c = cell_of(k); keys[k] = cellKeys[s_koff[c] + (k - s_off[c])]; knode[k] = 0; }
         __syncthreads();
-        octree_body<false>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
+        octree_body<0>(P, G, K, s_dyn, s_wave, s_misc, frame, level);
     }
 }
 
@@ -1059,6 +1074,7 @@ const char *kKernelNames[MSL_ORB_NKERNELS] = {"k_pyramid", "k_fast", "k_octree",
 struct msl_orb {
     int device = 0;
     int nfeatures = 0, nlevels = 0, iniTh = 0, minTh = 0, maxW = 0, maxH = 0, maxBatch = 0;
+    bool octBig = false;   // frames of more than 640 x 480 x 1.5 pixels: level 0 may hold more than 8192 FAST candidates -> k_octree<32>
     int outCap = 0;   // keypoints per frame the outputs are sized for: fixed by the creation geometry (msl_orb_capacity)
     double scaleFactor = 0;
     std::vector<float> scale, invScale, sigma2, invSigma2;
@@ -1251,7 +1267,10 @@ int build_geometry(msl_orb *h, int W, int H) {
         D.octLds = (int)((std::max<size_t>((size_t)OCT_NODE_BYTES * D.maxNode, 2 * sizeof(unsigned) * (size_t)(maxCells + 1)) + 15) & ~(size_t)15);
     }
     if (D.octLds > 32 * 1024)   // (a large feature budget: more dynamic LDS than a launch gets by default)
-        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree), hipFuncAttributeMaxDynamicSharedMemorySize, D.octLds));
+    {
+        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<16>), hipFuncAttributeMaxDynamicSharedMemorySize, D.octLds));
+        MSL_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_octree<32>), hipFuncAttributeMaxDynamicSharedMemorySize, D.octLds));
+    }
     if (h->outCap == 0) h->outCap = std::max(h->nfeatures + 2 * L, needCap);   // creation: the handle's capacity follows its (max_width, max_height) geometry
     if (needCap > h->outCap) {
         set_error("frame %dx%d can return %d keypoints (aspect ratio: %d quadtree roots), the extractor was created for %d; create it with this frame size", W, H,
@@ -1259,6 +1278,7 @@ int build_geometry(msl_orb *h, int W, int H) {
         return MSL_ERR_INVALID;
     }
     D.outCap = h->outCap;
+    h->octBig = (long long)W * H > 640ll * 480 * 3 / 2;
     D.blurTiles = tileBase;
     D.pyrStride = (pyrOff + 255) & ~(size_t)255;
     D.blurStride = (blurOff + 255) & ~(size_t)255;
@@ -1348,7 +1368,8 @@ int launch_pipeline(msl_orb *h, const uint8_t *d_gray, size_t rowStride, size_t 
     hipLaunchKernelGGL(k_fast, dim3(xcd_grid1((long long)P.cellsPerFrame * n)), dim3(256), 0, s, P);
     h->prof.end(s);
     h->prof.begin(KID_OCTREE, s);
-    hipLaunchKernelGGL(k_octree, dim3(xcd_grid1((long long)L * n)), dim3(OCT_NT), (size_t)P.octLds, s, P);
+    if (h->octBig) hipLaunchKernelGGL(k_octree<32>, dim3(xcd_grid1((long long)L * n)), dim3(OCT_NT), (size_t)P.octLds, s, P);
+    else hipLaunchKernelGGL(k_octree<16>, dim3(xcd_grid1((long long)L * n)), dim3(OCT_NT), (size_t)P.octLds, s, P);
     h->prof.end(s);
     if (fork) {
         MSL_HIP_TRY(hipStreamWaitEvent(s, h->evJoin, 0));

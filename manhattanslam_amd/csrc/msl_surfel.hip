@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <type_traits>
 #include <vector>
 
 using namespace msl;
@@ -1522,29 +1523,40 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
     unsigned cnt = 0;
-    unsigned long long emit = 0;   // bit j: seed s0 + j spawns a surfel (j < 64)
+    unsigned long long emit = 0, emitHi = 0;   // bit j: seed s0 + j spawns a surfel (emit: j < 64; emitHi: 64 <= j < 128)
     const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
     const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
-    if (per <= 32 && (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0) {
-        // common geometry: all flag words of the thread in ONE round trip
-        unsigned cw[8], fw[8];
+    const bool aligned4 = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
+    // all flag words of the thread in ONE round trip: 8 words each for <= 32 seeds per thread (640 x 480: 19), 24 words for <= 96 (1280 x 960: 76 --
+    // round 3 walked the seeds beyond the 64th one by one, two dependent byte loads each, and the kernel took 30 us at that size)
+    auto flags_in_one_trip = [&](auto nqTag) {
+        constexpr int NQ = decltype(nqTag)::value;
+        unsigned cw[NQ], fw[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < NQ; q++) {
             const int i = s0 + 4 * q;
             const bool in = 4 * q < per && i < s1;
             cw[q] = in ? *reinterpret_cast<const unsigned *>(candOk + i) : 0u;
             fw[q] = in ? *reinterpret_cast<const unsigned *>(fused + i) : 0u;
         }
-        asm volatile("" ::"v"(cw[0]), "v"(cw[1]), "v"(cw[2]), "v"(cw[3]), "v"(cw[4]), "v"(cw[5]), "v"(cw[6]), "v"(cw[7]),
-                     "v"(fw[0]), "v"(fw[1]), "v"(fw[2]), "v"(fw[3]), "v"(fw[4]), "v"(fw[5]), "v"(fw[6]), "v"(fw[7]));
 #pragma unroll
-        for (int q = 0; q < 8; q++)
+        for (int q = 0; q < NQ; q += 8)   // (a common use per group of loads keeps them from being sunk into their consumers)
+            asm volatile("" ::"v"(cw[q]), "v"(cw[q + 1]), "v"(cw[q + 2]), "v"(cw[q + 3]), "v"(cw[q + 4]), "v"(cw[q + 5]), "v"(cw[q + 6]), "v"(cw[q + 7]),
+                         "v"(fw[q]), "v"(fw[q + 1]), "v"(fw[q + 2]), "v"(fw[q + 3]), "v"(fw[q + 4]), "v"(fw[q + 5]), "v"(fw[q + 6]), "v"(fw[q + 7]));
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const unsigned e = (s0 + 4 * q + j < s1 && ((cw[q] >> (8 * j)) & 0xFF) && !((fw[q] >> (8 * j)) & 0xFF)) ? 1u : 0u;
                 cnt += e;
-                emit |= (unsigned long long)e << (4 * q + j);
+                if (4 * q + j < 64) emit |= (unsigned long long)e << ((4 * q + j) & 63);
+                else emitHi |= (unsigned long long)e << ((4 * q + j - 64) & 63);
             }
+    };
+    if (per <= 32 && aligned4) {
+        flags_in_one_trip(std::integral_constant<int, 8>{});
+    } else if (per <= 96 && aligned4) {
+        flags_in_one_trip(std::integral_constant<int, 24>{});
     } else {
         for (int i = s0; i < s1; i += 4) {
             unsigned c4, f4;
@@ -1559,6 +1571,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                 const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
                 cnt += e;
                 if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+                else if (i + j - s0 < 128) emitHi |= (unsigned long long)e << (i + j - s0 - 64);
             }
         }
     }
@@ -1701,7 +1714,8 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             else if (pf && j == 1) emit_one(e1);
             else emit_one(cand[i]);
         }
-        for (int i = s0 + 64; i < s1; i++)
+        for (unsigned long long mh = emitHi; mh; mh &= mh - 1) emit_one(cand[s0 + 64 + __builtin_ctzll(mh)]);
+        for (int i = s0 + 128; i < s1; i++)
             if (candOk[i] && !fused[i]) emit_one(cand[i]);
     }
     __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
