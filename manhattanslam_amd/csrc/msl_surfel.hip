@@ -138,6 +138,16 @@ struct SfDev {
     const long long *nPubPrev;         // live count before compaction j - 1 (= after compaction j - 2)
     long long *nPubOut;                // k_compact: the live count after this keyframe; k_fuse mode 0: the live count it found (for the next keyframe's mode 1)
     unsigned *resetDelUCount;          // k_compact: the hand-over count of the slot keyframe j + 2 will use
+    // merged launches (k_fuse_merged: workgroup 0 compacts keyframe j - 1 while the others fuse keyframe j)
+    const unsigned *prevDelU;          // hand-over list of keyframe j - 1
+    const unsigned *prevBlockUpd;      // updated surfels per sub-block of keyframe j - 1
+    long long *nPubCompact;            // where the compaction of keyframe j - 1 publishes the live count it leaves
+    unsigned *resetDelUCountCompact;   // the hand-over count that compaction re-arms (keyframe j + 1's slot)
+    unsigned *doneFlag;                // set to `epoch` (write-through) when the compaction is complete; the dependent waves poll it
+    unsigned epoch;
+    int prevSlot;                      // superpixel slot of keyframe j - 1 (candidates, fused flags)
+    unsigned *updCtr;                  // [64] updated-surfel counts of this keyframe, hashed by sub-block (merged batches only; NULL otherwise)
+    unsigned *prevUpdCtr;              // the same of keyframe j - 1: summed and cleared by its compaction
 };
 
 __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_NUM partition of :430-434
@@ -1240,8 +1250,33 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long m) {   // numbe
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int nSubHint) {   // F by value: kernarg -> SGPRs
-    __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
+// Agent-scope (L2-bypassing) forms of the record loads: the dependent waves of a merged launch read sub-blocks that workgroup 0 has just written
+// (write-through) from another XCD, and must not be served a line their own L2 fetched before.
+__device__ __forceinline__ uint4 ld_agent16(const uint4 *p) {
+    const unsigned *q = reinterpret_cast<const unsigned *>(p);
+    return make_uint4(ld_agent(q), ld_agent(q + 1), ld_agent(q + 2), ld_agent(q + 3));
+}
+__device__ __forceinline__ HotRec ld_hot(const MapSoA &M, long long i, bool coh) {
+    if (!coh) return M.hot[i];
+    const unsigned *q = reinterpret_cast<const unsigned *>(M.hot + i);
+    HotRec h;
+    h.px = __uint_as_float(ld_agent(q)); h.py = __uint_as_float(ld_agent(q + 1)); h.pz = __uint_as_float(ld_agent(q + 2));
+    h.updateTimes = (int)ld_agent(q + 3); h.lastUpdate = (int)ld_agent(q + 4);
+    return h;
+}
+__device__ __forceinline__ ColdRec ld_cold(const MapSoA &M, long long i, bool coh) {
+    if (!coh) return M.cold[i];
+    const uint4 a = ld_agent16(reinterpret_cast<const uint4 *>(M.cold + i)), b = ld_agent16(reinterpret_cast<const uint4 *>(M.cold + i) + 1);
+    ColdRec c;
+    c.nx = __uint_as_float(a.x); c.ny = __uint_as_float(a.y); c.nz = __uint_as_float(a.z); c.size = __uint_as_float(a.w);
+    c.color = __uint_as_float(b.x); c.weight = __uint_as_float(b.y); c.rgbf = b.z; c._spare = b.w;
+    return c;
+}
+
+// One fuse wave.  waveIdx / G: this wave's number and the number of fuse waves of the launch (a plain k_fuse launch: blockIdx.x / gridDim.x; a merged
+// launch: one less each, workgroup 0 being the compaction).
+template <bool MERGED>   // MERGED: the fuse waves of k_fuse_merged (fuseMode 3); the plain kernel does not carry the waiting / past-the-L2 paths
+__device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameDev &F, int nSubHint, unsigned waveIdx, int G) {
     const MapSoA &M = P.map;
     const unsigned lane = threadIdx.x;
     const uint2 *tex = P.tex + (size_t)slot * P.pxStride;
@@ -1250,7 +1285,6 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
     const int ref = F.ref;
     const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
     const float halfF = 0.5f * cameraF;   // BASELINE * cameraF (:220), exact
-    const int G = (int)gridDim.x;
     // Wave g owns sub-block G - 1 - g (the newest surfels -- nearly all in view: most phase-B work -- are dispatched first) and, should the
     // map have outgrown the grid, G - 1 - g + G, ... (grid-stride; normally one iteration).  The grid covers the host's last KNOWN live count
     // plus a margin, not its upper bound (which runs up to 1.5 x ahead between count snapshots).  Sub-blocks below nSubHint load at once; above
@@ -1260,21 +1294,44 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
     // it held no deleted slot after keyframe j - 1 (no new surfel or tail element lands in it) and it ends below n - D (the tail moves take
     // their sources from [n - (D - K), n), new surfels are appended from n on).  Mode 1 fuses the safe sub-blocks with the live count as it was
     // before that compaction (all of them lie below it whatever the compaction does); mode 2, launched behind the compaction, the others.
-    const int mode = P.fuseMode;
+    const int mode = MERGED ? 3 : P.fuseMode;
     long long nBefore = 0, safeEnd = 0;
     if (mode) {
         nBefore = *P.nPubPrev;
         safeEnd = nBefore - (long long)*P.prevDelUCount;
     }
-    if (mode == 0 && blockIdx.x == 0 && lane == 0) *P.nPubOut = P.ctr[0];   // what the next keyframe's mode-1 launch takes as its live count
-    for (long long sb = (long long)G - 1 - (long long)blockIdx.x;; sb += G) {
+    if (mode == 0 && waveIdx == 0 && lane == 0) *P.nPubOut = P.ctr[0];   // what the next keyframe's mode-1 launch takes as its live count
+    bool cohVar = false;   // mode 3: this wave waited for the compaction and reads its sub-block past the L2
+#define coh (MERGED && cohVar)
+    auto wait_compaction = [&]() -> bool {
+        unsigned spins = 0;
+        while (ld_agent(P.doneFlag) != P.epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 20)) {   // ~0.5 s: workgroup 0 is gone; report instead of hanging the queue
+                if (lane == 0) __hip_atomic_store(&P.ctr[5], 31ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        return true;
+    };
+    for (long long sb = (long long)G - 1 - (long long)waveIdx;; sb += G) {
 #ifdef MSL_FUSE_STAMPS   // instrumented experiment builds (tools/fuse_stamps.py): 100 MHz device-clock stamps of every wave in srcOf[]
         const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (mode == 1) {
+        if constexpr (MERGED) {
+            // merged launch: workgroup 0 compacts keyframe j - 1 meanwhile.  A wave whose sub-block that compaction can touch waits for it, then reads
+            // the sub-block past its L2 (the compaction's stores are write-through; this XCD must not serve an older copy of the line)
+            if (sb * SUB_ITEMS >= nBefore + P.nseeds) return;   // beyond anything the compaction can append
+            if (!coh && (sb + 1) * SUB_ITEMS > safeEnd) {       // the end of the array: tail moves, appended surfels
+                if (!wait_compaction()) return;
+                cohVar = true;
+            }
+            if (coh && sb * SUB_ITEMS >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        } else if (mode == 1) {
             if ((sb + 1) * SUB_ITEMS > safeEnd) return;   // this sub-block and the ones the wave would visit next (+G) belong to the mode-2 launch
         } else if (sb >= nSubHint && sb * SUB_ITEMS >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         unsigned prevDeleted = 0;
+        if (MERGED && !coh) prevDeleted = P.prevBlockSums[sb];   // (requested together with the hot records)
         if (mode == 2) {   // nearly every wave of this launch leaves here: decide before loading anything
             const bool unsafe = (sb + 1) * SUB_ITEMS > safeEnd || P.prevBlockSums[sb] != 0;
             if (!unsafe) {
@@ -1288,11 +1345,24 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
         uint4 q[5];
         {
             const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
+            if (coh) {
 #pragma unroll
-            for (int e = 0; e < 5; e++) q[e] = hp[e];
+                for (int e = 0; e < 5; e++) q[e] = ld_agent16(hp + e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 5; e++) q[e] = hp[e];
+            }
+        }
+        if (MERGED && prevDeleted) {   // a sub-block with a hole: the compaction may put a surfel there -- wait for it and load again, past the L2
+            if (!wait_compaction()) return;
+            cohVar = true;
+            const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);
+#pragma unroll
+            for (int e = 0; e < 5; e++) q[e] = ld_agent16(hp + e);
+            prevDeleted = 0;
         }
         if (prevDeleted) continue;   // mode 1: compaction j - 1 puts a surfel into this sub-block; the mode-2 launch fuses it
-        const long long n = mode == 1 ? nBefore : P.ctr[0];
+        const long long n = (mode == 1 || (MERGED && !coh)) ? nBefore : (coh ? __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.ctr[0]);
         const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
                                 q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
         int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
@@ -1374,8 +1444,8 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
             // lanes) -- conditional loads made the compiler sink the first uses into the load block and wait there
             const long long i = c0 + (item & 0xFFu);
             const unsigned sp = item >> 16;
-            const HotRec h = M.hot[i];
-            ColdRec c = M.cold[i];
+            const HotRec h = ld_hot(M, i, coh);
+            ColdRec c = ld_cold(M, i, coh);
             const float4 f0 = fuseRec[3 * sp], f1 = fuseRec[3 * sp + 1], f2 = fuseRec[3 * sp + 2];
             // common use of one field per load instruction: all records are in flight together
             asm volatile("" ::"v"(h.px), "v"(h.lastUpdate), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x));
@@ -1438,7 +1508,10 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
                 cntDelB += cb;
             }
         }
-        if (lane == 0) { P.blockSums[sb] = cntDel + cntDelB; P.blockUpd[sb] = nupd; }
+        if (lane == 0) {
+            P.blockSums[sb] = cntDel + cntDelB; P.blockUpd[sb] = nupd;
+            if (P.updCtr && nupd) atomicAdd(&P.updCtr[sb & 63], nupd);   // merged batches: the compaction wave adds up 64 words instead of one per sub-block
+        }
 #ifdef MSL_FUSE_STAMPS
         if (lane == 0 && ref == MSL_FUSE_STAMPS) {   // the keyframe with this number only: one in the middle of a batch, co-running kernels and all
             unsigned hwid;
@@ -1451,8 +1524,11 @@ __global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int 
             o[1] = make_uint4(hwid, xcc, nupd, 0u);
         }
 #endif
-        if ((sb + G) * SUB_ITEMS >= n) return;   // (normally) nothing beyond the grid
+        // (normally) nothing beyond the grid.  A merged launch's wave that has not waited knows the live count BEFORE the compaction only: what the
+        // compaction appends may lie in its next sub-block (the head of the loop decides)
+        if ((sb + G) * SUB_ITEMS >= ((MERGED && !coh) ? nBefore + (long long)P.nseeds : n)) return;
     }
+#undef coh
 }
 
 __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
@@ -1475,12 +1551,310 @@ __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long
     if (c.rgbf & COLD_WIDE) { M.rgbWide[3 * dst] = M.rgbWide[3 * src]; M.rgbWide[3 * dst + 1] = M.rgbWide[3 * src + 1]; M.rgbWide[3 * dst + 2] = M.rgbWide[3 * src + 2]; }
 }
 
+constexpr int TAIL_MAX_HOPS = 64;   // relay hops resolved per hole before the literal loop takes over (k_compact, compact_wave)
+
+// Write-through (agent-scope) forms for the compaction wave of a merged launch: other XCDs' waves read these records in the same launch.
+__device__ __forceinline__ void st_agent_f(float *p, float v) { __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void store_hot_wt(const MapSoA &M, long long i, const HotRec &h) {
+    unsigned *q = reinterpret_cast<unsigned *>(M.hot + i);
+    st_agent(q, __float_as_uint(h.px)); st_agent(q + 1, __float_as_uint(h.py)); st_agent(q + 2, __float_as_uint(h.pz));
+    st_agent(q + 3, (unsigned)h.updateTimes); st_agent(q + 4, (unsigned)h.lastUpdate);
+}
+__device__ __forceinline__ void store_cold_wt(const MapSoA &M, long long i, const ColdRec &c) {
+    unsigned *q = reinterpret_cast<unsigned *>(M.cold + i);
+    st_agent(q, __float_as_uint(c.nx)); st_agent(q + 1, __float_as_uint(c.ny)); st_agent(q + 2, __float_as_uint(c.nz)); st_agent(q + 3, __float_as_uint(c.size));
+    st_agent(q + 4, __float_as_uint(c.color)); st_agent(q + 5, __float_as_uint(c.weight)); st_agent(q + 6, c.rgbf); st_agent(q + 7, c._spare);
+}
+__device__ __forceinline__ void store_surfel_wt(const MapSoA &M, long long i, const msl_surfel &e) {
+    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
+    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.weight = e.weight; c._spare = 0;
+    if (rgb_fits(e.r, e.g, e.b)) c.rgbf = rgb_pack(e.r, e.g, e.b);
+    else {
+        c.rgbf = COLD_WIDE; __hip_atomic_store(M.wideFlag, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_agent(reinterpret_cast<unsigned *>(M.rgbWide + 3 * i), (unsigned)e.r); st_agent(reinterpret_cast<unsigned *>(M.rgbWide + 3 * i + 1), (unsigned)e.g);
+        st_agent(reinterpret_cast<unsigned *>(M.rgbWide + 3 * i + 2), (unsigned)e.b);
+    }
+    store_hot_wt(M, i, h); store_cold_wt(M, i, c);
+}
+__device__ __forceinline__ void move_surfel_wt(const MapSoA &M, long long dst, long long src, bool cohLoad) {
+    const ColdRec c = ld_cold(M, src, cohLoad);
+    store_hot_wt(M, dst, ld_hot(M, src, cohLoad)); store_cold_wt(M, dst, c);
+    if (c.rgbf & COLD_WIDE)
+        for (int q = 0; q < 3; q++) st_agent(reinterpret_cast<unsigned *>(M.rgbWide + 3 * dst + q), ld_agent(reinterpret_cast<const unsigned *>(M.rgbWide + 3 * src + q)));
+}
+
+// compact_wave: the whole of k_compact (mode 0) by ONE wave without LDS, for workgroup 0 of a merged launch (k_fuse_merged): it compacts keyframe
+// j - 1 while the other workgroups fuse keyframe j.  No LDS and <= 64 VGPRs on purpose: registers and LDS are allocated per kernel, and the fuse
+// waves of the same launch must keep fitting the holes the frame-batched kernels leave.  Everything other XCDs read in this launch (the records
+// it places or moves, the live count, the published count, the re-armed hand-over counter) is stored write-through, then the flag.
+//   D <= LIST_D (the steady state): the hand-over list is rank-sorted through the deleted-slot scratch and kept in registers (4 per lane,
+//   ascending; lookups by ds_bpermute).  Larger D (a mispredicted launch; the host uses the two-kernel chain when it expects many deletions):
+//   this wave lists the deleted slots of every sub-block that reports any, in order -- correct, slow.
+__device__ void compact_wave(const SfDev &P) {
+    const unsigned lane = threadIdx.x;
+#ifdef MSL_FUSE_STAMPS
+    unsigned long long cwst[10]; int cwn = 0;
+#define CW_STAMP() cwst[cwn++] = __builtin_amdgcn_s_memrealtime()
+#else
+#define CW_STAMP()
+#endif
+    CW_STAMP();
+    const MapSoA &M = P.map;
+    const int slot = P.prevSlot;
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.nseeds, *fused = P.fused + (size_t)slot * P.nseeds;
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    // ---- everything that depends on nothing is requested first: counters, the hand-over list, the updated counts, the first flag words ----
+    const unsigned dHand = *P.prevDelUCount;
+    const long long n = P.ctr[0];
+    const bool bad = P.ctr[5] == 20;
+    unsigned upd = P.prevUpdCtr[lane];   // updated surfels of keyframe j - 1: 64 hashed partial sums (its fuse waves added them up)
+    const long long tot8 = P.ctr[8], tot9 = P.ctr[9], tot10 = P.ctr[10], tot11 = P.ctr[11], tot12 = P.ctr[12];   // running totals (only this wave writes them)
+    unsigned du[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) du[t] = P.prevDelU[lane + 64 * t];   // (LIST_D entries exist whatever dHand is)
+    // flag bytes, 16 consecutive seeds per lane and load (1024 per round), five rounds (5120 seeds: the whole 640 x 480 lattice) requested at once;
+    // branch-free (clamped addresses; bytes beyond the lattice are masked when they are looked at)
+    constexpr int FR = 5;
+    uint4 cwv[FR], fwv[FR];
+    const int nRounds16 = (P.nseeds + 1023) >> 10;
+    const int lastQuad = ((P.nseeds - 1) >> 4) * 16;   // (nseeds is a multiple of 16 for every lattice the host merges launches for; the tail is masked)
+    auto load_flags = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < FR; q++) {
+            const int sI = min(1024 * (r0 + q) + 16 * (int)lane, lastQuad);
+            cwv[q] = *reinterpret_cast<const uint4 *>(candOk + sI);
+            fwv[q] = *reinterpret_cast<const uint4 *>(fused + sI);
+        }
+    };
+    auto spawn_bits = [&](const uint4 &c, const uint4 &f, int sI) -> unsigned {
+        const unsigned cw[4] = {c.x, c.y, c.z, c.w}, fw[4] = {f.x, f.y, f.z, f.w};
+        unsigned bits = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (((cw[w] >> (8 * j)) & 0xFF) && !((fw[w] >> (8 * j)) & 0xFF)) bits |= 1u << (4 * w + j);
+        const int left = P.nseeds - sI;   // seeds of this lane inside the lattice
+        return left >= 16 ? bits : (left <= 0 ? 0u : bits & ((1u << left) - 1u));
+    };
+    load_flags(0);
+    P.prevUpdCtr[lane] = 0;              // cleared for the slot's next use
+    upd = wave_incl_scan(upd);
+    upd = (unsigned)__builtin_amdgcn_readlane((int)upd, 63);
+    unsigned spawn[FR];   // one bit per seed that spawns a surfel; the 40 flag registers die here, before the sort below needs its own
+#pragma unroll
+    for (int q = 0; q < FR; q++) spawn[q] = q < nRounds16 ? spawn_bits(cwv[q], fwv[q], 1024 * q + 16 * (int)lane) : 0u;
+    asm volatile("" ::"v"(upd), "v"(du[0]), "v"(spawn[0]), "v"(spawn[1]), "v"(spawn[2]), "v"(spawn[3]), "v"(spawn[4]));
+    CW_STAMP();   // 1: first loads
+    // ---- deleted slots, ascending: rank r lives in lane r & 63, register r >> 6 ----
+    long long D = 0;
+    unsigned sd[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const bool regList = dHand <= LIST_D;
+    if (dHand <= 64) {
+        // the steady state: one entry per lane, sorted inside the wave -- rank = number of smaller entries; a lane without an entry takes a rank
+        // behind them, so that the ranks are a permutation and one ds_permute puts every entry in its place (no memory round trip)
+        D = dHand;
+        const bool has = lane < dHand;
+        const unsigned v = has ? du[0] : 0xFFFFFFFFu;
+        unsigned rk = 0;
+        for (unsigned j = 0; j < dHand; j++) {
+            const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)v, (int)j);
+            rk += x < v ? 1u : 0u;
+        }
+        if (!has) rk = lane;   // lanes dHand .. 63 keep their own places (the entries occupy ranks 0 .. dHand - 1)
+        sd[0] = (unsigned)__builtin_amdgcn_ds_permute((int)(rk * 4u), (int)v);
+    } else if (regList) {
+        D = dHand;
+        unsigned rk[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (lane + 64 * t >= dHand) du[t] = 0xFFFFFFFFu;
+        for (unsigned j = 0; j < dHand; j++) {   // rank = number of smaller entries (the slots are distinct)
+            const unsigned pick = (j >> 6) == 0 ? du[0] : ((j >> 6) == 1 ? du[1] : ((j >> 6) == 2 ? du[2] : du[3]));
+            const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)pick, (int)(j & 63));
+#pragma unroll
+            for (int t = 0; t < 4; t++) rk[t] += x < du[t] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (lane + 64 * t < dHand) st_agent(&P.delList[rk[t]], du[t]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (lane + 64 * t < dHand) sd[t] = ld_agent(&P.delList[lane + 64 * t]);
+    } else {
+        const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;
+        unsigned base = 0;
+        for (long long b0 = 0; b0 < nblk; b0 += 64) {
+            const long long bb = b0 + lane;
+            const unsigned cntb = bb < nblk ? P.prevBlockSums[bb] : 0u;
+            unsigned long long nz = __ballot(cntb != 0);
+            while (nz) {
+                const int src = __builtin_ctzll(nz);
+                nz &= nz - 1;
+                const long long sb = b0 + src;
+                for (int k = 0; k < SUB_ITEMS / 64; k++) {
+                    const long long i = sb * SUB_ITEMS + 64 * k + lane;
+                    const bool del = i < n && M.hot[i].updateTimes == 0;
+                    const unsigned long long m = __ballot(del);
+                    if (del) st_agent(&P.delList[base + lane_rank(m)], (unsigned)i);
+                    base += (unsigned)__popcll(m);
+                }
+            }
+        }
+        D = base;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    CW_STAMP();   // 2: sorted list
+    const bool oneReg = D <= 64;
+    auto DL = [&](long long j) -> unsigned {   // j-th smallest deleted slot (per-lane j; EVERY lane must call it: a cross-lane read)
+        if (!regList) return ld_agent(&P.delList[j]);
+        const int srcLane = (int)(j & 63) * 4;
+        const unsigned v0 = (unsigned)__builtin_amdgcn_ds_bpermute(srcLane, (int)sd[0]);
+        if (oneReg) return v0;
+        const unsigned v1 = (unsigned)__builtin_amdgcn_ds_bpermute(srcLane, (int)sd[1]);
+        const unsigned v2 = (unsigned)__builtin_amdgcn_ds_bpermute(srcLane, (int)sd[2]), v3 = (unsigned)__builtin_amdgcn_ds_bpermute(srcLane, (int)sd[3]);
+        return (j >> 6) == 0 ? v0 : ((j >> 6) == 1 ? v1 : ((j >> 6) == 2 ? v2 : v3));
+    };
+    // ---- initializeSurfels (:285-331), first half: which seeds spawn a surfel, in seed order.  The flag words of eight rounds travel together and the
+    // next eight are requested before these are looked at; the seed index of new surfel k goes to a list (srcOf[k]) so that the second half
+    // can work on 64 of them at a time instead of one round after the other.
+    long long pos = 0;
+    unsigned mySeed = 0;     // seed of new surfel number `lane` while regSeeds (the first 64 travel through registers; the others through srcOf[])
+    bool regSeeds = true;
+    for (int r0 = 0; r0 < nRounds16; r0 += FR) {
+        if (r0) {   // (larger lattices: one more trip per 5120 seeds)
+            load_flags(r0);
+#pragma unroll
+            for (int q = 0; q < FR; q++) spawn[q] = r0 + q < nRounds16 ? spawn_bits(cwv[q], fwv[q], 1024 * (r0 + q) + 16 * (int)lane) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < FR; q++) {
+            const int sI = 1024 * (r0 + q) + 16 * (int)lane;
+            const unsigned bits = spawn[q];
+            unsigned long long any = __ballot(bits != 0);
+            if (!any) continue;   // most rounds spawn nothing
+            if (__popcll(any) <= 12) {
+                // a few spawning lanes (the steady state): walked by the whole wave in lockstep, no scan
+                while (any) {
+                    const int src = __builtin_ctzll(any);
+                    any &= any - 1;
+                    unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bits, src);
+                    while (b) {
+                        const unsigned seed = (unsigned)(1024 * (r0 + q) + 16 * src + __builtin_ctz(b));
+                        b &= b - 1;
+                        if (regSeeds && pos < 64) { if ((long long)lane == pos) mySeed = seed; }
+                        else if (lane == 0) st_agent(&P.srcOf[pos], seed);
+                        pos++;
+                    }
+                }
+            } else {
+                // many (a young map): scanned, every lane lists its own through srcOf[]; what the registers held so far goes there too
+                if (regSeeds) { if ((long long)lane < pos) st_agent(&P.srcOf[lane], mySeed); regSeeds = false; }
+                const unsigned c = (unsigned)__builtin_popcount(bits);
+                const unsigned incl = wave_incl_scan(c);
+                long long k = pos + (long long)(incl - c);
+                for (unsigned m = bits; m; m &= m - 1) st_agent(&P.srcOf[k++], (unsigned)(sI + __builtin_ctz(m)));
+                pos += (long long)(unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+        }
+    }
+    CW_STAMP();   // 3: flags
+    const long long K = pos;
+    const long long nAfter = D >= K ? n - (D - K) : n + (K - D);
+    // second half: new surfel k -> the k-th largest deleted slot while any remain, else appended (SurfelMapping.cpp:372-384); 64 at a time
+    // (the host keeps room for nseeds more surfels before it enqueues a keyframe, so nAfter <= cap; checked all the same)
+    const bool place = !bad && (unsigned long long)nAfter <= P.cap;
+    if (K > 0) {
+        if (K > 64 || !regSeeds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the list entries kept in memory have arrived)
+        for (long long kb = 0; kb < K; kb += 64) {
+            const long long k = kb + lane;
+            const bool on = k < K;
+            const unsigned seed = (kb == 0 && regSeeds) ? mySeed : (on ? ld_agent(&P.srcOf[k]) : 0u);
+            const unsigned hole = DL(on && k < D ? D - 1 - k : 0);
+            if (on) {
+                const msl_surfel e = cand[seed];
+                P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
+                if (place) store_surfel_wt(M, k < D ? (long long)hole : n + (k - D), e);
+            }
+        }
+    }
+    CW_STAMP();   // 4: emission
+    // ---- leftover holes: the back-to-front loop of SurfelMapping.cpp:386-390 resolved per hole (k_compact's formulation) ----
+    if (place && D > K) {
+        const long long R = D - K, nFinal = n - R;
+        auto lower = [&](long long x) -> long long {   // first index in the R smallest deleted slots with value >= x (per-lane x)
+            long long lo = 0, hi = R;
+            while (__ballot(lo < hi)) {   // all lanes step together (DL() is a cross-lane read); a lane that has finished probes a dummy
+                const long long mid = lo < hi ? (lo + hi) >> 1 : 0;
+                const long long v = (long long)DL(mid);
+                if (lo < hi) { if (v < x) lo = mid + 1; else hi = mid; }
+            }
+            return lo;
+        };
+        // (lower() and DL() use cross-lane reads: every lane runs the same number of search steps on its own argument, inactive lanes on a dummy)
+        const long long cntLow = lower(nFinal);   // uniform argument -> uniform result
+        bool overflow = false;
+        for (long long a0 = 0; a0 < cntLow && !overflow; a0 += 64) {
+            const long long a = a0 + lane;
+            long long p = nFinal + (a < cntLow ? a : 0);
+            bool chain = a < cntLow;
+            for (int hop = 0; hop < TAIL_MAX_HOPS; hop++) {   // uniform trip count; a lane whose chain has ended keeps p
+                const long long lb = lower(p);
+                const long long held = (long long)DL(lb < R ? lb : 0);   // (every lane: a cross-lane read)
+                const bool relay = chain && lb < R && held == p;
+                if (relay) p = n - (R - lb); else chain = false;
+                if (!__ballot(chain)) break;
+            }
+            if (__ballot(chain)) { overflow = true; break; }   // pathological chain: literal loop below
+            const unsigned dst = DL(a < cntLow ? a : 0);
+            if (a < cntLow) move_surfel_wt(M, (long long)dst, p, false);
+        }
+        if (overflow) {
+            // literal back-to-front loop, pathological delete patterns only.  Moves already made above are repeated identically (same source
+            // content: a source is never a destination of this formulation), so starting over is safe.
+            for (long long i = 1; i <= R; i++) {
+                const unsigned hole = DL(R - i);   // (uniform argument)
+                const long long src = n - i;
+                if (lane == 0 && src != (long long)hole) move_surfel_wt(M, (long long)hole, src, true);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    CW_STAMP();   // 5: tail
+    if (lane == 0) {
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = upd; P.ctr[4] = n; P.ctr[6] = nAfter;
+        P.ctr[8] = tot8 + K; P.ctr[9] = tot9 + D; P.ctr[10] = tot10 + upd; P.ctr[11] = tot11 + 1; P.ctr[12] = tot12 + n;
+        if (!place && !bad) P.ctr[5] = 20;   // capacity exceeded
+        const long long nOut = place ? nAfter : n;
+        __hip_atomic_store(&P.ctr[0], nOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.nPubCompact, nOut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        st_agent(P.resetDelUCountCompact, 0u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane's write-through stores have been acknowledged
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) st_agent(P.doneFlag, P.epoch);
+#ifdef MSL_FUSE_STAMPS
+    CW_STAMP();   // 6: publish
+    if (lane == 0 && (P.epoch & 31) == 20) { for (int q = 0; q < cwn; q++) P.delList[4096 + q] = (unsigned)cwst[q]; P.delList[4096 + 15] = (unsigned)K; P.delList[4096 + 14] = (unsigned)D; }
+#endif
+}
+
+__global__ __launch_bounds__(64) void k_fuse(SfDev P, int slot, FrameDev F, int nSubHint) {   // F by value: kernarg -> SGPRs
+    __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
+    fuse_body<false>(P, slot, F, nSubHint, blockIdx.x, (int)gridDim.x);
+}
+// Merged launch: workgroup 0 compacts keyframe j - 1 (compact_wave), workgroups 1 .. G fuse keyframe j (fuseMode 3).
+__global__ __launch_bounds__(64) void k_fuse_merged(SfDev P, int slot, FrameDev F, int nSubHint) {
+    __builtin_amdgcn_s_setprio(3);
+    if (blockIdx.x == 0) { compact_wave(P); return; }
+    fuse_body<true>(P, slot, F, nSubHint, blockIdx.x - 1, (int)gridDim.x - 1);
+}
+
 // Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
 // new surfel k -> d_{D-1-k} while any remain, else appended.  If D > K the literal `while` loop (:386-390) moves,
 // at step i = 1..R (R = D-K), the element at position n-i into the i-th largest leftover hole; a hole inside the
 // tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole (< nFinal) finally receives
 // resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): a short upward chain.
-constexpr int TAIL_MAX_HOPS = 64;
 
 // k_compact: everything after k_fuse in ONE launch.
 //   every workgroup : exclusive scan of the per-chunk deleted counts (each workgroup scans the <= cap/1024 partials itself,
@@ -1722,6 +2096,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
 #ifdef MSL_FUSE_STAMPS
     cst[3] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (P.updCtr && threadIdx.x < 64) P.updCtr[threadIdx.x] = 0;   // merged batches: this keyframe's hashed updated counts (used by compact_wave only) start over
     if (threadIdx.x == 0) {
         P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
         // running totals over all keyframes of this handle (one writer per launch, launches are ordered): bench.py derives the
@@ -1921,7 +2296,7 @@ struct msl_sf {
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
-    unsigned *d_tickets = nullptr, *d_delU = nullptr;
+    unsigned *d_tickets = nullptr, *d_delU = nullptr, *d_updCtr = nullptr;
     float *d_projTab = nullptr;
     bool propLds = false;        // t(s) of one keyframe fits the LDS: single-launch relaxation
     msl_surfel *d_new = nullptr;
@@ -2273,6 +2648,12 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             MSL_HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming | hipEventReleaseToDevice)); MSL_HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventReleaseToDevice));
             h->evFuse.push_back(a); h->evTail.push_back(b);
         }
+    // Merged launches (MSL_SF_MERGED=1): from the third keyframe of a call on, ONE launch per keyframe -- workgroup 0 of k_fuse_merged compacts
+    // keyframe f - 1 (compact_wave) while the other workgroups fuse keyframe f; the few waves whose sub-block that compaction can touch poll a
+    // flag and then read past their L2.  No second stream, no events: the chain loses one dependent launch per keyframe and the compaction
+    // disappears behind the fusion.  fuse_0, compact_0, fuse_1 | K_2 = {compact_1, fuse_2} | K_3 | ... | compact_{n-1}.
+    static const bool mergedOn = getenv("MSL_SF_MERGED") && !strcmp(getenv("MSL_SF_MERGED"), "1");
+    const bool mg = mergedOn && !ov && compact && n >= 3 && (D.nseeds & 15) == 0;
     hipStream_t sc = ov ? h->cmpStream : sm;
     for (int f = 0; f < n; f++) {
         // slot rotation: this keyframe's hand-over data in slot j % 3, what keyframe j - 1 left in (j - 1) % 3, live counts published in ctr[16 + slot]
@@ -2284,6 +2665,26 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         P.nPubPrev = h->d_ctr + 16 + next;             // n before compaction j - 1 = after compaction j - 2, slot (j - 2) % 3 = (j + 1) % 3
         P.resetDelUCount = h->d_tickets + 4 + prev;    // slot (j + 2) % 3 = (j - 1) % 3: keyframe j + 2's; its last readers (fusion j) are done when compaction j runs
         h->lastPar = par;
+        P.updCtr = mg ? h->d_updCtr + 64 * par : nullptr;
+        if (mg && f >= 2) {
+            // K_f: compaction of keyframe f - 1 (its hand-over data in slot prev, its superpixel data in slot f - 1) + fusion of keyframe f
+            P.fuseMode = 3;
+            P.prevDelU = D.delU + (size_t)prev * LIST_D; P.prevUpdCtr = h->d_updCtr + 64 * prev; P.prevSlot = f - 1;
+            P.nPubCompact = h->d_ctr + 16 + prev;               // compaction j - 1 publishes in its own slot
+            P.resetDelUCountCompact = h->d_tickets + 4 + next;  // (j - 1 + 2) % 3: keyframe j + 1's counter
+            P.doneFlag = h->d_tickets + 7; P.epoch = (unsigned)j;
+            P.nPubOut = h->d_ctr + 16 + par;
+            LAUNCH(SK_FUSE, sm, k_fuse_merged, dim3((unsigned)nSubGrid + 1u), dim3(64), P, f, h->h_frames[slot0 + f], nSubHint);
+            if (f == n - 1) {   // the call's last keyframe: its compaction as a launch of its own
+                P.fuseMode = 0;
+                LAUNCH(SK_COMPACT, sm, k_compact, dim3(128), dim3(256), P, f, 0);
+            }
+            if (f == n / 2) {
+                hipEvent_t ea, eb;
+                if (h->prof.kernel_pair(SK_NEW, &ea, &eb)) hipExtLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, sm, ea, eb, 0, 0);
+            }
+            continue;
+        }
         if (ov && f > 0) {
             P.fuseMode = 2; P.nPubOut = h->d_ctr + 16 + par;
             hipLaunchKernelGGL(k_fuse, dim3((unsigned)nSubGrid), dim3(64), 0, sc, P, f, h->h_frames[slot0 + f], nSubHint);   // tail_f: behind compaction f - 1
@@ -2300,7 +2701,8 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             MSL_HIP_TRY(hipStreamWaitEvent(sc, h->evFuse[f], 0));
         }
         P.nPubOut = h->d_ctr + 16 + par;
-        LAUNCH(SK_COMPACT, sc, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
+        if (!(mg && f == 1))   // (merged: keyframe 1's compaction is workgroup 0 of K_2)
+            LAUNCH(SK_COMPACT, sc, k_compact, dim3(compact ? 128 : 1), dim3(256), P, f, compact ? 0 : 1);   // scan + new surfels + refill + tail compaction
         if (ov && f == n - 1) { MSL_HIP_TRY(hipEventRecord(h->evCmp, sc)); MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evCmp, 0)); }
         if (f == n / 2) {   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
             hipEvent_t ea, eb;   // (the pair's first event completes with the previous command, so every event time contains the dependent-launch gap)
@@ -2360,6 +2762,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 8) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 8) == hipSuccess;   // [0..1] tickets, [3] change-list length, [4..6] the rotating hand-over counts
     ok = ok && hipMalloc(&h->d_delU, sizeof(unsigned) * LIST_D * 3) == hipSuccess;
+    ok = ok && hipMalloc(&h->d_updCtr, sizeof(unsigned) * 64 * 3) == hipSuccess && hipMemset(h->d_updCtr, 0, sizeof(unsigned) * 64 * 3) == hipSuccess;
     {   // (u - cx) / fx and (v - cy) / fy of every integer pixel coordinate: the float expression of back_project
         // (src/SurfelFusion.cpp:80-85) evaluated once here instead of six divisions per pixel in kb_seed_plane
         std::vector<float> tab((size_t)width + 1 + height + 1);
@@ -2374,6 +2777,8 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 16);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 4;
+    D.prevDelU = h->d_delU; D.prevBlockUpd = nullptr; D.nPubCompact = h->d_ctr + 16; D.resetDelUCountCompact = h->d_tickets + 4; D.doneFlag = h->d_tickets + 7; D.epoch = 0; D.prevSlot = 0;
+    D.updCtr = nullptr; D.prevUpdCtr = h->d_updCtr;
     D.fuseMode = 0; D.prevBlockSums = nullptr; D.prevDelUCount = h->d_tickets + 4; D.nPubPrev = h->d_ctr + 16; D.nPubOut = h->d_ctr + 16; D.resetDelUCount = h->d_tickets + 4;
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
@@ -2389,7 +2794,7 @@ void msl_sf_destroy(msl_sf *h) {
     h->prof.destroy();
     free_slots(h);
     auto F = [](auto *p) { if (p) (void)hipFree(p); };
-    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos); F(h->d_snapStore);
+    F(h->d_ctr); F(h->d_tickets); F(h->d_delU); F(h->d_updCtr); F(h->d_projTab); F(h->d_new); F(h->d_mapStore); F(h->d_blockSums); F(h->d_blockUpd); F(h->d_delList); F(h->d_srcOf); F(h->d_aos); F(h->d_snapStore);
     if (h->h_ctr) (void)hipHostFree(h->h_ctr);
     if (h->h_snap) (void)hipHostFree(h->h_snap);
     if (h->h_blk) (void)hipHostFree(h->h_blk);

@@ -705,18 +705,67 @@ def test_host_vector_sparse_change_list(oracle):
     g.close()
 
 
-def test_overlapped_map_stage_gives_identical_maps():
-    """MSL_SF_OVERLAP=1 (off by default: it measured slower): compaction j on its own stream beside fusion j + 1, which skips
-    the sub-blocks that compaction can touch and leaves them to a launch behind it.  The flag is read once per process, so the batched /
-    resident parity tests run again in a child process with it set: same maps, counters and new-surfel lists as the oracle."""
+@pytest.mark.parametrize("flag", ["MSL_SF_OVERLAP", "MSL_SF_MERGED"])
+def test_overlapped_map_stage_gives_identical_maps(flag):
+    """The two forms of "compaction j beside fusion j + 1" (run_batch): MSL_SF_OVERLAP=1, compaction on its own stream and the fusion split into a
+    launch for the sub-blocks the compaction cannot touch and one behind it for the others; MSL_SF_MERGED=1, ONE launch per keyframe whose first
+    workgroup compacts keyframe j - 1 while the others fuse keyframe j and the few dependent waves poll a flag.  The flags are read once per process,
+    so the batched / resident parity tests run again in a child process with each set: same maps, counters and new-surfel lists as the oracle."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MSL_SF_OVERLAP="1")
+    env = dict(os.environ)
+    env.pop("MSL_SF_OVERLAP", None); env.pop("MSL_SF_MERGED", None)
+    env[flag] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_surfel_gpu.py"), os.path.join(root, "tests", "test_clutter_gpu.py"),
-                        "-k", "batched or full_size or grows or resident_sequence or snapshot or outgrows or dense_in_view or keyframe_every or compaction"],
+                        "-k", "batched or full_size or grows or resident_sequence or snapshot or outgrows or dense_in_view or keyframe_every or compaction or wide_rgb"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.parametrize("n,shares,tail_heavy,same_view", [
+    (20000, (0.3, 0.2, 0.1), False, False), (5000, (0.01, 0.02, 0.9), False, False), (30000, (0.5, 0.4, 0.3), True, False),
+    (9000, (0.004, 0.0, 0.01), False, False), (4097, (1.0, 0.0, 0.0), False, False), (40000, (0.0005, 0.6, 0.0005), True, False),
+    (9000, (0.004, 0.002, 0.01), False, True), (5000, (0.03, 0.02, 0.01), True, True), (70000, (0.003, 0.0036, 0.0001), True, True), (3000, (0.08, 0.08, 0.08), True, True)])
+def test_batched_compaction_patterns(oracle, n, shares, tail_heavy, same_view):
+    """Deletions that fall due at the SECOND, THIRD and FOURTH keyframe of one batched call (stale surfels: ref - lastUpdate > 5 with fewer than five
+    updates), in controlled amounts: a handful (the hand-over list), thousands (listed sub-block by sub-block), nearly everything, concentrated at
+    the end of the array (relay holes inside the tail), with many or hardly any new surfels to refill the holes.  In the default build this is the two-kernel chain; under MSL_SF_MERGED=1 / MSL_SF_OVERLAP=1
+    (the child-process test above) the same keyframes go through the compaction wave of the merged launch / the second stream."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    rng = np.random.default_rng(n)
+    m = synth.surfel_map(n, ref=0, seed=n % 97, min_update_times=5).astype(SURFEL_DTYPE)
+    m["pz"] += 100.0                      # out of range: the fusion itself touches nothing, only the stale rule and the compaction act
+    m["lastUpdate"] = 9
+    u = rng.random(n)
+    if tail_heavy:
+        u = np.sort(u)[::-1].copy()       # the surfels that go first sit at the end of the array
+    lo = 0.0
+    for f, sh in enumerate(shares):       # keyframe f + 1 (ref 11 + f) deletes the surfels whose lastUpdate is 5 + f
+        sel = (u >= lo) & (u < lo + sh)
+        m["lastUpdate"][sel] = 5 + f; m["updateTimes"][sel] = 1 + (f % 3)
+        lo += sh
+    g.set_batch_capacity(4)
+    g.map_reserve(2 * n + 40000)
+    g.map_upload(m); o.map_set(m)
+    # views 15 degrees apart: every keyframe also spawns > 1000 new surfels (K > D for small D); the same view four times: after the first
+    # keyframe hardly any (D > K: leftover holes, tail moves -- with D <= 256 through the register-resident list of the compaction wave)
+    frames = [synth.surfel_frame(0 if same_view else 30 * k) for k in range(4)]
+    refs = [10, 11, 12, 13]
+    g.fuse_resident_batch(refs, np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]), [f[3] for f in frames])
+    for k, f in enumerate(frames):
+        o.fuse_map(refs[k], f[0], f[1], f[2], f[3])
+    mo = o.map_get()
+    assert_surfels_close(g.map_download(), mo, f"map after the batch ({n}, {shares})")
+    c = g.counters()
+    assert c["n_live_after"] == len(mo)
+    # and the handle keeps working: a second batch on the compacted map
+    g.fuse_resident_batch([14, 15, 16], np.stack([f[0] for f in frames[:3]]), np.stack([f[1] for f in frames[:3]]), np.stack([f[2] for f in frames[:3]]), [f[3] for f in frames[:3]])
+    for k, f in enumerate(frames[:3]):
+        o.fuse_map(14 + k, f[0], f[1], f[2], f[3])
+    assert_surfels_close(g.map_download(), o.map_get(), "second batch")
+    g.close()
