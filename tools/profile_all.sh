@@ -25,5 +25,8 @@ python bench.py --map-order random --cpu-frames 0 --steps 8 > gpurun_out/bench_$
 python bench.py --sequences-per-gpu 2 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_two_sequences.json 2> gpurun_out/bench_${TAG}_two_sequences.err
 python bench.py --config 3 --map sparse --cpu-frames 0 --steps 8 > gpurun_out/bench_${TAG}_config3_sparse.json 2> gpurun_out/bench_${TAG}_config3_sparse.err
 MSL_PEAC_CLUSTER=device python bench.py --config 4 --cpu-frames 0 --steps 4 --no-breakdown > gpurun_out/bench_${TAG}_config4_device_cluster.json 2> gpurun_out/bench_${TAG}_config4_device_cluster.err
+# round 4: the opt-in merged launch (one wave compacts keyframe j - 1 inside keyframe j's fuse launch), SurfelFusion alone on both maps
+MSL_SF_MERGED=1 python bench.py --config 3 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_merged.json 2> gpurun_out/bench_${TAG}_config3_merged.err
+MSL_SF_MERGED=1 python bench.py --config 3 --map sparse --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_sparse_merged.json 2> gpurun_out/bench_${TAG}_config3_sparse_merged.err
 ls gpurun_out/prof_$TAG gpurun_out/pmc_$TAG | head -20
 for f in gpurun_out/bench_$TAG*.json; do echo $f; tail -c 300 $f; echo; done
