@@ -232,6 +232,32 @@ def test_1280x960_sequence(oracle):
     g.close()
 
 
+def test_1280x960_batched_keyframes(oracle):
+    """Five 1280x960 keyframes in ONE batched call on a young map (so that hundreds of seeds spawn per keyframe and stale surfels fall due inside the
+    call): k_compact's 19 200-seed flag scan in the default build; under MSL_SF_MERGED=1 (the child-process test below) the compaction wave's
+    multi-trip flag loop (5 120 seeds per trip), its scanned listing of many new surfels and its register-kept hand-over list."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    intr = {k: v * 2 for k, v in synth.TUM1.items()}
+    g, o = _mk(intr, 1280, 960)
+    g.set_batch_capacity(5)
+    m = synth.surfel_map(40000, ref=0, seed=5, min_update_times=1).astype(SURFEL_DTYPE)
+    m["lastUpdate"][::7] = -8          # stale with few updates: deleted by the first keyframes of the call
+    m["updateTimes"][::7] = 2
+    g.map_reserve(300000)
+    g.map_upload(m)
+    o.map_set(m)
+    frames = [synth.surfel_frame(k, 1280, 960, intr=intr, variant="B" if k == 2 else "A") for k in range(5)]
+    for k, (gray, depth, member, pose) in enumerate(frames):
+        o.fuse_map(k, gray, depth, member, pose)
+    g.fuse_resident_batch(list(range(5)), np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]),
+                          [f[3] for f in frames])
+    assert_surfels_close(g.map_download(), o.map_get(), "1280x960 map after a batched call")
+    assert np.array_equal(g.debug_index(), o.index())
+    t = g.debug_ctr()                  # running totals: [8] new, [9] deleted
+    assert t[8] > 500 and t[9] > 1000, t
+    g.close()
+
+
 def test_div100_exact():
     """The division-free x/100.0 used by the cost kernel is the correctly rounded quotient (bit-exact vs IEEE divide)."""
     from manhattanslam_amd import lib
