@@ -1227,14 +1227,15 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 // k_fuse (:167-283): ONE WAVE per sub-block of 256 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever a
 // SIMD has a free slot and registers -- next to the LDS-heavy frame-batched kernels the former 2 KB workgroups waited for LDS
 // (kb_seed_plane leaves 4 KB of a CU's 160 KB free) and k_fuse took 20 us in the timed region against 16 us alone.
-//   Phase A (streaming): a lane owns 4 CONSECUTIVE surfels = five 16-byte loads of the 20-byte hot records.  Stale / deleted / out of
-//     range / out of image surfels (~75 %) finish here; the in-view ones need ONE 8-byte gather each ({depth, superpixel index} texel
-//     written by kb_seed_plane) for the occlusion test.  The four gathers of a lane leave together (branch-free, clamped addresses).
-//   Hand-over inside the wave: survivor number s (rank by (k, lane)) goes to lane s % 64, round s / 64, with one ds_permute_b32 per k --
-//     a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining lanes, so every k is a
-//     permutation of the 64 lanes and no two lanes ever target the same destination.
-//   Phase B (gathers): per round one survivor per lane; its hot record (just streamed: cache hit), 32-byte cold record and 48-byte
-//     FuseRec are requested together, so <= 64 survivors per sub-block cost one round trip.
+//   Phase A (streaming): lane l owns the surfels l, 64 + l, 128 + l, 192 + l of the sub-block (four 20-byte hot records; a load instruction
+//     covers 64 consecutive records).  Stale / deleted / out of range / out of image surfels finish here; the in-view ones need ONE 8-byte
+//     gather each ({depth, superpixel index} texel written by kb_seed_plane) for the occlusion test.  The four gathers of a lane leave
+//     together (branch-free, clamped addresses).
+//   Hand-over inside the wave: survivor number s (rank by (k, lane) = array order) goes to lane s % 64, round s / 64, with one
+//     ds_permute_b32 per k -- a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining
+//     lanes, so every k is a permutation of the 64 lanes and no two lanes ever target the same destination.
+//   Phase B (gathers): per round one survivor per lane, neighbouring lanes = neighbouring surfels; its hot record (just streamed: cache
+//     hit), 32-byte cold record and 48-byte FuseRec are requested together, so <= 64 survivors per sub-block cost one round trip.
 // Deleted slots are handed to k_compact in delU (one atomic per wave that deleted something -- a handful per keyframe); per-sub-block
 // deleted / updated counts go to blockSums / blockUpd with plain stores.
 // The sub-block -> wave mapping uses the HOST's upper bound of the live count (nSubGrid), so the first loads do not wait for ctr[0].
@@ -1341,36 +1342,36 @@ __device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameD
         } else if (mode == 1) {
             prevDeleted = P.prevBlockSums[sb];   // requested together with the hot records (the few unsafe sub-blocks waste their loads)
         }
-        const long long c0 = sb * SUB_ITEMS, i0 = c0 + 4 * lane;
-        uint4 q[5];
-        {
-            const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);   // 4 hot records = 80 contiguous bytes
-            if (coh) {
+        const long long c0 = sb * SUB_ITEMS;
+        // lane l owns records l, 64 + l, 128 + l, 192 + l of the sub-block: the survivors' rank order (k, lane) is then the array order, so
+        // neighbouring lanes of phase B work on neighbouring records and their gathers and stores share cache lines (round 4: with four
+        // CONSECUTIVE records per lane -- five aligned 16-byte loads -- rank neighbours were 4 records apart and every lane of phase B
+        // touched lines of its own: 8 L2 requests per fused surfel; k_fuse 22.5 -> 17.7 us on the dense map)
+#define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
+        HotRec hq[4];
 #pragma unroll
-                for (int e = 0; e < 5; e++) q[e] = ld_agent16(hp + e);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 5; e++) q[e] = hp[e];
-            }
-        }
+        for (int k = 0; k < 4; k++) hq[k] = ld_hot(M, c0 + REC_LOCAL(k), coh);
         if (MERGED && prevDeleted) {   // a sub-block with a hole: the compaction may put a surfel there -- wait for it and load again, past the L2
             if (!wait_compaction()) return;
             cohVar = true;
-            const uint4 *hp = reinterpret_cast<const uint4 *>(M.hot + i0);
 #pragma unroll
-            for (int e = 0; e < 5; e++) q[e] = ld_agent16(hp + e);
+            for (int k = 0; k < 4; k++) hq[k] = ld_hot(M, c0 + REC_LOCAL(k), true);
             prevDeleted = 0;
         }
         if (prevDeleted) continue;   // mode 1: compaction j - 1 puts a surfel into this sub-block; the mode-2 launch fuses it
         const long long n = (mode == 1 || (MERGED && !coh)) ? nBefore : (coh ? __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : P.ctr[0]);
-        const unsigned w[20] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y,
-                                q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w};
+        unsigned w[20];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            w[5 * k] = __float_as_uint(hq[k].px); w[5 * k + 1] = __float_as_uint(hq[k].py); w[5 * k + 2] = __float_as_uint(hq[k].pz);
+            w[5 * k + 3] = (unsigned)hq[k].updateTimes; w[5 * k + 4] = (unsigned)hq[k].lastUpdate;
+        }
         int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
         float pzv[4];
         unsigned offT[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const long long i = i0 + k;
+            const long long i = c0 + REC_LOCAL(k);
             const float x = __uint_as_float(w[5 * k]), y = __uint_as_float(w[5 * k + 1]), z = __uint_as_float(w[5 * k + 2]);
             const int ut = (int)w[5 * k + 3], lu = (int)w[5 * k + 4];
             float pc[4];
@@ -1402,7 +1403,7 @@ __device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameD
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
-            if (state[k] == 1 || occluded) M.hot[i0 + k].updateTimes = 0;
+            if (state[k] == 1 || occluded) M.hot[c0 + REC_LOCAL(k)].updateTimes = 0;
             del[k] = state[k] == 1 || state[k] == 2 || occluded;
             surv[k] = state[k] == 3 && !occluded;
             mdel[k] = __ballot(del[k]);
@@ -1416,7 +1417,7 @@ __device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameD
             if (lane == 0) base = atomicAdd(P.delUCount, cntDel);
             base = __builtin_amdgcn_readfirstlane(base);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, i0 + k); base += (unsigned)__popcll(mdel[k]); }
+            for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, c0 + REC_LOCAL(k)); base += (unsigned)__popcll(mdel[k]); }
         }
         // ---- survivors -> (round, lane): one push per k.  word = local index (4 lane + k), valid bit, superpixel << 16 ----
         unsigned rcv[4], bk[4];
@@ -1426,7 +1427,7 @@ __device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameD
             const unsigned long long m = __ballot(surv[k]);
             const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
             const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
-            const unsigned payload = surv[k] ? ((4u * lane + (unsigned)k) | 0x100u | (tx[k].y << 16)) : 0u;
+            const unsigned payload = surv[k] ? (REC_LOCAL(k) | 0x100u | (tx[k].y << 16)) : 0u;
             rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
             bk[k] = total;
             total += c;
