@@ -1315,7 +1315,17 @@ __device__ __forceinline__ void fuse_body(const SfDev &P, int slot, const FrameD
         }
         return true;
     };
-    for (long long sb = (long long)G - 1 - (long long)waveIdx;; sb += G) {
+    // Workgroups are dispatched round-robin over the 8 XCDs: give each XCD runs of FUSE_CHUNK consecutive sub-blocks (neighbouring surfels
+    // project to neighbouring pixels, so an XCD's L2 fetches a part of the texel map instead of all of it; small enough runs keep the XCDs
+    // balanced -- whole eighths of the map were 2 x slower).  Dense map: k_fuse 17.4 -> 17.0 us.
+    constexpr unsigned FUSE_CHUNK = 16;
+    long long lin = waveIdx;
+    {
+        constexpr unsigned T = 8u * FUSE_CHUNK;
+        const unsigned full = ((unsigned)G / T) * T;
+        if (waveIdx < full) { const unsigned grp = waveIdx / T, r = waveIdx % T; lin = (long long)grp * T + (r & 7u) * FUSE_CHUNK + (r >> 3); }
+    }
+    for (long long sb = (long long)G - 1 - lin;; sb += G) {
 #ifdef MSL_FUSE_STAMPS   // instrumented experiment builds (tools/fuse_stamps.py): 100 MHz device-clock stamps of every wave in srcOf[]
         const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
