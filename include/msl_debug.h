@@ -64,6 +64,10 @@ MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n);
 
 #define MSL_SF_NKERNELS 12
 MSL_API int msl_sf_profile_enable(msl_sf *h, int mode);
+/* Sampling for the per-dispatch event pairs: only every stride-th launch of a timed kernel carries events (default 1 = every launch).  A
+ * dispatch that carries events costs the stream ~0.3 us; bench.py times every 5th k_fuse launch of its timed region (a stride coprime with the
+ * 32 keyframes of a call, so that every position of the chain is sampled equally). */
+MSL_API int msl_sf_profile_stride(msl_sf *h, int stride);
 MSL_API int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches);
 MSL_API const char *msl_sf_kernel_name(int k);
 

@@ -105,6 +105,7 @@ SIGNATURES = {
     "msl_debug_peac_mse": (_i, [_vp, _sz, _i, _vp]),
     "msl_debug_peac_cluster_on_device": (_i, [_i]),
     "msl_sf_profile_enable": (_i, [_vp, _i]),
+    "msl_sf_profile_stride": (_i, [_vp, _i]),
     "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),
     "msl_sf_kernel_name": (C.c_char_p, [_i]),
 }

@@ -33,6 +33,8 @@ int bind_device(int device);  // hipSetDevice + gfx950 check; returns msl_status
 struct KernelProfiler {
     bool on = false;
     unsigned mask = 0xFFFFFFFFu;  // bit k set = kernel id k is timed
+    int stride = 1;               // kernel_pair(): every stride-th launch of a kernel id carries events (sampling keeps the instrumented run close to the plain one)
+    unsigned tick[16] = {0};
     bool open_ = false;
     int nk = 0;
     float ms[16] = {0};
@@ -46,7 +48,7 @@ struct KernelProfiler {
     // (the events then carry the dispatch's own start/end timestamps), or false when kernel k is not being timed.
     bool kernel_pair(int k, hipEvent_t *a, hipEvent_t *b);
     void drain();  // requires the stream to be idle
-    void set_mode(int m) { on = m != 0; mask = (unsigned)m; for (int i = 0; i < 16; i++) { ms[i] = 0; launches[i] = 0; } }
+    void set_mode(int m) { on = m != 0; mask = (unsigned)m; for (int i = 0; i < 16; i++) { ms[i] = 0; launches[i] = 0; tick[i] = 0; } }
     void destroy();
 };
 

@@ -53,6 +53,7 @@ void KernelProfiler::end(hipStream_t s) {
 }
 bool KernelProfiler::kernel_pair(int k, hipEvent_t *a, hipEvent_t *b) {
     if (!on || !((mask >> k) & 1u)) return false;
+    if (stride > 1 && (tick[k & 15]++ % (unsigned)stride) != 0) return false;
     if (npairs == cap) {
         int ncap = cap ? cap * 2 : 256;
         Pair *np = (Pair *)realloc(pairs, sizeof(Pair) * ncap);

@@ -3276,6 +3276,11 @@ int msl_sf_profile_enable(msl_sf *h, int on) {
     h->prof.set_mode(on);
     return MSL_OK;
 }
+int msl_sf_profile_stride(msl_sf *h, int stride) {
+    if (!h || stride < 1) return MSL_ERR_INVALID;
+    h->prof.stride = stride;
+    return MSL_OK;
+}
 int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));

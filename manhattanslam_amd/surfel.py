@@ -172,6 +172,9 @@ class SurfelFusion:
         check(lib.msl_sf_debug_index(self._h, ptr(out)))
         return out
 
+    def profile_stride(self, stride=1):
+        check(lib.msl_sf_profile_stride(self._h, int(stride)))
+
     def profile_enable(self, mode=-1):
         check(lib.msl_sf_profile_enable(self._h, int(mode)))
 
