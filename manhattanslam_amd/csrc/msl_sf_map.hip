@@ -1,0 +1,1194 @@
+// msl_sf_map.hip -- map stage of the surfel fusion for gfx950 (MI355X): fusion, new surfels, compaction.
+//
+// Replaces fuseSurfelsKernel (reference src/SurfelFusion.cpp:167-283), initializeSurfels (:285-331) and the slot refill / tail
+// compaction of SurfelMapping::fuseMap (src/SurfelMapping.cpp:366-391) on a device-resident map of 16-byte hot + 32-byte cold records.
+//
+// Two ways through a keyframe (msl_surfel.hip decides):
+//   classic  : k_fuse<false> -> k_compact           two dependent launches per keyframe; the array is in the reference's order after
+//                                                   every keyframe (single keyframes, the host-vector drop-in, the first keyframe after
+//                                                   the map was replaced from outside)
+//   deferred : k_fuse<true> x F -> k_defer_tail -> k_replay -> k_gather -> k_scatter      (round 5) ONE launch per keyframe.
+//              fuseSurfelsKernel treats every surfel independently of its array position, so inside a window of F <= 32 keyframes nothing
+//              is moved: a keyframe's new surfels are appended physically behind the array (by the first waves of the NEXT keyframe's fuse
+//              launch, which fuse them right away), deleted slots stay as holes and are logged.  The window's placements and tail moves
+//              (new surfel k -> k-th largest hole else appended; back-to-front refill, SurfelMapping.cpp:372-390) are then replayed
+//              SYMBOLICALLY by one wave over the logs -- virtual position <-> element, only for the few positions that differ from the
+//              identity -- and applied as one gather + scatter, which leaves the array exactly as F classic keyframes would have.
+//
+// HBM-bound integer/float streaming; no MFMA.  Every float expression keeps the reference's evaluation order and float/double
+// promotions; compiled with -ffp-contract=off.
+
+#include "msl_sf.h"
+
+using namespace msl;
+using namespace msl::sf;
+
+namespace {
+
+// ---- record accessors ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ void set_wide_flag(const MapSoA &M, unsigned long long bit) { atomicOr(reinterpret_cast<unsigned long long *>(M.wideFlag), bit); }
+// updateTimes / lastUpdate of a record whose packed word is tl (the side array only for HOT_WIDE: rare)
+__device__ __forceinline__ void tl_unpack(const MapSoA &M, long long i, unsigned tl, int &ut, int &lu) {
+    ut = (int)(tl >> 20); lu = (int)(tl & 0xFFFFFu);
+    if (tl & 0x80000000u) {
+        if (tl == HOT_WIDE) { ut = M.utlWide[2 * i]; lu = M.utlWide[2 * i + 1]; }
+        else { ut = 0; lu = 0; }   // HOT_HOLE
+    }
+}
+__device__ __forceinline__ HotRec hot_load(const MapSoA &M, long long i) {
+    const HotPk p = M.hot[i];
+    HotRec h; h.px = p.px; h.py = p.py; h.pz = p.pz;
+    tl_unpack(M, i, p.tl, h.updateTimes, h.lastUpdate);
+    return h;
+}
+__device__ __forceinline__ unsigned tl_store_word(const MapSoA &M, long long i, int ut, int lu) {   // the packed word; writes the side array when it does not fit
+    if (tl_fits(ut, lu)) return tl_pack(ut, lu);
+    M.utlWide[2 * i] = ut; M.utlWide[2 * i + 1] = lu;
+    set_wide_flag(M, 2ull);
+    return HOT_WIDE;
+}
+__device__ __forceinline__ void hot_store(const MapSoA &M, long long i, const HotRec &h) {
+    HotPk p; p.px = h.px; p.py = h.py; p.pz = h.pz; p.tl = tl_store_word(M, i, h.updateTimes, h.lastUpdate);
+    M.hot[i] = p;
+}
+// updateTimes = 0 (:201, :229): lastUpdate stays what it was (the host-vector drop-in hands the record back)
+__device__ __forceinline__ void hot_mark_deleted(const MapSoA &M, long long i, unsigned tl) {
+    if (tl == HOT_WIDE) M.utlWide[2 * i] = 0;
+    else M.hot[i].tl = tl & 0xFFFFFu;
+}
+__device__ __forceinline__ bool hot_is_deleted(const MapSoA &M, long long i) {
+    const unsigned tl = M.hot[i].tl;
+    return tl == HOT_WIDE ? M.utlWide[2 * i] == 0 : (tl == HOT_HOLE || (tl >> 20) == 0);
+}
+
+__device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
+    HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
+    ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.weight = e.weight; c._spare = 0;
+    if (rgb_fits(e.r, e.g, e.b)) c.rgbf = rgb_pack(e.r, e.g, e.b);
+    else { c.rgbf = COLD_WIDE; set_wide_flag(M, 1ull); M.rgbWide[3 * i] = e.r; M.rgbWide[3 * i + 1] = e.g; M.rgbWide[3 * i + 2] = e.b; }
+    hot_store(M, i, h); M.cold[i] = c;
+}
+__device__ __forceinline__ void load_surfel(const MapSoA &M, long long i, const HotRec &h, msl_surfel &e) {
+    const ColdRec c = M.cold[i];
+    e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz; e.size = c.size; e.color = c.color;
+    if (c.rgbf & COLD_WIDE) { e.r = M.rgbWide[3 * i]; e.g = M.rgbWide[3 * i + 1]; e.b = M.rgbWide[3 * i + 2]; }
+    else { e.r = (int)(c.rgbf & 255u); e.g = (int)((c.rgbf >> 8) & 255u); e.b = (int)((c.rgbf >> 16) & 255u); }
+    e.weight = c.weight; e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
+}
+__device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
+    const ColdRec c = M.cold[src];
+    const HotPk p = M.hot[src];
+    M.hot[dst] = p; M.cold[dst] = c;
+    if (p.tl == HOT_WIDE) { M.utlWide[2 * dst] = M.utlWide[2 * src]; M.utlWide[2 * dst + 1] = M.utlWide[2 * src + 1]; }
+    if (c.rgbf & COLD_WIDE) { M.rgbWide[3 * dst] = M.rgbWide[3 * src]; M.rgbWide[3 * dst + 1] = M.rgbWide[3 * src + 1]; M.rgbWide[3 * dst + 2] = M.rgbWide[3 * src + 2]; }
+}
+
+// "Last workgroup continues" hand-off (cdna_hip_programming.md G16): every workgroup publishes its global stores with an
+// agent-scope release, then takes a ticket; the one that draws the last ticket acquires and carries on with the next
+// stage inside the same launch, saving a dependent kernel boundary (~5 us each on this latency-critical chain).
+__device__ __forceinline__ bool last_workgroup(unsigned *ticket, unsigned *s_flag) {
+    // Everything the continuing workgroup reads from this launch is stored write-through (agent-scope atomic stores /
+    // RMW atomics) and read back with agent-scope loads, so no L2 write-back fence is needed.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(ticket, 1u);
+        *s_flag = (t == gridDim.x - 1) ? 1u : 0u;
+        if (*s_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset for the next launch
+    }
+    __syncthreads();
+    return *s_flag != 0;
+}
+
+// int(projectU + 0.5) of :204-205 (a double addition, truncation towards zero) without double arithmetic: for u >= 1/2 it equals
+// floor(u) + (u - floor(u) >= 1/2) -- floor and the difference are exact in float --, and for smaller u (or NaN) both expressions are
+// <= 0, which the image test (pUInt < 1) rejects whatever the exact value is; the clamp keeps the conversion defined for huge / infinite u.
+__device__ __forceinline__ int round_half_up_pixel(float u) {
+    const float c = fminf(fmaxf(u, -4.0f), 1.0e6f);   // NaN -> -4
+    const float f = floorf(c);
+    return (int)f + ((c - f) >= 0.5f ? 1 : 0);
+}
+__device__ __forceinline__ unsigned lane_rank(unsigned long long m) {   // number of set bits of m below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// 16-byte stores of the records phase B rewrites.  MSL_FUSE_ST: 0 = plain (the lines stay dirty in the XCD's L2 until the kernel ends),
+// 1 = sc1 (write-through: nothing left to write back at the kernel boundary, the line leaves the L2), 2 = nt.  A/B in DESIGN.md section 6.
+#ifndef MSL_FUSE_ST
+#define MSL_FUSE_ST 0
+#endif
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16(void *p, u32x4 v) {
+#if MSL_FUSE_ST == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif MSL_FUSE_ST == 2
+    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+    *reinterpret_cast<u32x4 *>(p) = v;
+#endif
+}
+
+// What k_fuse reads of the handle and of the keyframe: slim copies of SfDev / FrameDev with the slot offsets folded in on the host.  The
+// whole structs are ~150 dwords of kernel arguments = scalar registers the compiler loads up front and then spills around the hot loop;
+// what only the few frontier waves of a deferred launch need (the previous keyframe's candidate arrays) stays in memory (DeferCtl::emit).
+struct FuseFrame {
+    float inv[12];   // rows 0..2 of pose.inverse(), inv[3 c + r] = invPose[4 c + r] (the fourth row is never used)
+    float rot[9];    // rotation of the pose, rot[3 c + r] = pose[4 c + r]
+    int ref;
+};
+struct FuseArgs {
+    int W, H, nseeds, kf;          // kf: keyframe number inside a deferred window (its launch materialises the new surfels of kf - 1 first)
+    int prevSlot, _pad;            // superpixel slot of keyframe kf - 1, counted from the first slot of the handle (DeferCtl holds the array bases)
+    float fx, fy, cx, cy, fuseFar, fuseNear;
+    const uint2 *tex; const float4 *fuseRec; uint8_t *fused;   // this keyframe's slot
+    MapSoA map;
+    unsigned long long cap;
+    long long *ctr;
+    unsigned *blockSums;           // classic only (deleted slots per sub-block)
+    unsigned *blockUpd;            // updated surfels per sub-block (deferred: the keyframe's slice)
+    unsigned *delOut;              // classic: delU[LIST_D], the hand-over list of k_compact; deferred: the window's deletion log
+    unsigned *delUCount;           // classic only
+    DeferCtl *dc;                  // deferred only
+};
+__host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
+    FuseArgs A;
+    A.W = P.W; A.H = P.H; A.nseeds = P.nseeds; A.kf = P.kf; A.prevSlot = P.prevSlotAbs; A._pad = 0;
+    A.fx = P.fx; A.fy = P.fy; A.cx = P.cx; A.cy = P.cy; A.fuseFar = P.fuseFar; A.fuseNear = P.fuseNear;
+    A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
+    A.map = P.map; A.cap = P.cap; A.ctr = P.ctr;
+    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd; A.delOut = deferred ? P.delList : P.delU; A.delUCount = P.delUCount; A.dc = P.dc;
+    return A;
+}
+__host__ inline FuseFrame fuse_frame(const FrameDev &F) {
+    FuseFrame f;
+    for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) f.inv[3 * c + r] = F.invPose[4 * c + r];
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) f.rot[3 * c + r] = F.pose[4 * c + r];
+    f.ref = F.ref;
+    return f;
+}
+// mul4 / mul3 of msl_sf.h on the packed rows: the same products and the same association
+__device__ __forceinline__ void mul4r(const float *m, float v0, float v1, float v2, float v3, float out[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[r] = ((m[r] * v0 + m[3 + r] * v1) + m[6 + r] * v2) + m[9 + r] * v3;
+}
+__device__ __forceinline__ void mul3r(const float *m, float v0, float v1, float v2, float out[3]) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) out[r] = (m[r] * v0 + m[3 + r] * v1) + m[6 + r] * v2;
+}
+
+// ---- new surfels of the previous keyframe, materialised by the fuse launch that follows it (deferred compaction) ----------------------
+// initializeSurfels (:285-331): every seed whose candidate is valid and that no fusion consumed spawns a surfel, in seed order.  New surfel
+// k of the keyframe before (slot P.prevSlot) goes to the physical slot E0 + k (E0 = the extent that keyframe's fuse launch worked on).  A "frontier"
+// wave -- one whose sub-block reaches beyond E0 -- scans the flag bytes of the whole lattice (lane l owns the `per` consecutive seeds from
+// l * per on; candOk / fused hold 0 / 1, zero padding behind the lattice), and writes the records that fall into ITS sub-block; it then fuses them
+// like any others.  Returns K, the keyframe's number of new surfels.  All 64 lanes must call it.
+__device__ __forceinline__ unsigned spawn_word(unsigned cw, unsigned fw) { return cw & ~fw & 0x01010101u; }
+__device__ __forceinline__ unsigned emit_pending(const FuseArgs &P, long long E0, long long sb, unsigned lane) {
+    const DeferCtl *dc = P.dc;
+    const int fs = dc->flagStride;
+    const uint8_t *candOk = dc->candOk + (size_t)P.prevSlot * fs, *fusedP = dc->fused + (size_t)P.prevSlot * fs;   // of keyframe kf - 1
+    const int per = fs >> 6, nch = per >> 4;   // seeds per lane (a multiple of 16), 16-byte words per lane
+    unsigned cnt = 0;
+    {
+        const uint4 *cq = reinterpret_cast<const uint4 *>(candOk + (size_t)lane * per), *fq = reinterpret_cast<const uint4 *>(fusedP + (size_t)lane * per);
+        for (int c = 0; c < nch; c += 3) {   // three words of each array per trip: 24 transient registers
+            uint4 a[3], b[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) { const int cc = min(c + q, nch - 1); a[q] = cq[cc]; b[q] = fq[cc]; }
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (c + q < nch)
+                    cnt += (unsigned)(__popc(spawn_word(a[q].x, b[q].x)) + __popc(spawn_word(a[q].y, b[q].y)) + __popc(spawn_word(a[q].z, b[q].z)) + __popc(spawn_word(a[q].w, b[q].w)));
+        }
+    }
+    const unsigned incl = wave_incl_scan(cnt), excl = incl - cnt;
+    const unsigned K = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    if (K == 0) return 0;
+    if ((sb + 1) * SUB_ITEMS <= E0 || sb * SUB_ITEMS >= E0 + (long long)K) return K;   // none of them lands in this sub-block
+    const msl_surfel *cand = dc->cand + (size_t)P.prevSlot * P.nseeds;
+#pragma unroll 1
+    for (int j = 0; j < SUB_ITEMS / 64; j++) {
+        const long long i = sb * SUB_ITEMS + 64 * j + lane, kS = i - E0;
+        const bool on = kS >= 0 && kS < (long long)K;
+        const unsigned k = on ? (unsigned)kS : 0u;
+        // owner: the last lane whose exclusive prefix is <= k (its inclusive prefix then exceeds k)
+        unsigned lo = 0, hi = 63, eLo = 0;
+#pragma unroll
+        for (int s = 0; s < 6; s++) {
+            const unsigned mid = (lo + hi + 1) >> 1;
+            const unsigned e = (unsigned)__builtin_amdgcn_ds_bpermute((int)(mid * 4u), (int)excl);
+            if (e <= k) { lo = mid; eLo = e; } else hi = mid - 1;
+        }
+        unsigned r = k - eLo;   // the r-th spawning seed of lane `lo`'s range
+        int seed = -1;
+        const uint4 *oc = reinterpret_cast<const uint4 *>(candOk + (size_t)lo * per), *of = reinterpret_cast<const uint4 *>(fusedP + (size_t)lo * per);
+        for (int c = 0; c < nch; c++) {
+            const uint4 a = oc[c], b = of[c];
+            const unsigned w[4] = {spawn_word(a.x, b.x), spawn_word(a.y, b.y), spawn_word(a.z, b.z), spawn_word(a.w, b.w)};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const unsigned pc = (unsigned)__popc(w[q]);
+                if (seed < 0) {
+                    if (r < pc) {
+                        unsigned m = w[q];
+                        for (unsigned t = 0; t < r; t++) m &= m - 1;
+                        seed = (int)lo * per + 16 * c + 4 * q + (__builtin_ctz(m) >> 3);
+                    } else r -= pc;
+                }
+            }
+        }
+        if (on && seed >= 0) {
+            if ((unsigned long long)i < P.cap) store_surfel(P.map, i, cand[seed]);
+            else P.ctr[5] = 20;   // capacity exceeded (the host reserves nseeds slots per keyframe: never happens)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave reads these records back right away
+    return K;
+}
+
+// k_fuse (:167-283): ONE WAVE per sub-block of 256 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever a
+// SIMD has a free slot and registers -- next to the LDS-heavy frame-batched kernels workgroups with LDS waited for it.
+//   Phase A (streaming): lane l owns the surfels l, 64 + l, 128 + l, 192 + l of the sub-block (four 16-byte hot records; a load instruction
+//     covers 64 consecutive records = 1 KB).  Stale / deleted / out of range / out of image surfels finish here; the in-view ones need ONE
+//     8-byte gather each ({depth, superpixel index} texel written by kb_seed_plane) for the occlusion test.  The four gathers of a lane leave
+//     together (branch-free, clamped addresses).
+//   Hand-over inside the wave: survivor number s (rank by (k, lane) = array order) goes to lane s % 64, round s / 64, with one
+//     ds_permute_b32 per k -- a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining
+//     lanes, so every k is a permutation of the 64 lanes and no two lanes ever target the same destination.
+//   Phase B (gathers): per round one survivor per lane, neighbouring lanes = neighbouring surfels; its hot record (just streamed: cache
+//     hit), 32-byte cold record and the three 16-byte words of its seed are requested together, so <= 64 survivors per sub-block cost one
+//     round trip.
+// DEFER = false (classic): deleted slots are handed to k_compact in delU (one atomic per wave that deleted something), per-sub-block deleted /
+//   updated counts go to blockSums / blockUpd with plain stores.
+// DEFER = true: deleted slots become HOT_HOLE and go to the window's deletion log; the launch of keyframe kf > 0 first materialises the new
+//   surfels of keyframe kf - 1 behind the array (emit_pending, frontier waves only) and works on the extent that results.
+template <bool DEFER>
+__device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F, int nSubHint, unsigned waveIdx, int G) {
+    const MapSoA &M = P.map;
+    const unsigned lane0 = threadIdx.x;
+    const uint2 *tex = P.tex;
+    const float4 *fuseRec = P.fuseRec;
+    uint8_t *fused = P.fused;
+    const int ref = F.ref;
+    const float cameraF = (float)(((double)fabsf(P.fx) + (double)fabsf(P.fy)) / 2.0);
+    const float halfF = 0.5f * cameraF;   // BASELINE * cameraF (:220), exact
+    // deferred, keyframe kf > 0: E0 = the extent keyframe kf - 1 worked on; its new surfels follow from there
+    const bool pending = DEFER && P.kf > 0;
+    long long E0 = 0;
+    if (pending) E0 = P.dc->ext[P.kf - 1];
+    if (DEFER && !pending && waveIdx == 0 && lane0 == 0) P.dc->ext[0] = P.ctr[0];
+    // Wave g owns sub-block G - 1 - g (the newest surfels -- nearly all in view: most phase-B work -- are dispatched first) and, should the
+    // map have outgrown the grid, G - 1 - g + G, ... (grid-stride; normally one iteration).  The grid covers the host's last KNOWN live count
+    // plus a margin, not its upper bound.  Sub-blocks below nSubHint load at once; above it the wave reads the live count first and leaves if
+    // there is nothing for it.  Capacity is a multiple of 4096 and every sub-block that loads speculatively lies below it.
+    // Workgroups are dispatched round-robin over the 8 XCDs: give each XCD runs of FUSE_CHUNK consecutive sub-blocks (neighbouring surfels
+    // project to neighbouring pixels, so an XCD's L2 fetches a part of the texel map instead of all of it; small enough runs keep the XCDs
+    // balanced -- whole eighths of the map were 2 x slower).
+    constexpr unsigned FUSE_CHUNK = 16;
+    long long lin = waveIdx;
+    {
+        constexpr unsigned T = 8u * FUSE_CHUNK;
+        const unsigned full = ((unsigned)G / T) * T;
+        if (waveIdx < full) { const unsigned grp = waveIdx / T, r = waveIdx % T; lin = (long long)grp * T + (r & 7u) * FUSE_CHUNK + (r >> 3); }
+    }
+    for (long long sb = (long long)G - 1 - lin;; sb += G) {
+        // (the lane number is re-materialised per iteration: values derived from it are then not hoisted out of this -- normally single-trip --
+        // loop and kept in registers / scratch for its whole body)
+        unsigned lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const long long c0 = sb * SUB_ITEMS;
+        long long n = 0;
+        bool frontier = false;
+        if (pending) {
+            if (c0 >= E0 + P.nseeds) return;   // beyond anything keyframe kf - 1 can have spawned
+            frontier = c0 + SUB_ITEMS > E0;
+            if (frontier) {
+                n = E0 + (long long)emit_pending(P, E0, sb, lane);
+                if (sb == (E0 >> 8) && lane == 0) P.dc->ext[P.kf] = n;   // (exactly one sub-block contains E0)
+                if (c0 >= n) return;
+            } else n = E0;   // every record of this sub-block lies below the extent
+        } else if (sb >= nSubHint && c0 >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        // lane l owns records l, 64 + l, 128 + l, 192 + l of the sub-block: the survivors' rank order (k, lane) is then the array order, so
+        // neighbouring lanes of phase B work on neighbouring records and their gathers and stores share cache lines
+#define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
+        HotPk hq[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) hq[k] = M.hot[c0 + REC_LOCAL(k)];
+        if (!pending) n = P.ctr[0];
+        int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
+        float pzv[4];
+        unsigned offT[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const long long i = c0 + REC_LOCAL(k);
+            const float x = hq[k].px, y = hq[k].py, z = hq[k].pz;
+            const unsigned tl = hq[k].tl;
+            int ut = (int)(tl >> 20), lu = (int)(tl & 0xFFFFFu);
+            bool hole = false;
+            if (__builtin_expect(__ballot(tl >> 31) != 0ull, 0)) {   // rare: exact ints in the side array / a slot the window has logged already
+                if (tl == HOT_WIDE) { ut = M.utlWide[2 * i]; lu = M.utlWide[2 * i + 1]; }
+                else if (tl & 0x80000000u) hole = true;
+            }
+            float pc[3];
+            mul4r(F.inv, x, y, z, 1.0f, pc);
+            const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
+            const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+            const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+            const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
+            const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+            int st = 0;
+            if (i < n && !hole) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+            state[k] = st; pzv[k] = pc[2];
+            const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+            offT[k] = (unsigned)(pVc * P.W + pUc);
+        }
+        uint2 tx[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) tx[k] = tex[offT[k]];
+        // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
+        // round trip back into up to four dependent ones
+        asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+        // ---- classification: deletions of phase A, survivors ----
+        bool del[4], surv[4];
+        unsigned long long mdel[4];
+        unsigned cntDel = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
+            del[k] = state[k] == 1 || state[k] == 2 || occluded;
+            if (DEFER) { if (del[k]) M.hot[c0 + REC_LOCAL(k)].tl = HOT_HOLE; }
+            else if (state[k] == 1 || occluded) hot_mark_deleted(M, c0 + REC_LOCAL(k), hq[k].tl);
+            surv[k] = state[k] == 3 && !occluded;
+            mdel[k] = __ballot(del[k]);
+            cntDel += (unsigned)__popcll(mdel[k]);
+        }
+        // deleted slots: classic -> delU (k_compact's fast path), deferred -> the window's log behind the entries of the keyframes before
+        auto list_base = [&](unsigned c) -> unsigned {
+            unsigned base = 0;
+            if (DEFER) {
+                for (int q = 0; q < P.kf; q++) base += P.dc->delCnt[q];
+                unsigned b2 = 0;
+                if (lane == 0) b2 = atomicAdd(&P.dc->delCnt[P.kf], c);
+                base += (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
+            } else {
+                if (lane == 0) base = atomicAdd(P.delUCount, c);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            }
+            return base;
+        };
+        auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {
+            if (d) {
+                const unsigned j = base + lane_rank(m);
+                if (DEFER ? j < P.cap : j < (unsigned)LIST_D) P.delOut[j] = (unsigned)i;
+            }
+        };
+        if (cntDel) {   // rare: a handful of slots per keyframe
+            unsigned base = list_base(cntDel);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, c0 + REC_LOCAL(k)); base += (unsigned)__popcll(mdel[k]); }
+        }
+        // ---- survivors -> (round, lane): one push per k.  word = local index, valid bit, superpixel << 16 ----
+        unsigned rcv[4], bk[4];
+        unsigned total = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(surv[k]);
+            const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
+            const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
+            const unsigned payload = surv[k] ? (REC_LOCAL(k) | 0x100u | (tx[k].y << 16)) : 0u;
+            rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
+            bk[k] = total;
+            total += c;
+        }
+        const unsigned rounds = (total + 63u) >> 6;
+        unsigned nupd = 0, cntDelB = 0;
+        for (unsigned r = 0; r < rounds; r++) {   // one round for <= 64 survivors
+            unsigned item = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned rk = (bk[k] + ((lane - bk[k]) & 63u)) >> 6;   // round of the survivor this lane received from k (if any)
+                if ((rcv[k] & 0x100u) && rk == r) item = rcv[k];
+            }
+            // branch-free loads: a lane without a survivor in this round reads record c0 / seed 0 (valid addresses, one line for all such
+            // lanes) -- conditional loads made the compiler sink the first uses into the load block and wait there
+            const long long i = c0 + (item & 0xFFu);
+            const unsigned sp = item >> 16;
+            const HotPk h = M.hot[i];
+            ColdRec c = M.cold[i];
+            const float4 f0 = fuseRec[sp], f1 = fuseRec[P.nseeds + sp], f2 = fuseRec[2 * (size_t)P.nseeds + sp];
+            // common use of one field per load instruction: all records are in flight together
+            asm volatile("" ::"v"(h.px), "v"(h.tl), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x));
+            bool upd = false, delB = false;
+            if (item && __float_as_uint(f2.w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
+                const float seedDepth = f0.w;
+                const float pz = ((F.inv[2] * h.px + F.inv[5] * h.py) + F.inv[8] * h.pz) + F.inv[11] * 1.0f;   // row 2 of mul4: as in phase A
+                // :220-221 is (float)((double)(pz pz) / (0.5 (double)cameraF) * 4.0).  Both operands of the division are float values (0.5 cameraF
+                // exactly), the multiplication by 4 is exact, and rounding a correctly rounded binary64 quotient of two binary32 numbers to
+                // binary32 gives the correctly rounded binary32 quotient (53 >= 2 * 24 + 2: double rounding is innocuous for division), so one
+                // IEEE float division yields the same bits as the double expression at a third of the instructions.
+                float tolerateDiff = (pz * pz) / halfF * 4.0f;
+                tolerateDiff = tolerateDiff < MIN_TOLERATE_DIFF ? (float)MIN_TOLERATE_DIFF : tolerateDiff;
+                if (!(pz < seedDepth - tolerateDiff) && !(pz > seedDepth + tolerateDiff)) {
+                    float nc[3];
+                    mul3r(F.inv, c.nx, c.ny, c.nz, nc);
+                    const float normDiffCos = nc[0] * f0.x + nc[1] * f0.y + nc[2] * f0.z;
+                    if (normDiffCos < MAX_ANGLE_COS) {
+                        if (DEFER) M.hot[i].tl = HOT_HOLE; else hot_mark_deleted(M, i, h.tl);
+                        delB = true;
+                    } else {
+                        const float oldWeight = c.weight;
+                        const float newWeight = f1.w;                      // getWeight(seed.meanDepth)
+                        const float sumWeight = oldWeight + newWeight;
+                        const float fusedPx = (h.px * oldWeight + newWeight * f1.x) / sumWeight;   // f1.xyz = pose * seed.pos
+                        const float fusedPy = (h.py * oldWeight + newWeight * f1.y) / sumWeight;
+                        const float fusedPz = (h.pz * oldWeight + newWeight * f1.z) / sumWeight;
+                        float fusedNx = nc[0] * oldWeight + newWeight * f0.x;
+                        float fusedNy = nc[1] * oldWeight + newWeight * f0.y;
+                        float fusedNz = nc[2] * oldWeight + newWeight * f0.z;
+                        // :254-257: newNormLength is a double that holds a float (std::sqrt(float)); float /= double is a binary64 division
+                        // of two float values rounded to float = the IEEE float division (same argument as above)
+                        const float newNormLength = sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
+                        fusedNx = fusedNx / newNormLength; fusedNy = fusedNy / newNormLength; fusedNz = fusedNz / newNormLength;
+                        float newNormW[3];
+                        mul3r(F.rot, fusedNx, fusedNy, fusedNz, newNormW);
+                        int ut = (int)(h.tl >> 20);   // (a survivor is never a hole; HOT_WIDE: the side array)
+                        if (__builtin_expect(h.tl == HOT_WIDE, 0)) ut = M.utlWide[2 * i];
+                        const unsigned tlNew = tl_store_word(M, i, ut + 1, ref);   // updateTimes + 1, lastUpdate = reference index (:275-276)
+                        c.rgbf = __float_as_uint(f2.z);                    // r, g, b of the seed (bytes: never COLD_WIDE)
+                        c.nx = newNormW[0]; c.ny = newNormW[1]; c.nz = newNormW[2];
+                        c.weight = sumWeight;
+                        c.color = f2.y;                                    // seed.meanIntensity
+                        const float newSize = f2.x;                        // seed.size * fabs(meanDepth / (cameraF * viewCos))
+                        if (newSize < c.size) c.size = newSize;
+                        u32x4 hv = {__float_as_uint(fusedPx), __float_as_uint(fusedPy), __float_as_uint(fusedPz), tlNew};
+                        u32x4 c0v = {__float_as_uint(c.nx), __float_as_uint(c.ny), __float_as_uint(c.nz), __float_as_uint(c.size)};
+                        u32x4 c1v = {__float_as_uint(c.color), __float_as_uint(c.weight), c.rgbf, c._spare};
+                        st16(M.hot + i, hv);
+                        st16(M.cold + i, c0v);
+                        st16(reinterpret_cast<u32x4 *>(M.cold + i) + 1, c1v);
+                        fused[sp] = 1;
+                        upd = true;
+                    }
+                }
+            }
+            nupd += (unsigned)__popcll(__ballot(upd));
+            const unsigned long long mb = __ballot(delB);
+            if (mb) {   // rare
+                const unsigned cb = (unsigned)__popcll(mb);
+                hand_over(delB, mb, list_base(cb), i);
+                cntDelB += cb;
+            }
+        }
+        if (lane == 0) {
+            if (!DEFER) P.blockSums[sb] = cntDel + cntDelB;
+            P.blockUpd[sb] = nupd;
+        }
+        // (normally) nothing beyond the grid; a deferred launch decides at the head of the loop (the new surfels may reach into the next sub-block)
+        if ((sb + G) * SUB_ITEMS >= (pending ? E0 + (long long)P.nseeds : n)) return;
+    }
+#undef REC_LOCAL
+}
+
+template <bool DEFER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fuse(FuseArgs P, FuseFrame F, int nSubHint) {   // by value: kernarg -> SGPRs; 8 waves / SIMD = 64 VGPRs
+    __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
+    fuse_body<DEFER>(P, F, nSubHint, blockIdx.x, (int)gridDim.x);
+}
+
+constexpr int TAIL_MAX_HOPS = 64;   // relay hops resolved per hole before the literal loop takes over (k_compact)
+
+// =============================================================================================
+// Classic compaction (one launch per keyframe, behind k_fuse<false>)
+// =============================================================================================
+// Resident-map compaction (SurfelMapping.cpp:366-391) with prefix sums.  Deleted slots ascending d_0..d_{D-1};
+// new surfel k -> d_{D-1-k} while any remain, else appended.  If D > K the literal `while` loop (:386-390) moves,
+// at step i = 1..R (R = D-K), the element at position n-i into the i-th largest leftover hole; a hole inside the
+// tail [nFinal, n) only relays what lands in it.  So the a-th smallest leftover hole (< nFinal) finally receives
+// resolve(nFinal + a), resolve(p) = p if p is live, else resolve(n - rank_desc(p)): a short upward chain.
+
+// k_compact: everything after k_fuse in ONE launch.
+//   every workgroup : exclusive scan of the per-chunk deleted counts (each workgroup scans the <= cap/1024 partials itself,
+//                     so there is no inter-workgroup dependency), then lists the deleted slots of its own chunks in
+//                     ascending order (write-through stores);
+//   last workgroup  : initializeSurfels (:285-331) = ordered emission of the seed candidates the fuse step did not consume,
+//                     counters, new surfel k -> k-th largest deleted slot else appended, tail sources resolved and moved.
+// mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
+constexpr int SMALL_D = 512, SMALL_CHUNKS = 48;   // single-workgroup path: few deletions in few chunks
+
+// LDS is kept to ~3.5 KB: on a GPU saturated by the LDS-heavy batched kernels a larger workgroup waits for a CU to drain.
+__global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
+    constexpr int NT = 256, TILE = 4 * NT;
+    __shared__ unsigned s_wave[33];
+    __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
+    __shared__ unsigned s_raw[LIST_D];          // fastest path: k_fuse's unordered hand-over list
+    __shared__ unsigned s_last, s_upd, s_nzChunks, s_base, s_cntChunk;
+    __shared__ unsigned s_nzIdx[SMALL_CHUNKS], s_nzCnt[SMALL_CHUNKS], s_nzSortIdx[SMALL_CHUNKS], s_nzSortCnt[SMALL_CHUNKS];   // sub-blocks with deletions
+    __shared__ int s_fallback;
+    __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
+    // Steady state (k_fuse handed over <= LIST_D deleted slots): workgroup 0 does everything alone; the others leave after one load
+    // instead of fetching the partials and flags as well.
+    if (mode == 0 && blockIdx.x != 0 && *P.delUCount <= LIST_D) return;
+    // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
+    // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
+    const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
+    uint4 bu[4];   // the first 4096 per-workgroup updated counts (arrays are padded by >= 4096 zeroed entries)
+#pragma unroll
+    for (int q = 0; q < 4; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
+    static_assert(LIST_D == NT, "one hand-over entry per thread");
+    const unsigned du = P.delU[threadIdx.x];
+    const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
+    const long long n = P.ctr[0];
+    const bool bad = P.ctr[5] == 20;
+    const uint8_t *candOk = P.candOk + (size_t)slot * P.flagStride, *fused = P.fused + (size_t)slot * P.flagStride;
+    const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
+    const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
+    unsigned cnt = 0;
+    unsigned long long emit = 0, emitHi = 0;   // bit j: seed s0 + j spawns a surfel (emit: j < 64; emitHi: 64 <= j < 128)
+    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
+    const bool aligned4 = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
+    // all flag words of the thread in ONE round trip: 8 words each for <= 32 seeds per thread (640 x 480: 19), 24 words for <= 96 (1280 x 960: 76 --
+    // round 3 walked the seeds beyond the 64th one by one, two dependent byte loads each, and the kernel took 30 us at that size)
+    auto flags_in_one_trip = [&](auto nqTag) {
+        constexpr int NQ = decltype(nqTag)::value;
+        unsigned cw[NQ], fw[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            const int i = s0 + 4 * q;
+            const bool in = 4 * q < per && i < s1;
+            cw[q] = in ? *reinterpret_cast<const unsigned *>(candOk + i) : 0u;
+            fw[q] = in ? *reinterpret_cast<const unsigned *>(fused + i) : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; q += 8)   // (a common use per group of loads keeps them from being sunk into their consumers)
+            asm volatile("" ::"v"(cw[q]), "v"(cw[q + 1]), "v"(cw[q + 2]), "v"(cw[q + 3]), "v"(cw[q + 4]), "v"(cw[q + 5]), "v"(cw[q + 6]), "v"(cw[q + 7]),
+                         "v"(fw[q]), "v"(fw[q + 1]), "v"(fw[q + 2]), "v"(fw[q + 3]), "v"(fw[q + 4]), "v"(fw[q + 5]), "v"(fw[q + 6]), "v"(fw[q + 7]));
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (s0 + 4 * q + j < s1 && ((cw[q] >> (8 * j)) & 0xFF) && !((fw[q] >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                if (4 * q + j < 64) emit |= (unsigned long long)e << ((4 * q + j) & 63);
+                else emitHi |= (unsigned long long)e << ((4 * q + j - 64) & 63);
+            }
+    };
+    if (per <= 32 && aligned4) {
+        flags_in_one_trip(std::integral_constant<int, 8>{});
+    } else if (per <= 96 && aligned4) {
+        flags_in_one_trip(std::integral_constant<int, 24>{});
+    } else {
+        for (int i = s0; i < s1; i += 4) {
+            unsigned c4, f4;
+            if (i + 4 <= P.nseeds && ((reinterpret_cast<size_t>(candOk + i) | reinterpret_cast<size_t>(fused + i)) & 3) == 0) {
+                c4 = *reinterpret_cast<const unsigned *>(candOk + i); f4 = *reinterpret_cast<const unsigned *>(fused + i);
+            } else {
+                c4 = f4 = 0;
+                for (int j = 0; j < 4 && i + j < P.nseeds; j++) { c4 |= (unsigned)candOk[i + j] << (8 * j); f4 |= (unsigned)fused[i + j] << (8 * j); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned e = (i + j < s1 && ((c4 >> (8 * j)) & 0xFF) && !((f4 >> (8 * j)) & 0xFF)) ? 1u : 0u;
+                cnt += e;
+                if (i + j - s0 < 64) emit |= (unsigned long long)e << (i + j - s0);
+                else if (i + j - s0 < 128) emitHi |= (unsigned long long)e << (i + j - s0 - 64);
+            }
+        }
+    }
+    // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
+    // that this round trip overlaps the scans below instead of following them.
+    msl_surfel e0, e1;
+    memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
+    if (pf && emit) {
+        e0 = cand[s0 + __builtin_ctzll(emit)];
+        const unsigned long long m1 = emit & (emit - 1);
+        if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
+    }
+    const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
+    const long long nWg = nblk;   // k_fuse waves (blockUpd entries): one per sub-block
+    s_raw[threadIdx.x] = du;
+    if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
+    __syncthreads();
+    // k_fuse already counted the deleted slots; when they all fit its hand-over list (the steady state) the per-sub-block
+    // counts are not needed at all.  Otherwise one pass over them (4 consecutive per thread and tile) lists the sub-blocks
+    // that contain deletions.
+    const bool fastest = mode == 0 && dHand <= LIST_D;
+    unsigned vsum = 0;
+    if (!fastest)
+        for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+            const long long c = t0 + 4 * threadIdx.x;
+            const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+            const unsigned x[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (x[j] > 0) {
+                    vsum += x[j];
+                    const unsigned q = atomicAdd(&s_nzChunks, 1u);
+                    if (q < SMALL_CHUNKS) { s_nzIdx[q] = (unsigned)(c + j); s_nzCnt[q] = x[j]; }
+                }
+        }
+    unsigned Dtot, Ku, exUnused, pos;
+    block_excl_scan_pair(vsum, cnt, s_wave, &Dtot, &Ku, exUnused, pos);   // total deletions + emission scan
+    const long long D = fastest ? (long long)dHand : (long long)Dtot;
+    // single-workgroup paths: workgroup 0 does everything alone -- no ticket, no write-through list
+    const bool small = mode == 0 && !fastest && D <= SMALL_D && s_nzChunks <= SMALL_CHUNKS;
+    const bool single = fastest || small;
+    if (single && blockIdx.x != 0) return;
+    if (mode == 0 && !bad) {
+        if (fastest) {
+            if (threadIdx.x < D) {   // rank-sort in LDS
+                unsigned r = 0;
+                for (unsigned j = 0; j < (unsigned)D; j++) r += s_raw[j] < du ? 1u : 0u;
+                s_dl[r] = du;
+            }
+        } else if (small) {
+            // few sub-blocks hold all deletions: order them by index (rank sort); a sub-block's offset in the ascending
+            // list is the sum of the counts before it -- no scan over the (thousands of) empty sub-blocks
+            const unsigned nz = s_nzChunks;
+            if (threadIdx.x < nz) {
+                const unsigned me = s_nzIdx[threadIdx.x];
+                unsigned r = 0;
+                for (unsigned j = 0; j < nz; j++) r += s_nzIdx[j] < me ? 1u : 0u;
+                s_nzSortIdx[r] = me; s_nzSortCnt[r] = s_nzCnt[threadIdx.x];
+            }
+            __syncthreads();
+            unsigned base = 0;
+            for (unsigned it = 0; it < nz; it++) {
+                const long long i0 = (long long)s_nzSortIdx[it] * SUB_ITEMS + threadIdx.x;   // one slot per thread: ascending
+                const unsigned f = (i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
+                unsigned tt;
+                const unsigned w = base + block_excl_scan(f, s_wave, &tt);
+                if (f) s_dl[w] = (unsigned)i0;
+                base += s_nzSortCnt[it];
+            }
+        } else {
+            // every workgroup lists the deleted slots of its own sub-blocks in ascending order; a sub-block's base offset
+            // lives in the registers of the thread that scanned it and is broadcast through one LDS word
+            unsigned carry = 0;
+            for (long long t0 = 0; t0 < nblk; t0 += TILE) {
+                const long long c = t0 + 4 * threadIdx.x;
+                const uint4 v4 = t0 == 0 ? bs0 : *reinterpret_cast<const uint4 *>(P.blockSums + c);
+                const unsigned v[4] = {c < nblk ? v4.x : 0u, c + 1 < nblk ? v4.y : 0u, c + 2 < nblk ? v4.z : 0u, c + 3 < nblk ? v4.w : 0u};
+                unsigned tot;
+                const unsigned ex = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], s_wave, &tot);
+                const long long nIter = (min(t0 + TILE, nblk) - t0 - blockIdx.x + gridDim.x - 1) / gridDim.x;
+                for (long long it = 0; it < nIter; it++) {
+                    const long long b = t0 + blockIdx.x + it * gridDim.x;
+                    const int q = (int)(b - t0);
+                    if ((int)threadIdx.x == (q >> 2)) {
+                        const int comp = q & 3;
+                        s_base = ex + (comp > 0 ? v[0] : 0u) + (comp > 1 ? v[1] : 0u) + (comp > 2 ? v[2] : 0u);
+                        s_cntChunk = v[comp];
+                    }
+                    __syncthreads();
+                    const unsigned base = s_base, cntChunk = s_cntChunk;
+                    if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this sub-block
+                    const long long i0 = b * SUB_ITEMS + threadIdx.x;       // one slot per thread keeps the list ascending
+                    const unsigned f = (i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
+                    unsigned tt;
+                    const unsigned w = base + block_excl_scan(f, s_wave, &tt);   // (its barriers also protect s_base)
+                    if (f) st_agent(&P.delList[w], (unsigned)i0);
+                }
+                carry += tot;
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    if (mode == 0 && !single && !last_workgroup(&P.tickets[1], &s_last)) return;
+    // ================= continuation: one workgroup =================
+    // updated count
+    {
+        unsigned u = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long c = TILE * q + 4 * threadIdx.x;
+            u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
+        }
+        for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
+        u = wave_incl_scan(u);                                   // one LDS atomic per wave instead of 256 on one address
+        if ((threadIdx.x & 63) == 63 && u) atomicAdd(&s_upd, u);
+    }
+    // initializeSurfels (:285-331): thread t owns the contiguous seeds [t*per, (t+1)*per); emission order = seed index order
+    const long long K = Ku;
+    const long long nAfter = mode == 1 ? n : (D >= K ? n - (D - K) : n + (K - D));
+    const bool place = mode == 0 && !bad && (unsigned long long)nAfter <= P.cap;
+    auto DL = [&](long long j) -> unsigned { return single ? s_dl[j] : ld_agent(&P.delList[j]); };
+    if (cnt) {
+        auto emit_one = [&](const msl_surfel &e) {
+            const long long k = pos++;
+            P.newSurfels[k] = e;                    // host-vector mode and debugging read this list
+            if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
+                store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
+        };
+        unsigned long long m = emit;
+        for (int j = 0; m; j++, m &= m - 1) {
+            const int i = s0 + __builtin_ctzll(m);
+            if (pf && j == 0) emit_one(e0);
+            else if (pf && j == 1) emit_one(e1);
+            else emit_one(cand[i]);
+        }
+        for (unsigned long long mh = emitHi; mh; mh &= mh - 1) emit_one(cand[s0 + 64 + __builtin_ctzll(mh)]);
+        for (int i = s0 + 128; i < s1; i++)
+            if (candOk[i] && !fused[i]) emit_one(cand[i]);
+    }
+    __syncthreads();   // s_upd complete; new-surfel stores ordered before the tail moves below (same workgroup)
+    if (threadIdx.x == 0) {
+        P.ctr[1] = K; P.ctr[2] = D; P.ctr[3] = s_upd; P.ctr[4] = n; P.ctr[6] = nAfter;
+        // running totals over all keyframes of this handle (one writer per launch, launches are ordered): bench.py derives the
+        // per-keyframe averages of a timed region from their differences
+        P.ctr[8] += K; P.ctr[9] += D; P.ctr[10] += s_upd; P.ctr[11] += 1; P.ctr[12] += n;
+        if ((unsigned long long)nAfter > P.cap) P.ctr[5] = 20;  // capacity exceeded
+    }
+    if (!place) { if (threadIdx.x == 0) *P.delUCount = 0; return; }   // (host-vector mode, or the deferred capacity error: the live count stays)
+    const long long t0 = threadIdx.x, stride = blockDim.x;
+    if (D > K) {
+        const long long R = D - K, nFinal = n - R;
+        auto lower = [&](long long x) -> long long {   // first index in delList[0..R) with value >= x
+            long long lo = 0, hi = R;
+            while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
+            return lo;
+        };
+        const long long cntLow = lower(nFinal);
+        for (long long a = t0; a < cntLow; a += stride) {
+            long long p = nFinal + a;
+            int hop = 0;
+            for (; hop < TAIL_MAX_HOPS; hop++) {
+                const long long lb = lower(p);
+                if (lb < R && (long long)DL(lb) == p) p = n - (R - lb);   // relay hole: follow to where its content came from
+                else break;
+            }
+            if (hop == TAIL_MAX_HOPS) s_fallback = 1;   // pathological chain: fall back to the literal loop
+            P.srcOf[a] = (unsigned)p;
+        }
+        __syncthreads();   // also orders the new-surfel stores above before the moves below (same workgroup)
+        if (s_fallback) {
+            if (threadIdx.x == 0)   // literal back-to-front loop (SurfelMapping.cpp:386-390), pathological delete patterns only
+                for (long long i = 1; i <= R; i++) {
+                    const long long hole = DL(R - i), src = n - i;
+                    if (src != hole) move_surfel(P.map, hole, src);
+                }
+        } else {
+            for (long long a = t0; a < cntLow; a += stride) move_surfel(P.map, (long long)DL(a), (long long)P.srcOf[a]);
+        }
+    }
+    if (threadIdx.x == 0) { P.ctr[0] = nAfter; *P.delUCount = 0; }   // publish the new live count, re-arm the hand-over list
+}
+
+// =============================================================================================
+// Deferred compaction: the end of a window
+// =============================================================================================
+// k_defer_tail: what is left to do per keyframe once the window's F fuse launches are through.
+//   workgroups 0 .. F - 1          : the updated-surfel count of keyframe f (sum of its per-sub-block counts) -> running total, ctr[3] for the last
+//   workgroups F .. F + NFRONT - 1 : the new surfels of the LAST keyframe (there is no next fuse launch to materialise them)
+__global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, unsigned blkStride) {   // A.kf = F
+    const unsigned lane = threadIdx.x;
+    if ((int)blockIdx.x < F) {
+        const int f = (int)blockIdx.x;
+        const long long nblk = (P.dc->ext[f] + SUB_ITEMS - 1) / SUB_ITEMS;
+        const unsigned *bu = P.blockUpd + (size_t)f * blkStride;
+        unsigned u = 0;
+        for (long long b = lane; b < nblk; b += 64) u += bu[b];
+        u = wave_incl_scan(u);
+        if (lane == 63) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&P.ctr[10]), (unsigned long long)u);
+            if (f == F - 1) P.ctr[3] = u;
+        }
+        return;
+    }
+    const long long E0 = P.dc->ext[F - 1];
+    const long long q = (long long)blockIdx.x - F, sb = (E0 >> 8) + q;
+    if (sb * SUB_ITEMS >= E0 + P.nseeds) return;
+    const unsigned K = emit_pending(A, E0, sb, lane);
+    if (q == 0 && lane == 0) P.dc->ext[F] = E0 + (long long)K;
+}
+
+// k_replay: the window's F compactions, replayed symbolically by ONE wave.
+// Elements are named by their PHYSICAL slot (nothing moved during the window): base elements 0 .. n0 - 1, the k-th new surfel of keyframe
+// f = ext[f] + k.  The reference's array ("virtual" order) differs from the identity only where a compaction put something:
+//   loc64[p]  = element at virtual position p, with the keyframe (stamp) that put it there      -- only for explicit placements
+//   vposD[e]  = virtual position of element e                                                   -- only for elements placed explicitly
+//   run f     = the new surfels of keyframe f that were APPENDED: elements ext[f] + k0 + q at virtual positions runV + q, q < runCnt
+// (a run is clipped when a later keyframe shortens the array; where a run and an explicit entry both cover a position the later stamp wins).
+// Per keyframe: virtual positions of the logged slots -> ascending (LDS rank sort; a bitmap over the positions beyond RP_SORT entries) ->
+// new surfel k to the k-th largest hole, else appended (SurfelMapping.cpp:372-384) -> if holes remain, the back-to-front loop (:386-390) as
+// k_compact resolves it: the a-th smallest leftover hole below the new end receives resolve(nFinal + a).  At the end every virtual position
+// whose element is not already in that physical slot becomes one move (source, destination); k_gather / k_scatter apply them.
+// All table traffic is agent-scope (L2): one wave, but its own stores must be what its later loads see.
+constexpr int RP_SORT = 2048;
+__global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
+    __shared__ __attribute__((aligned(16))) unsigned s_v[RP_SORT + 4];
+    __shared__ unsigned s_d[RP_SORT];
+    __shared__ long long s_ext[DEFER_WIN + 1], s_runV[DEFER_WIN];
+    __shared__ unsigned s_runK0[DEFER_WIN], s_runCnt[DEFER_WIN];
+    const unsigned lane = threadIdx.x;
+    DeferCtl *dc = P.dc;
+    if ((int)lane <= F) s_ext[lane] = dc->ext[lane];
+    if (lane < DEFER_WIN) { s_runCnt[lane] = 0; s_runV[lane] = 0; s_runK0[lane] = 0; }
+    __syncthreads();
+    const long long n0 = s_ext[0];
+    long long n = n0;
+    unsigned nLocKeys = 0, nVposKeys = 0, logBase = 0;
+    long long totK = 0, totD = 0, totNb = 0, lastK = 0, lastD = 0, lastNb = 0;
+    auto vpos_of = [&](unsigned id) -> unsigned {
+        const unsigned v = ld_agent(&P.vposD[id]);
+        if (v) return v - 1;
+        if ((long long)id < n0) return id;
+        int g = 0;
+        for (int q = 1; q < F; q++) if ((long long)id >= s_ext[q]) g = q;   // the keyframe that spawned it
+        return (unsigned)(s_runV[g] + ((long long)id - s_ext[g] - (long long)s_runK0[g]));
+    };
+    // newest run covering p: its keyframe (-1: none) and element
+    auto run_of = [&](long long p, int upto, unsigned &elem) -> int {
+        for (int g = upto; g >= 0; g--) {
+            const long long v0 = s_runV[g];
+            if (s_runCnt[g] && p >= v0 && p < v0 + (long long)s_runCnt[g]) { elem = (unsigned)(s_ext[g] + (long long)s_runK0[g] + (p - v0)); return g; }
+        }
+        return -1;
+    };
+    auto loc_of = [&](long long p, int upto) -> unsigned {
+        const unsigned long long v = ld_agent64(&P.loc64[p]);
+        unsigned er = 0;
+        const int g = run_of(p, upto, er);
+        if (v && (g < 0 || (unsigned)(v >> 32) > (unsigned)(g + 1))) return (unsigned)v - 1u;
+        return g >= 0 ? er : (unsigned)p;
+    };
+    for (int f = 0; f < F; f++) {
+        const unsigned D = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_agent(&dc->delCnt[f]));
+        const long long K = s_ext[f + 1] - s_ext[f];
+        const unsigned long long stamp = (unsigned long long)(f + 1) << 32;
+        const bool inLds = D <= (unsigned)RP_SORT;
+        lastK = K; lastD = D; lastNb = n; totK += K; totD += D; totNb += n;
+        // ---- 1. virtual positions of the logged slots ----
+        for (unsigned j0 = 0; j0 < D; j0 += 64) {
+            const unsigned j = j0 + lane;
+            if (j < D) {
+                const unsigned vp = vpos_of(ld_agent(&P.delList[logBase + j]));
+                if (inLds) s_v[j] = vp;
+                else atomicOr(&P.bitmap[vp >> 5], 1u << (vp & 31u));
+            }
+        }
+        if (inLds && lane < 4) s_v[D + lane] = 0xFFFFFFFFu;   // padding of the last 16-byte read
+        __syncthreads();
+        // ---- 2. ascending order ----
+        if (inLds) {
+            for (unsigned j0 = 0; j0 < D; j0 += 64) {
+                const unsigned j = j0 + lane;
+                const unsigned v = j < D ? s_v[j] : 0u;
+                unsigned r = 0;
+                for (unsigned q = 0; q < D; q += 4) {   // (the positions are distinct: the ranks are a permutation)
+                    const uint4 x = *reinterpret_cast<const uint4 *>(&s_v[q]);
+                    r += (x.x < v ? 1u : 0u) + (x.y < v ? 1u : 0u) + (x.z < v ? 1u : 0u) + (x.w < v ? 1u : 0u);
+                }
+                if (j < D) s_d[r] = v;
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long nw = (n + 31) >> 5;
+            unsigned base = 0;
+            for (long long w0 = 0; w0 < nw; w0 += 64) {
+                const long long w = w0 + lane;
+                unsigned bits = w < nw ? ld_agent(&P.bitmap[w]) : 0u;
+                const unsigned c = (unsigned)__popc(bits);
+                const unsigned incl = wave_incl_scan(c);
+                unsigned o = base + incl - c;
+                if (bits) st_agent(&P.bitmap[w], 0u);   // clean for the next use
+                for (; bits; bits &= bits - 1) st_agent(&P.dBig[o++], (unsigned)(w * 32 + __builtin_ctz(bits)));
+                base += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        auto DL = [&](long long j) -> unsigned { return inLds ? s_d[j] : ld_agent(&P.dBig[j]); };
+        auto put = [&](bool on, long long pos, unsigned elem) {   // explicit placement: element `elem` now sits at virtual position `pos`
+            if (on) { st_agent64(&P.loc64[pos], (unsigned long long)(elem + 1u) | stamp); st_agent(&P.vposD[elem], (unsigned)pos + 1u); }
+            const unsigned long long m = __ballot(on);
+            if (on) { const unsigned r = lane_rank(m); st_agent(&P.locKeys[nLocKeys + r], (unsigned)pos); st_agent(&P.vposKeys[nVposKeys + r], elem); }
+            nLocKeys += (unsigned)__popcll(m); nVposKeys += (unsigned)__popcll(m);
+        };
+        // ---- 3. new surfel k -> k-th largest hole (SurfelMapping.cpp:372-384) ----
+        const long long nPl = K < (long long)D ? K : (long long)D;
+        for (long long k0 = 0; k0 < nPl; k0 += 64) {
+            const long long k = k0 + lane;
+            const bool on = k < nPl;
+            put(on, on ? (long long)DL((long long)D - 1 - k) : 0, (unsigned)(s_ext[f] + k));
+        }
+        if (K > (long long)D) {   // the others are appended: a run
+            if (lane == 0) { s_runV[f] = n; s_runK0[f] = D; s_runCnt[f] = (unsigned)(K - (long long)D); }
+            n += K - (long long)D;
+        } else if ((long long)D > K) {
+            // ---- 4. leftover holes: the back-to-front loop of :386-390, per hole ----
+            const long long R = (long long)D - K, nFinal = n - R;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a tail source may be a surfel placed just above)
+            auto lower = [&](long long x) -> long long {   // first index in the R smallest holes with value >= x
+                long long lo = 0, hi = R;
+                while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
+                return lo;
+            };
+            const long long cntLow = lower(nFinal);   // holes below the new end: each receives a tail element
+            for (long long a0 = 0; a0 < cntLow; a0 += 64) {
+                const long long a = a0 + lane;
+                const bool on = a < cntLow;
+                long long p = nFinal + (on ? a : 0);
+                bool chain = on;
+                while (__ballot(chain)) {
+                    if (chain) {
+                        const long long lb = lower(p);
+                        if (lb < R && (long long)DL(lb) == p) p = n - (R - lb);   // a hole inside the tail only relays: follow to where its content comes from
+                        else chain = false;
+                    }
+                }
+                const unsigned e = on ? loc_of(p, f) : 0u;
+                put(on, on ? (long long)DL(a) : 0, e);
+            }
+            __syncthreads();
+            if ((int)lane <= f && s_runCnt[lane] && s_runV[lane] + (long long)s_runCnt[lane] > nFinal)
+                s_runCnt[lane] = s_runV[lane] >= nFinal ? 0u : (unsigned)(nFinal - s_runV[lane]);
+            n = nFinal;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the keyframe's table stores are complete before the next one reads
+        __syncthreads();
+        logBase += D;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the moves: every virtual position whose element is not already in that physical slot ----
+    const long long nF = n;
+    unsigned nMoves = 0;
+    auto add_move = [&](bool on, unsigned dst, unsigned src) {
+        const unsigned long long m = __ballot(on);
+        if (on) { const unsigned r = nMoves + lane_rank(m); P.moveDst[r] = dst; P.srcOf[r] = src; }
+        nMoves += (unsigned)__popcll(m);
+    };
+    for (int g = 0; g < F; g++) {   // appended runs first, while the explicit table is intact
+        const unsigned cnt = s_runCnt[g];
+        for (unsigned q0 = 0; q0 < cnt; q0 += 64) {
+            const unsigned q = q0 + lane;
+            bool on = q < cnt;
+            const long long p = s_runV[g] + q;
+            const unsigned id = (unsigned)(s_ext[g] + (long long)s_runK0[g] + q);
+            if (on) { const unsigned long long v = ld_agent64(&P.loc64[p]); if (v && (unsigned)(v >> 32) > (unsigned)(g + 1)) on = false; }   // a later explicit placement owns p
+            if (on && (long long)id == p) on = false;
+            add_move(on, (unsigned)p, id);
+        }
+    }
+    for (unsigned j0 = 0; j0 < nLocKeys; j0 += 64) {   // explicit placements (a position may be listed more than once: cleared at its first visit)
+        const unsigned j = j0 + lane;
+        bool on = j < nLocKeys;
+        const unsigned p = on ? ld_agent(&P.locKeys[j]) : 0u;
+        const unsigned long long v = on ? ld_agent64(&P.loc64[p]) : 0ull;
+        on = on && v != 0ull;
+        if (on) st_agent64(&P.loc64[p], 0ull);
+        unsigned er = 0;
+        if (on) { const int g = run_of((long long)p, F - 1, er); if (g >= 0 && (unsigned)(g + 1) > (unsigned)(v >> 32)) on = false; }   // stale: a later run covers p
+        if (on && (long long)p >= nF) on = false;
+        const unsigned id = (unsigned)v - 1u;
+        if (on && id == p) on = false;
+        add_move(on, p, id);
+    }
+    for (unsigned j0 = 0; j0 < nVposKeys; j0 += 64) { const unsigned j = j0 + lane; if (j < nVposKeys) st_agent(&P.vposD[ld_agent(&P.vposKeys[j])], 0u); }
+    if (lane < DEFER_WIN) dc->delCnt[lane] = 0;   // the next window starts with empty logs
+    if (lane == 0) {
+        dc->nMoves = nMoves;
+        P.ctr[0] = nF; P.ctr[1] = lastK; P.ctr[2] = lastD; P.ctr[4] = lastNb; P.ctr[6] = nF;
+        P.ctr[8] += totK; P.ctr[9] += totD; P.ctr[11] += F; P.ctr[12] += totNb;
+    }
+}
+
+// The window's moves: all sources first (a destination may be another move's source), then all destinations.
+__global__ __launch_bounds__(256) void k_gather(SfDev P) {
+    const MapSoA &M = P.map;
+    const unsigned nM = P.dc->nMoves;
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < nM; j += gridDim.x * 256) {
+        const unsigned s = P.srcOf[j];
+        const HotPk h = M.hot[s];
+        const ColdRec c = M.cold[s];
+        P.stageHot[j] = h; P.stageCold[j] = c;
+        if (h.tl == HOT_WIDE) { P.stageUtl[2 * (size_t)j] = M.utlWide[2 * (size_t)s]; P.stageUtl[2 * (size_t)j + 1] = M.utlWide[2 * (size_t)s + 1]; }
+        if (c.rgbf & COLD_WIDE) for (int q = 0; q < 3; q++) P.stageRgb[3 * (size_t)j + q] = M.rgbWide[3 * (size_t)s + q];
+    }
+}
+__global__ __launch_bounds__(256) void k_scatter(SfDev P) {
+    const MapSoA &M = P.map;
+    const unsigned nM = P.dc->nMoves;
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < nM; j += gridDim.x * 256) {
+        const unsigned d = P.moveDst[j];
+        const HotPk h = P.stageHot[j];
+        const ColdRec c = P.stageCold[j];
+        M.hot[d] = h; M.cold[d] = c;
+        if (h.tl == HOT_WIDE) { M.utlWide[2 * (size_t)d] = P.stageUtl[2 * (size_t)j]; M.utlWide[2 * (size_t)d + 1] = P.stageUtl[2 * (size_t)j + 1]; }
+        if (c.rgbf & COLD_WIDE) for (int q = 0; q < 3; q++) M.rgbWide[3 * (size_t)d + q] = P.stageRgb[3 * (size_t)j + q];
+    }
+}
+
+// ---- map maintenance: ordered selection of surfels by a predicate -------------------------------
+// mode 0: updateTimes > 0 && lastUpdate == arg (moveAddSurfels, src/SurfelMapping.cpp:213)   mode 1: updateTimes >= arg (Stop, :68)
+__device__ __forceinline__ bool select_pred(const HotRec &h, int mode, int arg) {
+    return mode == 0 ? (h.updateTimes > 0 && h.lastUpdate == arg) : (h.updateTimes >= arg);
+}
+__global__ __launch_bounds__(256) void k_select_count(SfDev P, int mode, int arg) {
+    __shared__ unsigned s_c;
+    const long long n = P.ctr[0];
+    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        if (threadIdx.x == 0) s_c = 0;
+        __syncthreads();
+        unsigned c = 0;
+        for (int k = 0; k < SCAN_ITEMS / 256; k++) {
+            const long long i = b * SCAN_ITEMS + k * 256 + threadIdx.x;
+            if (i < n && select_pred(hot_load(P.map, i), mode, arg)) c++;
+        }
+        if (c) atomicAdd(&s_c, c);
+        __syncthreads();
+        if (threadIdx.x == 0) P.blockSums[b] = s_c;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(1024) void k_select_scan(SfDev P) {   // one workgroup: exclusive scan of the chunk counts, total -> ctr[7]
+    __shared__ unsigned s_wave[17];
+    const long long n = P.ctr[0];
+    const int nblk = (int)((n + SCAN_ITEMS - 1) / SCAN_ITEMS);
+    unsigned carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const unsigned v = b < nblk ? P.blockSums[b] : 0;
+        unsigned tot;
+        const unsigned ex = carry + block_excl_scan(v, s_wave, &tot);
+        if (b < nblk) P.blockSums[b] = ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) P.ctr[7] = carry;
+}
+__global__ __launch_bounds__(256) void k_select_write(SfDev P, int mode, int arg, msl_surfel *out, int markDeleted) {
+    __shared__ unsigned s_wave[17];
+    const long long n = P.ctr[0];
+    const long long nblk = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    for (long long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        unsigned base = P.blockSums[b];
+        for (int k = 0; k < SCAN_ITEMS / 256; k++) {           // 256 consecutive surfels per round keep the map order
+            const long long i = b * SCAN_ITEMS + k * 256 + threadIdx.x;
+            HotRec h{};
+            unsigned tl = 0;
+            if (i < n) { tl = P.map.hot[i].tl; h = hot_load(P.map, i); }
+            const bool sel = i < n && select_pred(h, mode, arg);
+            unsigned tot;
+            const unsigned pos = base + block_excl_scan(sel ? 1u : 0u, s_wave, &tot);
+            if (sel) {
+                msl_surfel e;
+                load_surfel(P.map, i, h, e);
+                out[pos] = e;
+                if (markDeleted) hot_mark_deleted(P.map, i, tl);   // "Delete the surfel from the local point" (:224)
+            }
+            base += tot;
+        }
+    }
+}
+__global__ void k_add_ctr(long long *ctr, long long add) {
+    if (threadIdx.x == 0) { ctr[0] += add; ctr[4] = ctr[0]; ctr[6] = ctr[0]; }
+}
+__global__ __launch_bounds__(256) void k_aos_to_soa_at(MapSoA M, const msl_surfel *src, long long n, const long long *ctr) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) store_surfel(M, ctr[0] + i, src[i]);
+}
+
+// AoS <-> SoA conversion for upload / download / host-vector mode
+__global__ __launch_bounds__(256) void k_aos_to_soa(MapSoA M, const msl_surfel *src, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) store_surfel(M, i, src[i]);
+}
+__global__ __launch_bounds__(256) void k_soa_to_aos(MapSoA M, msl_surfel *dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const HotRec h = hot_load(M, i);
+    msl_surfel e;
+    load_surfel(M, i, h, e);
+    dst[i] = e;
+}
+// wide: -1 = leave the wide-record flags ctr[13] alone (upload: k_aos_to_soa has just set them if needed), otherwise the restored snapshot's flags
+__global__ void k_set_ctr(long long *ctr, long long n, unsigned *delUCount, int wide) {
+    if (threadIdx.x == 0) {
+        delUCount[0] = 0;
+        ctr[0] = n; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; ctr[4] = n; ctr[6] = n; ctr[7] = 0;
+        if (wide >= 0) ctr[13] = wide;
+    }
+}
+
+// Host-vector mode, sparse case: the records this keyframe touched (updated: lastUpdate == ref; deleted: updateTimes == 0) of the sub-blocks that
+// report any, as a compact list {index, reference-layout record}.  One wave per sub-block; slots by one atomic per wave.
+__global__ __launch_bounds__(64) void k_collect_changed(SfDev P, int ref, long long n, unsigned *count, unsigned *idxOut, msl_surfel *recOut, unsigned capOut) {
+    const long long sb = blockIdx.x;
+    if (!(P.blockSums[sb] | P.blockUpd[sb])) return;
+    const unsigned lane = threadIdx.x;
+    for (int k = 0; k < SUB_ITEMS / 64; k++) {
+        const long long i = sb * SUB_ITEMS + k * 64 + lane;
+        HotRec h; h.px = h.py = h.pz = 0; h.updateTimes = 1; h.lastUpdate = ref - 1;
+        if (i < n) h = hot_load(P.map, i);
+        const bool ch = i < n && (h.updateTimes == 0 || h.lastUpdate == ref);
+        const unsigned long long m = __ballot(ch);
+        if (!m) continue;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (ch) {
+            const unsigned j = base + lane_rank(m);
+            if (j < capOut) { msl_surfel e; load_surfel(P.map, i, h, e); recOut[j] = e; idxOut[j] = (unsigned)i; }
+        }
+    }
+}
+
+__global__ void k_empty(int grid_dummy) { (void)grid_dummy; }
+
+}  // namespace
+
+namespace msl {
+namespace sf {
+
+void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred) {
+    const FuseArgs A = fuse_args(P, slot, deferred);
+    const FuseFrame FF = fuse_frame(F);
+    if (deferred) MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<true>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
+    else MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<false>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
+}
+void map_launch_compact(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, bool resident) {
+    MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_compact, dim3(resident ? 128 : 1), dim3(256), P, slot, resident ? 0 : 1);   // scan + new surfels + refill + tail compaction
+}
+// Closes a deferred window of F keyframes (P.prevSlotAbs = the slot of its last keyframe, P.blockUpd = the window's first per-sub-block slice).
+void map_launch_replay(KernelProfiler &prof, hipStream_t st, const SfDev &P, int F, unsigned blkStride) {
+    const unsigned nFront = (unsigned)((P.nseeds + SUB_ITEMS - 1) / SUB_ITEMS) + 1u;
+    hipLaunchKernelGGL(k_defer_tail, dim3((unsigned)F + nFront), dim3(64), 0, st, P, fuse_args(P, 0, true), F, blkStride);
+    MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_replay, dim3(1), dim3(64), P, F);
+    hipLaunchKernelGGL(k_gather, dim3(128), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(k_scatter, dim3(128), dim3(256), 0, st, P);
+}
+void map_launch_empty_pair(KernelProfiler &prof, hipStream_t st) {   // what an event pair reports for an EMPTY dispatch at this place of the chain
+    hipEvent_t ea, eb;   // (the pair's first event completes with the previous command, so every event time contains the dependent-launch gap)
+    if (prof.kernel_pair(SK_NEW, &ea, &eb)) hipExtLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, st, ea, eb, 0, 0);
+}
+void map_launch_set_ctr(hipStream_t st, const SfDev &P, long long n, int wide) { hipLaunchKernelGGL(k_set_ctr, dim3(1), dim3(64), 0, st, P.ctr, n, P.delUCount, wide); }
+void map_launch_add_ctr(hipStream_t st, const SfDev &P, long long add) { hipLaunchKernelGGL(k_add_ctr, dim3(1), dim3(64), 0, st, P.ctr, add); }
+void map_launch_aos_to_soa(KernelProfiler &prof, hipStream_t st, const SfDev &P, const msl_surfel *src, long long n, bool atEnd) {
+    if (atEnd) hipLaunchKernelGGL(k_aos_to_soa_at, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.map, src, n, P.ctr);
+    else MSL_SF_LAUNCH(prof, SK_CONVERT, st, k_aos_to_soa, dim3((unsigned)((n + 255) / 256)), dim3(256), P.map, src, n);
+}
+void map_launch_soa_to_aos(KernelProfiler &prof, hipStream_t st, const SfDev &P, msl_surfel *dst, long long n) {
+    MSL_SF_LAUNCH(prof, SK_CONVERT, st, k_soa_to_aos, dim3((unsigned)((n + 255) / 256)), dim3(256), P.map, dst, n);
+}
+void map_launch_select_count(hipStream_t st, const SfDev &P, int mode, int arg) {
+    hipLaunchKernelGGL(k_select_count, dim3(512), dim3(256), 0, st, P, mode, arg);
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, st, P);
+}
+void map_launch_select_write(hipStream_t st, const SfDev &P, int mode, int arg, msl_surfel *out, int markDeleted) {
+    hipLaunchKernelGGL(k_select_write, dim3(512), dim3(256), 0, st, P, mode, arg, out, markDeleted);
+}
+void map_launch_collect_changed(hipStream_t st, const SfDev &P, int ref, long long n, unsigned *count, unsigned *idxOut, msl_surfel *recOut, unsigned capOut) {
+    const unsigned nblk = (unsigned)((n + SUB_ITEMS - 1) / SUB_ITEMS);
+    hipLaunchKernelGGL(k_collect_changed, dim3(nblk), dim3(64), 0, st, P, ref, n, count, idxOut, recOut, capOut);
+}
+void map_launch_empty(hipStream_t st, int grid, hipEvent_t a, hipEvent_t b) { hipExtLaunchKernelGGL(k_empty, dim3((unsigned)grid), dim3(64), 0, st, a, b, 0, grid); }
+
+}  // namespace sf
+}  // namespace msl

@@ -52,7 +52,8 @@ def test_surfel_fusion_macros():
     got = {k: _const(h, k) for k in ("ITERATION_NUM", "THREAD_NUM", "SP_SIZE", "MAX_ANGLE_COS", "HUBER_RANGE", "BASELINE", "DISPARITY_ERROR", "MIN_TOLERATE_DIFF")}
     assert got == {"ITERATION_NUM": 3, "THREAD_NUM": 10, "SP_SIZE": 8, "MAX_ANGLE_COS": 0.1, "HUBER_RANGE": 0.4, "BASELINE": 0.5, "DISPARITY_ERROR": 4.0,
                    "MIN_TOLERATE_DIFF": 0.1}
-    hip = open(os.path.join(ROOT, "manhattanslam_amd", "csrc", "msl_surfel.hip")).read()
+    csrc = os.path.join(ROOT, "manhattanslam_amd", "csrc")
+    hip = "".join(open(os.path.join(csrc, f)).read() for f in ("msl_sf.h", "msl_sf_superpixel.hip", "msl_sf_map.hip", "msl_surfel.hip"))
     assert "constexpr int SP = 8;" in hip and "constexpr int NCHUNK = 10;" in hip
     assert "MAX_ANGLE_COS = 0.1, HUBER_RANGE = 0.4, MIN_TOLERATE_DIFF = 0.1" in hip
     assert "halfF = 0.5f * cameraF" in hip and "/ halfF * 4.0f" in hip          # BASELINE and DISPARITY_ERROR as exact float factors in k_fuse

@@ -731,25 +731,61 @@ def test_host_vector_sparse_change_list(oracle):
     g.close()
 
 
-@pytest.mark.parametrize("flag", ["MSL_SF_OVERLAP", "MSL_SF_MERGED"])
-def test_overlapped_map_stage_gives_identical_maps(flag):
-    """The two forms of "compaction j beside fusion j + 1" (run_batch): MSL_SF_OVERLAP=1, compaction on its own stream and the fusion split into a
-    launch for the sub-blocks the compaction cannot touch and one behind it for the others; MSL_SF_MERGED=1, ONE launch per keyframe whose first
-    workgroup compacts keyframe j - 1 while the others fuse keyframe j and the few dependent waves poll a flag.  The flags are read once per process,
-    so the batched / resident parity tests run again in a child process with each set: same maps, counters and new-surfel lists as the oracle."""
+def test_classic_chain_gives_identical_maps():
+    """Resident batches take the DEFERRED compaction by default (round 5: one k_fuse launch per keyframe, new surfels appended physically, the
+    window's placements and tail moves replayed at its end, msl_sf_map.hip).  MSL_SF_DEFER=0 sends every keyframe through the classic pair
+    k_fuse + k_compact instead.  The flag is read once per process, so the batched / resident parity tests run again in a child process with
+    it set: both chains leave the oracle's maps, counters and new-surfel lists."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.pop("MSL_SF_OVERLAP", None); env.pop("MSL_SF_MERGED", None)
-    env[flag] = "1"
+    env["MSL_SF_DEFER"] = "0"
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         os.path.join(root, "tests", "test_surfel_gpu.py"), os.path.join(root, "tests", "test_clutter_gpu.py"),
-                        "-k", "batched or full_size or grows or resident_sequence or snapshot or outgrows or dense_in_view or keyframe_every or compaction or wide_rgb"],
+                        "-k", "batched or full_size or grows or resident_sequence or snapshot or outgrows or dense_in_view or keyframe_every or compaction or wide or moving"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_wide_update_counters_survive_the_packed_hot_record(oracle):
+    """The resident hot record packs updateTimes (11 bits) and lastUpdate (20 bits) into one word (round 5); values outside those ranges --
+    negative reference indices, more than 2047 fusions, indices beyond a million -- keep their exact ints in a side array, through upload,
+    classic and deferred keyframes (fusion increments, stale deletions, tail moves), detach / append and snapshot / restore."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map(30000, ref=2000000, min_update_times=1).astype(SURFEL_DTYPE)   # lastUpdate around two million: every record is wide
+    rng = np.random.default_rng(7)
+    big = rng.choice(len(m), 4000, replace=False)
+    m["updateTimes"][big] = rng.integers(2040, 5000, len(big))     # around and beyond the 11-bit limit
+    m["lastUpdate"][big[::5]] = -3                                  # negative reference index (stale: deleted when updateTimes < 5 -- none here)
+    m["updateTimes"][big[1::7]] = 2047                              # the largest packed value: one more fusion makes it wide
+    g.map_upload(m)
+    assert g.map_download().tobytes() == m.tobytes()
+    g.map_snapshot()
+    o.map_set(m)
+    g.set_batch_capacity(4)
+    refs = [2000002, 2000003, 2000009, 2000010]                     # 2000009 deletes what went stale
+    frames = [synth.surfel_frame(k) for k in (2, 3, 9, 10)]
+    g.fuse_resident_batch(refs, np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]), [f[3] for f in frames])
+    for r, f in zip(refs, frames):
+        o.fuse_map(r, f[0], f[1], f[2], f[3])
+    mo = o.map_get()
+    assert_surfels_close(g.map_download(), mo, "map with wide updateTimes / lastUpdate")
+    assert (mo["updateTimes"] > 2047).sum() > 100 and (mo["lastUpdate"] > (1 << 20)).sum() > 1000
+    # a narrow map on the same handle: small reference indices, the packed form
+    m2 = synth.surfel_map(20000, ref=2, min_update_times=1).astype(SURFEL_DTYPE)
+    g.map_upload(m2); o.map_set(m2)
+    frames = [synth.surfel_frame(k) for k in (2, 3, 9)]
+    g.fuse_resident_batch([2, 3, 9], np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]), np.stack([f[2] for f in frames]), [f[3] for f in frames])
+    for r, f in zip([2, 3, 9], frames):
+        o.fuse_map(r, f[0], f[1], f[2], f[3])
+    assert_surfels_close(g.map_download(), o.map_get(), "narrow map after a wide one")
+    g.map_restore()
+    assert g.map_download().tobytes() == m.tobytes()
+    g.close()
 
 
 @pytest.mark.parametrize("n,shares,tail_heavy,same_view", [
@@ -759,8 +795,8 @@ def test_overlapped_map_stage_gives_identical_maps(flag):
 def test_batched_compaction_patterns(oracle, n, shares, tail_heavy, same_view):
     """Deletions that fall due at the SECOND, THIRD and FOURTH keyframe of one batched call (stale surfels: ref - lastUpdate > 5 with fewer than five
     updates), in controlled amounts: a handful (the hand-over list), thousands (listed sub-block by sub-block), nearly everything, concentrated at
-    the end of the array (relay holes inside the tail), with many or hardly any new surfels to refill the holes.  In the default build this is the two-kernel chain; under MSL_SF_MERGED=1 / MSL_SF_OVERLAP=1
-    (the child-process test above) the same keyframes go through the compaction wave of the merged launch / the second stream."""
+    the end of the array (relay holes inside the tail), with many or hardly any new surfels to refill the holes.  By default the call is one deferred window behind a classic first keyframe (the map was just uploaded): keyframes with more than 2048
+    deletions take the replay's bitmap ordering; under MSL_SF_DEFER=0 (the child-process test above) every keyframe takes the two-kernel chain."""
     from manhattanslam_amd import synth, SURFEL_DTYPE
     g, o = _mk(synth.TUM1)
     rng = np.random.default_rng(n)
