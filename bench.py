@@ -88,8 +88,10 @@ def parse(argv=None):
     ap.add_argument("--surfels", type=int, default=1_000_000)
     ap.add_argument("--sequences-per-gpu", type=int, default=1, help="independent RGB-D sequences per GPU, each with its own handles, streams, resident map and host "
                     "thread (the weak-scaling unit stays the sequence; BASELINE's shape is 1).  `value` is the total over all sequences")
-    ap.add_argument("--map", default=None, choices=["dense", "sparse"], help="pre-seeded live map: dense = ~35 %% of it inside the frustum of every keyframe (SURVEY.md "
-                    "8(d) config 3 as written; the default of every configuration); sparse = the area-uniform room map of rounds 1-3 (~6 %% in view)")
+    ap.add_argument("--map", default=None, choices=["dense", "sparse", "moving"], help="pre-seeded live map: dense = ~35 %% of it inside the frustum of every keyframe (SURVEY.md "
+                    "8(d) config 3 as written; the default of every configuration); sparse = the area-uniform room map of rounds 1-3 (~6 %% in view); "
+                    "moving = a pan of 4 degrees per keyframe over a dense map with unmapped stripes: every keyframe spawns and deletes hundreds of "
+                    "surfels (a pass is one sweep of --distinct-frames keyframes)")
     ap.add_argument("--map-order", default="creation", choices=["creation", "random"], help="array order of the dense map: creation = (source keyframe, superpixel) as "
                     "initializeSurfels appends surfels; random = no locality between array neighbours")
     ap.add_argument("--scene", default=None, choices=["room", "clutter"], help="depth / membership content: the bare box room or the furnished room (config 4's default)")
@@ -205,6 +207,12 @@ def geometry(args):
     kfe = args.keyframe_every or cfg["kfe"]
     F = args.frames_per_pass or cfg.get("frames_per_pass", 256)
     P = args.passes_per_step or cfg["passes"]
+    if (args.map or cfg.get("map")) == "moving" and not args.frames_per_pass:
+        # the moving-camera regime: a pass is ONE sweep over the distinct frames (a 4 degree pan per keyframe into partly unmapped territory), never
+        # a repetition of it -- a frame seen again would find the surfels it spawned the first time
+        F = min(args.distinct_frames, F)
+        if not args.passes_per_step:
+            P = P * max(1, cfg.get("frames_per_pass", 256) // F)
     B = min(args.batch, F)
     D = min(args.distinct_frames, F)
     if F % B or B % kfe or F % D:
@@ -498,7 +506,7 @@ def main():
                    "stationary": bool(reseed) or not do_sf,
                    "map_reseed": "msl_sf_map_restore (device-to-device, inside the timed region) at the start of every pass" if reseed else "none",
                    "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg),
-                   "map": (f"{map_kind} ({'~35 % of the map inside the frustum of every keyframe, SURVEY.md 8(d) config 3' if map_kind == 'dense' else 'area-uniform over the room, ~6 % in view'}"
+                   "map": (f"{map_kind} ({'~35 % of the map inside the frustum of every keyframe, SURVEY.md 8(d) config 3' if map_kind == 'dense' else 'a 4 degree pan per keyframe over a dense map with unmapped stripes (synth.surfel_map_moving): 25-34 % in view, every keyframe spawns and deletes hundreds of surfels' if map_kind == 'moving' else 'area-uniform over the room, ~6 % in view'}"
                            f"{', array order = ' + args.map_order if map_kind == 'dense' else ''})") if do_sf else None,
                    "in_view_fraction_keyframe0": round(synth.in_view_fraction(smap, 0, W, H, intr), 4) if do_sf else None, "scene": scene_kind,
                    "surfels_updated_per_keyframe": round(avg_upd, 1), "surfels_new_per_keyframe": round(avg_new, 2), "surfels_deleted_per_keyframe": round(avg_del, 2),

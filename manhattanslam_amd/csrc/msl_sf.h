@@ -77,6 +77,15 @@ struct alignas(32) AssignRec {
     unsigned long long _pad;
 };
 
+// What only a few waves of a k_fuse launch need (rare paths): kept in device memory, not in kernel arguments.
+struct FuseAux {
+    MapSoA map;                     // (the side arrays of wide records, the wide-record flags)
+    unsigned long long cap;
+    unsigned *delU, *delUCount;     // classic: the hand-over list of k_compact and its length
+    unsigned *delList;              // deferred: the window's deletion log
+    unsigned *blockSums, *blockUpd; // per-sub-block deleted / updated counts (blockUpd: DEFER_WIN slices of blkStride entries)
+    unsigned long long blkStride;
+};
 // Deferred compaction (round 5): what the fuse launches of one window leave for the replay.
 struct DeferCtl {
     long long ext[DEFER_WIN + 1];   // ext[f]: physical extent of the array the fuse launch of keyframe f works on (= ext[f - 1] + new surfels of f - 1)
@@ -87,6 +96,7 @@ struct DeferCtl {
     // surfels of keyframe kf - 1 from them
     const uint8_t *candOk, *fused;
     const msl_surfel *cand;
+    FuseAux aux;                    // written whenever the map is (re)allocated
 };
 
 struct SfDev {
@@ -97,7 +107,7 @@ struct SfDev {
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
     uint8_t *candOk;             // [slots][flagStride]
-    uint8_t *fused;              // [slots][flagStride] seed consumed by a fusion
+    uint8_t *fused;              // [slots][flagStride] 1: seed consumed by a fusion; 2: invalid candidate (kb_seed_plane); 0: the seed spawns a surfel
     uint2 *tex;                  // [slots][npx] {depth bits, final superpixel index} of every pixel: k_fuse's ONE gather per in-view surfel
     float4 *fuseRec;             // [slots][3][nseeds] what k_fuse needs of a seed (FuseRec, msl_sf_superpixel.hip), three planes of 16-byte words
     unsigned short *index, *amap;  // [slots][npx]

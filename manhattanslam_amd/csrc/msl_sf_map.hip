@@ -31,7 +31,8 @@ __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void set_wide_flag(const MapSoA &M, unsigned long long bit) { atomicOr(reinterpret_cast<unsigned long long *>(M.wideFlag), bit); }
+__device__ __forceinline__ void set_wide_flag_ptr(long long *flag, unsigned long long bit) { atomicOr(reinterpret_cast<unsigned long long *>(flag), bit); }
+__device__ __forceinline__ void set_wide_flag(const MapSoA &M, unsigned long long bit) { set_wide_flag_ptr(M.wideFlag, bit); }
 // updateTimes / lastUpdate of a record whose packed word is tl (the side array only for HOT_WIDE: rare)
 __device__ __forceinline__ void tl_unpack(const MapSoA &M, long long i, unsigned tl, int &ut, int &lu) {
     ut = (int)(tl >> 20); lu = (int)(tl & 0xFFFFFu);
@@ -138,37 +139,34 @@ __device__ __forceinline__ void st16(void *p, u32x4 v) {
 // what only the few frontier waves of a deferred launch need (the previous keyframe's candidate arrays) stays in memory (DeferCtl::emit).
 struct FuseFrame {
     float inv[12];   // rows 0..2 of pose.inverse(), inv[3 c + r] = invPose[4 c + r] (the fourth row is never used)
-    float rot[9];    // rotation of the pose, rot[3 c + r] = pose[4 c + r]
     int ref;
+    const FrameDev *frame;   // the keyframe's device record: the pose itself (only the update path of phase B rotates a normal back into the world)
 };
 struct FuseArgs {
     int W, H, nseeds, kf;          // kf: keyframe number inside a deferred window (its launch materialises the new surfels of kf - 1 first)
     int prevSlot, _pad;            // superpixel slot of keyframe kf - 1, counted from the first slot of the handle (DeferCtl holds the array bases)
     float fx, fy, cx, cy, fuseFar, fuseNear;
     const uint2 *tex; const float4 *fuseRec; uint8_t *fused;   // this keyframe's slot
-    MapSoA map;
-    unsigned long long cap;
+    HotPk *hot; ColdRec *cold;
     long long *ctr;
-    unsigned *blockSums;           // classic only (deleted slots per sub-block)
-    unsigned *blockUpd;            // updated surfels per sub-block (deferred: the keyframe's slice)
-    unsigned *delOut;              // classic: delU[LIST_D], the hand-over list of k_compact; deferred: the window's deletion log
-    unsigned *delUCount;           // classic only
-    DeferCtl *dc;                  // deferred only
+    DeferCtl *dc;                  // extents and deletion counts of a deferred window; and what only a few waves per launch need (DeferCtl::aux):
+                                   // side arrays of wide records, deletion lists, capacity -- loaded where they are used instead of living in scalar
+                                   // registers through the whole kernel
 };
 __host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
     FuseArgs A;
     A.W = P.W; A.H = P.H; A.nseeds = P.nseeds; A.kf = P.kf; A.prevSlot = P.prevSlotAbs; A._pad = 0;
     A.fx = P.fx; A.fy = P.fy; A.cx = P.cx; A.cy = P.cy; A.fuseFar = P.fuseFar; A.fuseNear = P.fuseNear;
     A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
-    A.map = P.map; A.cap = P.cap; A.ctr = P.ctr;
-    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd; A.delOut = deferred ? P.delList : P.delU; A.delUCount = P.delUCount; A.dc = P.dc;
+    A.hot = P.map.hot; A.cold = P.map.cold; A.ctr = P.ctr;
+    A.dc = P.dc;
+    (void)deferred;
     return A;
 }
-__host__ inline FuseFrame fuse_frame(const FrameDev &F) {
+__host__ inline FuseFrame fuse_frame(const FrameDev &F, const FrameDev *dev) {
     FuseFrame f;
     for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) f.inv[3 * c + r] = F.invPose[4 * c + r];
-    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) f.rot[3 * c + r] = F.pose[4 * c + r];
-    f.ref = F.ref;
+    f.ref = F.ref; f.frame = dev;
     return f;
 }
 // mul4 / mul3 of msl_sf.h on the packed rows: the same products and the same association
@@ -184,32 +182,38 @@ __device__ __forceinline__ void mul3r(const float *m, float v0, float v1, float 
 // ---- new surfels of the previous keyframe, materialised by the fuse launch that follows it (deferred compaction) ----------------------
 // initializeSurfels (:285-331): every seed whose candidate is valid and that no fusion consumed spawns a surfel, in seed order.  New surfel
 // k of the keyframe before (slot P.prevSlot) goes to the physical slot E0 + k (E0 = the extent that keyframe's fuse launch worked on).  A "frontier"
-// wave -- one whose sub-block reaches beyond E0 -- scans the flag bytes of the whole lattice (lane l owns the `per` consecutive seeds from
-// l * per on; candOk / fused hold 0 / 1, zero padding behind the lattice), and writes the records that fall into ITS sub-block; it then fuses them
-// like any others.  Returns K, the keyframe's number of new surfels.  All 64 lanes must call it.
-__device__ __forceinline__ unsigned spawn_word(unsigned cw, unsigned fw) { return cw & ~fw & 0x01010101u; }
-__device__ __forceinline__ unsigned emit_pending(const FuseArgs &P, long long E0, long long sb, unsigned lane) {
+// wave -- one whose sub-block reaches beyond E0 -- scans the `fused` bytes of the whole lattice (lane l owns the `per` consecutive seeds from
+// l * per on).  A seed spawns iff its byte is 0: kb_seed_init clears it, kb_seed_plane sets 2 where the candidate is invalid (candOk = 0), a
+// fusion sets 1; the padding behind the lattice holds 1.  The wave writes the records that fall into ITS sub-block and then fuses them like any
+// others.  All 64 lanes must call these.
+__device__ __forceinline__ unsigned spawn_word(unsigned fw) { return ~(fw | (fw >> 1)) & 0x01010101u; }   // one bit per byte that is 0
+// Pass 1: this lane's number of spawning seeds; the wave-wide exclusive prefix and the total K come from one scan.
+__device__ __forceinline__ unsigned spawn_count(const FuseArgs &P, unsigned lane, unsigned &excl) {
     const DeferCtl *dc = P.dc;
     const int fs = dc->flagStride;
-    const uint8_t *candOk = dc->candOk + (size_t)P.prevSlot * fs, *fusedP = dc->fused + (size_t)P.prevSlot * fs;   // of keyframe kf - 1
+    const uint8_t *fusedP = dc->fused + (size_t)P.prevSlot * fs;   // of keyframe kf - 1
     const int per = fs >> 6, nch = per >> 4;   // seeds per lane (a multiple of 16), 16-byte words per lane
     unsigned cnt = 0;
-    {
-        const uint4 *cq = reinterpret_cast<const uint4 *>(candOk + (size_t)lane * per), *fq = reinterpret_cast<const uint4 *>(fusedP + (size_t)lane * per);
-        for (int c = 0; c < nch; c += 3) {   // three words of each array per trip: 24 transient registers
-            uint4 a[3], b[3];
+    const uint4 *fq = reinterpret_cast<const uint4 *>(fusedP + (size_t)lane * per);
+    for (int c = 0; c < nch; c += 5) {   // five words per trip (640 x 480: the whole lattice in ONE round trip, beside the wave's hot records)
+        uint4 b[5];
 #pragma unroll
-            for (int q = 0; q < 3; q++) { const int cc = min(c + q, nch - 1); a[q] = cq[cc]; b[q] = fq[cc]; }
+        for (int q = 0; q < 5; q++) b[q] = fq[min(c + q, nch - 1)];
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-                if (c + q < nch)
-                    cnt += (unsigned)(__popc(spawn_word(a[q].x, b[q].x)) + __popc(spawn_word(a[q].y, b[q].y)) + __popc(spawn_word(a[q].z, b[q].z)) + __popc(spawn_word(a[q].w, b[q].w)));
-        }
+        for (int q = 0; q < 5; q++)
+            if (c + q < nch) cnt += (unsigned)(__popc(spawn_word(b[q].x)) + __popc(spawn_word(b[q].y)) + __popc(spawn_word(b[q].z)) + __popc(spawn_word(b[q].w)));
     }
-    const unsigned incl = wave_incl_scan(cnt), excl = incl - cnt;
-    const unsigned K = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    if (K == 0) return 0;
-    if ((sb + 1) * SUB_ITEMS <= E0 || sb * SUB_ITEMS >= E0 + (long long)K) return K;   // none of them lands in this sub-block
+    const unsigned incl = wave_incl_scan(cnt);
+    excl = incl - cnt;
+    return (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+}
+// Pass 2 (only when the keyframe spawned something that lands in this sub-block): slot i of the sub-block takes new surfel k = i - E0; its seed is
+// the (k - excl[owner])-th spawning seed of the lane whose range contains it.
+__device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, long long sb, unsigned lane, unsigned K, unsigned excl) {
+    const DeferCtl *dc = P.dc;
+    const int fs = dc->flagStride;
+    const uint8_t *fusedP = dc->fused + (size_t)P.prevSlot * fs;
+    const int per = fs >> 6, nch = per >> 4;
     const msl_surfel *cand = dc->cand + (size_t)P.prevSlot * P.nseeds;
 #pragma unroll 1
     for (int j = 0; j < SUB_ITEMS / 64; j++) {
@@ -226,10 +230,10 @@ __device__ __forceinline__ unsigned emit_pending(const FuseArgs &P, long long E0
         }
         unsigned r = k - eLo;   // the r-th spawning seed of lane `lo`'s range
         int seed = -1;
-        const uint4 *oc = reinterpret_cast<const uint4 *>(candOk + (size_t)lo * per), *of = reinterpret_cast<const uint4 *>(fusedP + (size_t)lo * per);
+        const uint4 *of = reinterpret_cast<const uint4 *>(fusedP + (size_t)lo * per);
         for (int c = 0; c < nch; c++) {
-            const uint4 a = oc[c], b = of[c];
-            const unsigned w[4] = {spawn_word(a.x, b.x), spawn_word(a.y, b.y), spawn_word(a.z, b.z), spawn_word(a.w, b.w)};
+            const uint4 b = of[c];
+            const unsigned w[4] = {spawn_word(b.x), spawn_word(b.y), spawn_word(b.z), spawn_word(b.w)};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const unsigned pc = (unsigned)__popc(w[q]);
@@ -243,12 +247,12 @@ __device__ __forceinline__ unsigned emit_pending(const FuseArgs &P, long long E0
             }
         }
         if (on && seed >= 0) {
-            if ((unsigned long long)i < P.cap) store_surfel(P.map, i, cand[seed]);
-            else P.ctr[5] = 20;   // capacity exceeded (the host reserves nseeds slots per keyframe: never happens)
+            if ((unsigned long long)i < dc->aux.cap) store_surfel(dc->aux.map, i, cand[seed]);
+            else { long long code = 20; asm volatile("" : "+v"(code)); P.ctr[5] = code; }   // capacity exceeded (the host reserves nseeds slots per keyframe: never
+                                                                                          // happens; the constant is kept out of the loop-invariant registers)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave reads these records back right away
-    return K;
 }
 
 // k_fuse (:167-283): ONE WAVE per sub-block of 256 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever a
@@ -269,7 +273,8 @@ __device__ __forceinline__ unsigned emit_pending(const FuseArgs &P, long long E0
 //   surfels of keyframe kf - 1 behind the array (emit_pending, frontier waves only) and works on the extent that results.
 template <bool DEFER>
 __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F, int nSubHint, unsigned waveIdx, int G) {
-    const MapSoA &M = P.map;
+    struct { HotPk *hot; ColdRec *cold; } M = {P.hot, P.cold};
+    const FuseAux *aux = &P.dc->aux;
     const unsigned lane0 = threadIdx.x;
     const uint2 *tex = P.tex;
     const float4 *fuseRec = P.fuseRec;
@@ -303,24 +308,36 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         asm volatile("" : "+v"(lane));
         const long long c0 = sb * SUB_ITEMS;
         long long n = 0;
-        bool frontier = false;
+#define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
+        const long long rel = c0 - E0;   // (everything in terms of this difference: E0 + nseeds would be one more loop-invariant register pair)
         if (pending) {
-            if (c0 >= E0 + P.nseeds) return;   // beyond anything keyframe kf - 1 can have spawned
-            frontier = c0 + SUB_ITEMS > E0;
-            if (frontier) {
-                n = E0 + (long long)emit_pending(P, E0, sb, lane);
+            if (rel >= (long long)P.nseeds) return;   // beyond anything keyframe kf - 1 can have spawned
+            n = E0;   // (not a frontier wave: every record of this sub-block lies below the extent)
+            if (rel + SUB_ITEMS > 0) {
+                // A frontier wave: it needs the new surfels of keyframe kf - 1 first.  One word of each of its hot records is requested now and only
+                // consumed behind the flag scan -- the records' cache lines travel beside the flag words and wait in the caches for the loads proper
+                // below, so that in the steady state (nothing spawned) the scan costs this wave, the first of the launch and the one with the most
+                // survivors, a cache hit instead of a round trip.  (Plain loads the compiler counts: a load hidden in inline asm would break its
+                // s_waitcnt accounting for the flag words.)
+                unsigned pf[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) pf[k] = M.hot[c0 + REC_LOCAL(k)].tl;
+                unsigned excl;
+                const unsigned K = spawn_count(P, lane, excl);
+                asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+                n = E0 + (long long)K;
                 if (sb == (E0 >> 8) && lane == 0) P.dc->ext[P.kf] = n;   // (exactly one sub-block contains E0)
                 if (c0 >= n) return;
-            } else n = E0;   // every record of this sub-block lies below the extent
+                if (K) emit_records(P, E0, sb, lane, K, excl);
+            }
         } else if (sb >= nSubHint && c0 >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         // lane l owns records l, 64 + l, 128 + l, 192 + l of the sub-block: the survivors' rank order (k, lane) is then the array order, so
         // neighbouring lanes of phase B work on neighbouring records and their gathers and stores share cache lines
-#define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
         HotPk hq[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) hq[k] = M.hot[c0 + REC_LOCAL(k)];
         if (!pending) n = P.ctr[0];
-        int state[4];      // 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
+        unsigned stp = 0;  // two bits per record: 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
         float pzv[4];
         unsigned offT[4];
 #pragma unroll
@@ -331,7 +348,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             int ut = (int)(tl >> 20), lu = (int)(tl & 0xFFFFFu);
             bool hole = false;
             if (__builtin_expect(__ballot(tl >> 31) != 0ull, 0)) {   // rare: exact ints in the side array / a slot the window has logged already
-                if (tl == HOT_WIDE) { ut = M.utlWide[2 * i]; lu = M.utlWide[2 * i + 1]; }
+                if (tl == HOT_WIDE) { const int *w = aux->map.utlWide; ut = w[2 * i]; lu = w[2 * i + 1]; }
                 else if (tl & 0x80000000u) hole = true;
             }
             float pc[3];
@@ -343,7 +360,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
             int st = 0;
             if (i < n && !hole) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
-            state[k] = st; pzv[k] = pc[2];
+            stp |= (unsigned)st << (2 * k); pzv[k] = pc[2];
             const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
             offT[k] = (unsigned)(pVc * P.W + pUc);
         }
@@ -354,18 +371,19 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         // round trip back into up to four dependent ones
         asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
         // ---- classification: deletions of phase A, survivors ----
-        bool del[4], surv[4];
-        unsigned long long mdel[4];
+        // (one bit field per lane instead of eight lane masks: the masks would live in scalar registers, which this kernel is short of)
+        unsigned fl = 0;   // bit k: record k deleted in phase A; bit 4 + k: record k survives into phase B
         unsigned cntDel = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool occluded = state[k] == 3 && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
-            del[k] = state[k] == 1 || state[k] == 2 || occluded;
-            if (DEFER) { if (del[k]) M.hot[c0 + REC_LOCAL(k)].tl = HOT_HOLE; }
-            else if (state[k] == 1 || occluded) hot_mark_deleted(M, c0 + REC_LOCAL(k), hq[k].tl);
-            surv[k] = state[k] == 3 && !occluded;
-            mdel[k] = __ballot(del[k]);
-            cntDel += (unsigned)__popcll(mdel[k]);
+            const unsigned st = (stp >> (2 * k)) & 3u;
+            const bool occluded = st == 3u && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
+            const bool del = st == 1u || st == 2u || occluded;
+            if (DEFER) { if (del) M.hot[c0 + REC_LOCAL(k)].tl = HOT_HOLE; }
+            else if (st == 1u || occluded) hot_mark_deleted(aux->map, c0 + REC_LOCAL(k), M.hot[c0 + REC_LOCAL(k)].tl);   // (rare: the word is read again rather than kept)
+            fl |= del ? (1u << k) : 0u;
+            fl |= (st == 3u && !occluded) ? (16u << k) : 0u;
+            cntDel += (unsigned)__popcll(__ballot(del));
         }
         // deleted slots: classic -> delU (k_compact's fast path), deferred -> the window's log behind the entries of the keyframes before
         auto list_base = [&](unsigned c) -> unsigned {
@@ -376,7 +394,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                 if (lane == 0) b2 = atomicAdd(&P.dc->delCnt[P.kf], c);
                 base += (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
             } else {
-                if (lane == 0) base = atomicAdd(P.delUCount, c);
+                if (lane == 0) base = atomicAdd(aux->delUCount, c);
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
             }
             return base;
@@ -384,23 +402,28 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {
             if (d) {
                 const unsigned j = base + lane_rank(m);
-                if (DEFER ? j < P.cap : j < (unsigned)LIST_D) P.delOut[j] = (unsigned)i;
+                if (DEFER ? j < aux->cap : j < (unsigned)LIST_D) (DEFER ? aux->delList : aux->delU)[j] = (unsigned)i;
             }
         };
         if (cntDel) {   // rare: a handful of slots per keyframe
             unsigned base = list_base(cntDel);
 #pragma unroll
-            for (int k = 0; k < 4; k++) { hand_over(del[k], mdel[k], base, c0 + REC_LOCAL(k)); base += (unsigned)__popcll(mdel[k]); }
+            for (int k = 0; k < 4; k++) {
+                const bool d = (fl >> k) & 1u;
+                const unsigned long long m = __ballot(d);
+                hand_over(d, m, base, c0 + REC_LOCAL(k)); base += (unsigned)__popcll(m);
+            }
         }
         // ---- survivors -> (round, lane): one push per k.  word = local index, valid bit, superpixel << 16 ----
         unsigned rcv[4], bk[4];
         unsigned total = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long m = __ballot(surv[k]);
+            const bool sv = (fl >> (4 + k)) & 1u;
+            const unsigned long long m = __ballot(sv);
             const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
-            const unsigned dest = (surv[k] ? total + rs : total + c + (lane - rs)) & 63u;
-            const unsigned payload = surv[k] ? (REC_LOCAL(k) | 0x100u | (tx[k].y << 16)) : 0u;
+            const unsigned dest = (sv ? total + rs : total + c + (lane - rs)) & 63u;
+            const unsigned payload = sv ? (REC_LOCAL(k) | 0x100u | (tx[k].y << 16)) : 0u;
             rcv[k] = (unsigned)__builtin_amdgcn_ds_permute((int)(dest * 4u), (int)payload);
             bk[k] = total;
             total += c;
@@ -438,7 +461,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                     mul3r(F.inv, c.nx, c.ny, c.nz, nc);
                     const float normDiffCos = nc[0] * f0.x + nc[1] * f0.y + nc[2] * f0.z;
                     if (normDiffCos < MAX_ANGLE_COS) {
-                        if (DEFER) M.hot[i].tl = HOT_HOLE; else hot_mark_deleted(M, i, h.tl);
+                        if (DEFER) M.hot[i].tl = HOT_HOLE; else hot_mark_deleted(aux->map, i, h.tl);
                         delB = true;
                     } else {
                         const float oldWeight = c.weight;
@@ -455,10 +478,17 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                         const float newNormLength = sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
                         fusedNx = fusedNx / newNormLength; fusedNy = fusedNy / newNormLength; fusedNz = fusedNz / newNormLength;
                         float newNormW[3];
-                        mul3r(F.rot, fusedNx, fusedNy, fusedNz, newNormW);
+                        mul3(F.frame->pose, fusedNx, fusedNy, fusedNz, newNormW);
                         int ut = (int)(h.tl >> 20);   // (a survivor is never a hole; HOT_WIDE: the side array)
-                        if (__builtin_expect(h.tl == HOT_WIDE, 0)) ut = M.utlWide[2 * i];
-                        const unsigned tlNew = tl_store_word(M, i, ut + 1, ref);   // updateTimes + 1, lastUpdate = reference index (:275-276)
+                        if (__builtin_expect(h.tl == HOT_WIDE, 0)) ut = aux->map.utlWide[2 * i];
+                        unsigned tlNew = tl_pack(ut + 1, ref);             // updateTimes + 1, lastUpdate = reference index (:275-276)
+                        if (__builtin_expect(!tl_fits(ut + 1, ref), 0)) {   // rare: exact ints to the side array (pointers fetched one at a time: no register tuples in a cold path)
+                            int *w = aux->map.utlWide;
+                            w[2 * i] = ut + 1; w[2 * i + 1] = ref;
+                            asm volatile("" ::: "memory");
+                            set_wide_flag_ptr(aux->map.wideFlag, 2ull);
+                            tlNew = HOT_WIDE;
+                        }
                         c.rgbf = __float_as_uint(f2.z);                    // r, g, b of the seed (bytes: never COLD_WIDE)
                         c.nx = newNormW[0]; c.ny = newNormW[1]; c.nz = newNormW[2];
                         c.weight = sumWeight;
@@ -484,12 +514,12 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                 cntDelB += cb;
             }
         }
-        if (lane == 0) {
-            if (!DEFER) P.blockSums[sb] = cntDel + cntDelB;
-            P.blockUpd[sb] = nupd;
+        if (lane == 0) {   // per-sub-block counts: deleted (classic: the slow paths of k_compact, the host-vector download), updated (deferred: the keyframe's slice)
+            if (!DEFER) aux->blockSums[sb] = cntDel + cntDelB;
+            aux->blockUpd[(size_t)(DEFER ? P.kf : 0) * aux->blkStride + sb] = nupd;
         }
         // (normally) nothing beyond the grid; a deferred launch decides at the head of the loop (the new surfels may reach into the next sub-block)
-        if ((sb + G) * SUB_ITEMS >= (pending ? E0 + (long long)P.nseeds : n)) return;
+        if (pending ? rel + (long long)G * SUB_ITEMS >= (long long)P.nseeds : (sb + G) * SUB_ITEMS >= n) return;
     }
 #undef REC_LOCAL
 }
@@ -787,6 +817,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
 //   workgroups 0 .. F - 1          : the updated-surfel count of keyframe f (sum of its per-sub-block counts) -> running total, ctr[3] for the last
 //   workgroups F .. F + NFRONT - 1 : the new surfels of the LAST keyframe (there is no next fuse launch to materialise them)
 __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, unsigned blkStride) {   // A.kf = F
+    __builtin_amdgcn_s_setprio(3);
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x < F) {
         const int f = (int)blockIdx.x;
@@ -804,8 +835,10 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
     const long long E0 = P.dc->ext[F - 1];
     const long long q = (long long)blockIdx.x - F, sb = (E0 >> 8) + q;
     if (sb * SUB_ITEMS >= E0 + P.nseeds) return;
-    const unsigned K = emit_pending(A, E0, sb, lane);
+    unsigned excl;
+    const unsigned K = spawn_count(A, lane, excl);
     if (q == 0 && lane == 0) P.dc->ext[F] = E0 + (long long)K;
+    if (K && sb * SUB_ITEMS < E0 + (long long)K) emit_records(A, E0, sb, lane, K, excl);
 }
 
 // k_replay: the window's F compactions, replayed symbolically by ONE wave.
@@ -820,72 +853,135 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
 // k_compact resolves it: the a-th smallest leftover hole below the new end receives resolve(nFinal + a).  At the end every virtual position
 // whose element is not already in that physical slot becomes one move (source, destination); k_gather / k_scatter apply them.
 // All table traffic is agent-scope (L2): one wave, but its own stores must be what its later loads see.
-constexpr int RP_SORT = 2048;
-__global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
-    __shared__ __attribute__((aligned(16))) unsigned s_v[RP_SORT + 4];
-    __shared__ unsigned s_d[RP_SORT];
-    __shared__ long long s_ext[DEFER_WIN + 1], s_runV[DEFER_WIN];
-    __shared__ unsigned s_runK0[DEFER_WIN], s_runCnt[DEFER_WIN];
+constexpr int RP_SORT = 1024;          // deleted positions of one keyframe ordered in the LDS up to here
+constexpr int RP_HASH = 2048;          // slots of the LDS tables (explicit placements of a window with <= RP_HASH / 2 deletions in all)
+constexpr unsigned RP_EMPTY = 0xFFFFFFFFu;
+struct ReplayLds {
+    unsigned v[RP_SORT + 4], d[RP_SORT];                      // a keyframe's deleted positions: as logged, ascending
+    long long ext[DEFER_WIN + 1], runV[DEFER_WIN];
+    unsigned runK0[DEFER_WIN], runCnt[DEFER_WIN];
+    unsigned dcnt[DEFER_WIN];                                 // deletions per keyframe
+    unsigned log[RP_HASH / 2];                                // LDS mode: the whole window's deletion log (fetched in one trip)
+    unsigned locK[RP_HASH], locV[RP_HASH], vposK[RP_HASH], vposV[RP_HASH];   // LDS tables (open addressing; locV = element + 1 | stamp << 26)
+};
+__device__ __forceinline__ unsigned rp_hash(unsigned key) { return (key * 2654435761u) >> 21; }   // 11 bits
+static_assert(RP_HASH == 2048, "rp_hash yields 11 bits");
+
+// LDS = true: the window's explicit placements live in two LDS hash tables (few deletions: the steady state; no global round trips inside the
+// keyframe loop).  LDS = false: dense global tables indexed by position / element (any number of deletions; agent-scope accesses).
+template <bool LDS>
+__device__ __forceinline__ void replay_body(const SfDev &P, int F, ReplayLds &S) {
     const unsigned lane = threadIdx.x;
     DeferCtl *dc = P.dc;
-    if ((int)lane <= F) s_ext[lane] = dc->ext[lane];
-    if (lane < DEFER_WIN) { s_runCnt[lane] = 0; s_runV[lane] = 0; s_runK0[lane] = 0; }
-    __syncthreads();
-    const long long n0 = s_ext[0];
+    const long long n0 = S.ext[0];
     long long n = n0;
     unsigned nLocKeys = 0, nVposKeys = 0, logBase = 0;
     long long totK = 0, totD = 0, totNb = 0, lastK = 0, lastD = 0, lastNb = 0;
+    // ---- the two tables: virtual position -> (element, stamp), element -> virtual position ----
+    auto loc_get = [&](unsigned p, unsigned &elem, unsigned &stampOut) -> bool {
+        if constexpr (LDS) {
+            for (unsigned s = rp_hash(p);; s = (s + 1) & (RP_HASH - 1)) {
+                const unsigned k = S.locK[s];
+                if (k == RP_EMPTY) return false;
+                if (k == p) { const unsigned v = S.locV[s]; elem = (v & 0x3FFFFFFu) - 1u; stampOut = v >> 26; return true; }
+            }
+        } else {
+            const unsigned long long v = ld_agent64(&P.loc64[p]);
+            if (!v) return false;
+            elem = (unsigned)v - 1u; stampOut = (unsigned)(v >> 32);
+            return true;
+        }
+    };
+    auto vpos_get = [&](unsigned id, unsigned &pos) -> bool {
+        if constexpr (LDS) {
+            for (unsigned s = rp_hash(id);; s = (s + 1) & (RP_HASH - 1)) {
+                const unsigned k = S.vposK[s];
+                if (k == RP_EMPTY) return false;
+                if (k == id) { pos = S.vposV[s]; return true; }
+            }
+        } else {
+            const unsigned v = ld_agent(&P.vposD[id]);
+            if (!v) return false;
+            pos = v - 1u;
+            return true;
+        }
+    };
+    // explicit placement (all lanes call; `on` lanes place): element `elem` now sits at virtual position `pos`
+    auto put = [&](bool on, unsigned pos, unsigned elem, unsigned stampNo) {
+        if constexpr (LDS) {
+            if (on) {
+                unsigned s = rp_hash(pos);
+                for (;; s = (s + 1) & (RP_HASH - 1)) { const unsigned old = atomicCAS(&S.locK[s], RP_EMPTY, pos); if (old == RP_EMPTY || old == pos) break; }
+                S.locV[s] = (elem + 1u) | (stampNo << 26);
+                s = rp_hash(elem);
+                for (;; s = (s + 1) & (RP_HASH - 1)) { const unsigned old = atomicCAS(&S.vposK[s], RP_EMPTY, elem); if (old == RP_EMPTY || old == elem) break; }
+                S.vposV[s] = pos;
+            }
+        } else {
+            if (on) { st_agent64(&P.loc64[pos], (unsigned long long)(elem + 1u) | ((unsigned long long)stampNo << 32)); st_agent(&P.vposD[elem], pos + 1u); }
+            const unsigned long long m = __ballot(on);
+            if (on) { const unsigned r = lane_rank(m); st_agent(&P.locKeys[nLocKeys + r], pos); st_agent(&P.vposKeys[nVposKeys + r], elem); }
+            nLocKeys += (unsigned)__popcll(m); nVposKeys += (unsigned)__popcll(m);
+        }
+    };
+    auto tables_sync = [&]() {   // a keyframe's (or phase's) table stores are complete before anything reads them
+        if constexpr (LDS) __syncthreads();
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+    };
+    unsigned runMask = 0;   // bit g: keyframe g appended a run that still has entries (uniform)
     auto vpos_of = [&](unsigned id) -> unsigned {
-        const unsigned v = ld_agent(&P.vposD[id]);
-        if (v) return v - 1;
+        unsigned pos;
+        if (vpos_get(id, pos)) return pos;
         if ((long long)id < n0) return id;
         int g = 0;
-        for (int q = 1; q < F; q++) if ((long long)id >= s_ext[q]) g = q;   // the keyframe that spawned it
-        return (unsigned)(s_runV[g] + ((long long)id - s_ext[g] - (long long)s_runK0[g]));
+        for (int q = 1; q < F; q++) if ((long long)id >= S.ext[q]) g = q;   // the keyframe that spawned it
+        return (unsigned)(S.runV[g] + ((long long)id - S.ext[g] - (long long)S.runK0[g]));
     };
     // newest run covering p: its keyframe (-1: none) and element
     auto run_of = [&](long long p, int upto, unsigned &elem) -> int {
-        for (int g = upto; g >= 0; g--) {
-            const long long v0 = s_runV[g];
-            if (s_runCnt[g] && p >= v0 && p < v0 + (long long)s_runCnt[g]) { elem = (unsigned)(s_ext[g] + (long long)s_runK0[g] + (p - v0)); return g; }
+        for (unsigned m = upto >= 31 ? runMask : (runMask & ((2u << upto) - 1u)); m;) {   // (newest first; the steady state has no runs at all)
+            const int g = 31 - __builtin_clz(m);
+            m &= ~(1u << g);
+            const long long v0 = S.runV[g];
+            if (p >= v0 && p < v0 + (long long)S.runCnt[g]) { elem = (unsigned)(S.ext[g] + (long long)S.runK0[g] + (p - v0)); return g; }
         }
         return -1;
     };
     auto loc_of = [&](long long p, int upto) -> unsigned {
-        const unsigned long long v = ld_agent64(&P.loc64[p]);
-        unsigned er = 0;
+        unsigned ee = 0, st = 0, er = 0;
+        const bool have = loc_get((unsigned)p, ee, st);
         const int g = run_of(p, upto, er);
-        if (v && (g < 0 || (unsigned)(v >> 32) > (unsigned)(g + 1))) return (unsigned)v - 1u;
+        if (have && (g < 0 || st > (unsigned)(g + 1))) return ee;
         return g >= 0 ? er : (unsigned)p;
     };
     for (int f = 0; f < F; f++) {
-        const unsigned D = (unsigned)__builtin_amdgcn_readfirstlane((int)ld_agent(&dc->delCnt[f]));
-        const long long K = s_ext[f + 1] - s_ext[f];
-        const unsigned long long stamp = (unsigned long long)(f + 1) << 32;
+        const unsigned D = S.dcnt[f];
+        const long long K = S.ext[f + 1] - S.ext[f];
+        const unsigned stampNo = (unsigned)(f + 1);
         const bool inLds = D <= (unsigned)RP_SORT;
         lastK = K; lastD = D; lastNb = n; totK += K; totD += D; totNb += n;
         // ---- 1. virtual positions of the logged slots ----
         for (unsigned j0 = 0; j0 < D; j0 += 64) {
             const unsigned j = j0 + lane;
             if (j < D) {
-                const unsigned vp = vpos_of(ld_agent(&P.delList[logBase + j]));
-                if (inLds) s_v[j] = vp;
+                const unsigned vp = vpos_of(LDS ? S.log[logBase + j] : ld_agent(&P.delList[logBase + j]));
+                if (inLds) S.v[j] = vp;
                 else atomicOr(&P.bitmap[vp >> 5], 1u << (vp & 31u));
             }
         }
-        if (inLds && lane < 4) s_v[D + lane] = 0xFFFFFFFFu;   // padding of the last 16-byte read
+        if (inLds && lane < 4) S.v[D + lane] = 0xFFFFFFFFu;   // padding of the last 16-byte read
         __syncthreads();
         // ---- 2. ascending order ----
         if (inLds) {
             for (unsigned j0 = 0; j0 < D; j0 += 64) {
                 const unsigned j = j0 + lane;
-                const unsigned v = j < D ? s_v[j] : 0u;
+                const unsigned v = j < D ? S.v[j] : 0u;
                 unsigned r = 0;
                 for (unsigned q = 0; q < D; q += 4) {   // (the positions are distinct: the ranks are a permutation)
-                    const uint4 x = *reinterpret_cast<const uint4 *>(&s_v[q]);
+                    const uint4 x = *reinterpret_cast<const uint4 *>(&S.v[q]);
                     r += (x.x < v ? 1u : 0u) + (x.y < v ? 1u : 0u) + (x.z < v ? 1u : 0u) + (x.w < v ? 1u : 0u);
                 }
-                if (j < D) s_d[r] = v;
+                if (j < D) S.d[r] = v;
             }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -904,27 +1000,22 @@ __global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        auto DL = [&](long long j) -> unsigned { return inLds ? s_d[j] : ld_agent(&P.dBig[j]); };
-        auto put = [&](bool on, long long pos, unsigned elem) {   // explicit placement: element `elem` now sits at virtual position `pos`
-            if (on) { st_agent64(&P.loc64[pos], (unsigned long long)(elem + 1u) | stamp); st_agent(&P.vposD[elem], (unsigned)pos + 1u); }
-            const unsigned long long m = __ballot(on);
-            if (on) { const unsigned r = lane_rank(m); st_agent(&P.locKeys[nLocKeys + r], (unsigned)pos); st_agent(&P.vposKeys[nVposKeys + r], elem); }
-            nLocKeys += (unsigned)__popcll(m); nVposKeys += (unsigned)__popcll(m);
-        };
+        auto DL = [&](long long j) -> unsigned { return inLds ? S.d[j] : ld_agent(&P.dBig[j]); };
         // ---- 3. new surfel k -> k-th largest hole (SurfelMapping.cpp:372-384) ----
         const long long nPl = K < (long long)D ? K : (long long)D;
         for (long long k0 = 0; k0 < nPl; k0 += 64) {
             const long long k = k0 + lane;
             const bool on = k < nPl;
-            put(on, on ? (long long)DL((long long)D - 1 - k) : 0, (unsigned)(s_ext[f] + k));
+            put(on, on ? DL((long long)D - 1 - k) : 0u, (unsigned)(S.ext[f] + k), stampNo);
         }
         if (K > (long long)D) {   // the others are appended: a run
-            if (lane == 0) { s_runV[f] = n; s_runK0[f] = D; s_runCnt[f] = (unsigned)(K - (long long)D); }
+            if (lane == 0) { S.runV[f] = n; S.runK0[f] = D; S.runCnt[f] = (unsigned)(K - (long long)D); }
+            runMask |= 1u << f;
             n += K - (long long)D;
         } else if ((long long)D > K) {
             // ---- 4. leftover holes: the back-to-front loop of :386-390, per hole ----
             const long long R = (long long)D - K, nFinal = n - R;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (a tail source may be a surfel placed just above)
+            tables_sync();   // (a tail source may be a surfel placed just above)
             auto lower = [&](long long x) -> long long {   // first index in the R smallest holes with value >= x
                 long long lo = 0, hi = R;
                 while (lo < hi) { const long long mid = (lo + hi) >> 1; if ((long long)DL(mid) < x) lo = mid + 1; else hi = mid; }
@@ -944,18 +1035,23 @@ __global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
                     }
                 }
                 const unsigned e = on ? loc_of(p, f) : 0u;
-                put(on, on ? (long long)DL(a) : 0, e);
+                if constexpr (LDS) __syncthreads();   // (every lane has read the tables before this chunk's placements go in: a destination < nFinal is never a source, but slots move)
+                put(on, on ? DL(a) : 0u, e, stampNo);
             }
             __syncthreads();
-            if ((int)lane <= f && s_runCnt[lane] && s_runV[lane] + (long long)s_runCnt[lane] > nFinal)
-                s_runCnt[lane] = s_runV[lane] >= nFinal ? 0u : (unsigned)(nFinal - s_runV[lane]);
+            if (runMask) {   // runs that reach beyond the new end are clipped
+                bool gone = false;
+                if ((int)lane <= f && ((runMask >> lane) & 1u) && S.runV[lane] + (long long)S.runCnt[lane] > nFinal) {
+                    S.runCnt[lane] = S.runV[lane] >= nFinal ? 0u : (unsigned)(nFinal - S.runV[lane]);
+                    gone = S.runCnt[lane] == 0;
+                }
+                runMask &= ~(unsigned)__ballot(gone);
+            }
             n = nFinal;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the keyframe's table stores are complete before the next one reads
-        __syncthreads();
+        tables_sync();
         logBase += D;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- the moves: every virtual position whose element is not already in that physical slot ----
     const long long nF = n;
     unsigned nMoves = 0;
@@ -965,38 +1061,82 @@ __global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
         nMoves += (unsigned)__popcll(m);
     };
     for (int g = 0; g < F; g++) {   // appended runs first, while the explicit table is intact
-        const unsigned cnt = s_runCnt[g];
+        const unsigned cnt = ((runMask >> g) & 1u) ? S.runCnt[g] : 0u;
         for (unsigned q0 = 0; q0 < cnt; q0 += 64) {
             const unsigned q = q0 + lane;
             bool on = q < cnt;
-            const long long p = s_runV[g] + q;
-            const unsigned id = (unsigned)(s_ext[g] + (long long)s_runK0[g] + q);
-            if (on) { const unsigned long long v = ld_agent64(&P.loc64[p]); if (v && (unsigned)(v >> 32) > (unsigned)(g + 1)) on = false; }   // a later explicit placement owns p
+            const long long p = S.runV[g] + q;
+            const unsigned id = (unsigned)(S.ext[g] + (long long)S.runK0[g] + q);
+            unsigned ee = 0, st = 0;
+            if (on && loc_get((unsigned)p, ee, st) && st > (unsigned)(g + 1)) on = false;   // a later explicit placement owns p
             if (on && (long long)id == p) on = false;
             add_move(on, (unsigned)p, id);
         }
     }
-    for (unsigned j0 = 0; j0 < nLocKeys; j0 += 64) {   // explicit placements (a position may be listed more than once: cleared at its first visit)
-        const unsigned j = j0 + lane;
-        bool on = j < nLocKeys;
-        const unsigned p = on ? ld_agent(&P.locKeys[j]) : 0u;
-        const unsigned long long v = on ? ld_agent64(&P.loc64[p]) : 0ull;
-        on = on && v != 0ull;
-        if (on) st_agent64(&P.loc64[p], 0ull);
+    // explicit placements: a stale one (a later run covers its position) or one beyond the final end is dropped
+    auto explicit_move = [&](bool on, unsigned p, unsigned id, unsigned st) {
         unsigned er = 0;
-        if (on) { const int g = run_of((long long)p, F - 1, er); if (g >= 0 && (unsigned)(g + 1) > (unsigned)(v >> 32)) on = false; }   // stale: a later run covers p
+        if (on) { const int g = run_of((long long)p, F - 1, er); if (g >= 0 && (unsigned)(g + 1) > st) on = false; }
         if (on && (long long)p >= nF) on = false;
-        const unsigned id = (unsigned)v - 1u;
         if (on && id == p) on = false;
         add_move(on, p, id);
+    };
+    if constexpr (LDS) {
+        for (unsigned s0 = 0; s0 < (unsigned)RP_HASH; s0 += 64) {
+            const unsigned k = S.locK[s0 + lane], v = S.locV[s0 + lane];
+            explicit_move(k != RP_EMPTY, k, (v & 0x3FFFFFFu) - 1u, v >> 26);
+        }
+    } else {
+        for (unsigned j0 = 0; j0 < nLocKeys; j0 += 64) {   // (a position may be listed more than once: cleared at its first visit)
+            const unsigned j = j0 + lane;
+            bool on = j < nLocKeys;
+            const unsigned p = on ? ld_agent(&P.locKeys[j]) : 0u;
+            const unsigned long long v = on ? ld_agent64(&P.loc64[p]) : 0ull;
+            on = on && v != 0ull;
+            if (on) st_agent64(&P.loc64[p], 0ull);
+            explicit_move(on, p, (unsigned)v - 1u, (unsigned)(v >> 32));
+        }
+        for (unsigned j0 = 0; j0 < nVposKeys; j0 += 64) { const unsigned j = j0 + lane; if (j < nVposKeys) st_agent(&P.vposD[ld_agent(&P.vposKeys[j])], 0u); }
     }
-    for (unsigned j0 = 0; j0 < nVposKeys; j0 += 64) { const unsigned j = j0 + lane; if (j < nVposKeys) st_agent(&P.vposD[ld_agent(&P.vposKeys[j])], 0u); }
     if (lane < DEFER_WIN) dc->delCnt[lane] = 0;   // the next window starts with empty logs
     if (lane == 0) {
         dc->nMoves = nMoves;
         P.ctr[0] = nF; P.ctr[1] = lastK; P.ctr[2] = lastD; P.ctr[4] = lastNb; P.ctr[6] = nF;
         P.ctr[8] += totK; P.ctr[9] += totD; P.ctr[11] += F; P.ctr[12] += totNb;
     }
+}
+
+// k_replay: the window's F compactions, replayed symbolically by ONE wave.
+// Elements are named by their PHYSICAL slot (nothing moved during the window): base elements 0 .. n0 - 1, the k-th new surfel of keyframe
+// f = ext[f] + k.  The reference's array ("virtual" order) differs from the identity only where a compaction put something:
+//   loc   : virtual position -> element, with the keyframe (stamp) that put it there      -- only explicit placements
+//   vpos  : element -> virtual position                                                   -- only elements placed explicitly
+//   run f : the new surfels of keyframe f that were APPENDED: elements ext[f] + k0 + q at virtual positions runV + q, q < runCnt
+// (a run is clipped when a later keyframe shortens the array; where a run and an explicit entry both cover a position the later stamp wins).
+// Per keyframe: virtual positions of the logged slots -> ascending (LDS rank sort; a bitmap over the positions beyond RP_SORT entries) ->
+// new surfel k to the k-th largest hole, else appended (SurfelMapping.cpp:372-384) -> if holes remain, the back-to-front loop (:386-390) as
+// k_compact resolves it: the a-th smallest leftover hole below the new end receives resolve(nFinal + a).  At the end every virtual position
+// whose element is not already in that physical slot becomes one move (source, destination); k_gather / k_scatter apply them.
+// Checked against the literal loop by a host model of exactly this scheme (tests/test_replay_model.py) and by the GPU parity tests.
+__global__ __launch_bounds__(64) void k_replay(SfDev P, int F) {
+    __shared__ __attribute__((aligned(16))) ReplayLds S;
+    __builtin_amdgcn_s_setprio(3);   // one wave on the latency-critical map stream, next to the throughput-oriented batched kernels
+    const unsigned lane = threadIdx.x;
+    DeferCtl *dc = P.dc;
+    if ((int)lane <= F) S.ext[lane] = dc->ext[lane];
+    if (lane < DEFER_WIN) { S.runCnt[lane] = 0; S.runV[lane] = 0; S.runK0[lane] = 0; }
+    const unsigned dmine = (int)lane < F ? ld_agent(&dc->delCnt[lane]) : 0u;
+    if (lane < DEFER_WIN) S.dcnt[lane] = dmine;
+    const unsigned dsum = wave_incl_scan(dmine);
+    const unsigned totalD = (unsigned)__builtin_amdgcn_readlane((int)dsum, 63);
+    const bool useLds = totalD <= (unsigned)RP_HASH / 2 && P.cap < (1ull << 26) - 1;
+    if (useLds) {
+        for (unsigned j = lane; j < totalD; j += 64) S.log[j] = ld_agent(&P.delList[j]);   // (all requests leave together)
+        for (unsigned s = lane; s < (unsigned)RP_HASH; s += 64) { S.locK[s] = RP_EMPTY; S.vposK[s] = RP_EMPTY; }
+    }
+    __syncthreads();
+    if (useLds) replay_body<true>(P, F, S);
+    else replay_body<false>(P, F, S);
 }
 
 // The window's moves: all sources first (a destination may be another move's source), then all destinations.
@@ -1149,7 +1289,7 @@ namespace sf {
 
 void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred) {
     const FuseArgs A = fuse_args(P, slot, deferred);
-    const FuseFrame FF = fuse_frame(F);
+    const FuseFrame FF = fuse_frame(F, P.frames + slot);
     if (deferred) MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<true>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
     else MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<false>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
 }

@@ -957,6 +957,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const bool valid = !(S.viewCos < MAX_ANGLE_COS) && !(S.normX == 0 && S.normY == 0 && S.normZ == 0);
     const bool ok = valid && !(S.meanDepth == 0);
     P.candOk[(size_t)slot * P.flagStride + seedI] = ok ? 1 : 0;
+    if (!ok) P.fused[(size_t)slot * P.flagStride + seedI] = 2;   // "spawns nothing" for the deferred map stage's one-array scan (kb_seed_init cleared the byte; a fusion writes 1)
     float pw[4] = {0, 0, 0, 0};
     float seedWeight = 0, seedSize = 0;
     if (valid) {

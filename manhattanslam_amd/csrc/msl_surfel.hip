@@ -64,8 +64,14 @@ struct msl_sf {
     // up whatever has arrived, so the bound follows the real count a couple of batches late instead of forcing a pipeline drain
     // every capacity / nseeds keyframes
     static constexpr int NSNAP = 4;
+    static constexpr int SNAPW = 16;   // counters per snapshot: ctr[0 .. 15]
     long long *h_snap = nullptr; hipEvent_t snapEv[NSNAP] = {}; unsigned long long snapKf[NSNAP] = {}; bool snapBusy[NSNAP] = {};
+    bool snapLive[NSNAP] = {};   // the snapshot's live count still describes the resident map (no upload / restore since it was taken)
     unsigned long long kfEnq = 0; int snapNext = 0;
+    // churn = surfels spawned + deleted per keyframe over the most recent batch the host has seen (from the running totals of two snapshots):
+    // the deferred compaction is built for the steady state (a replay by ONE wave per window); under heavy churn the classic chain, whose
+    // compaction works with all its workgroups, is faster
+    long long churnNew = -1, churnDel = 0, churnKf = 0; unsigned long long churnAt = 0; double churn = 0.0;
     unsigned *d_blockSums = nullptr, *d_blockUpd = nullptr, *d_delList = nullptr, *d_srcOf = nullptr;
     msl_surfel *d_aos = nullptr; size_t aosCap = 0;
     float *d_snapStore = nullptr; size_t snapCap = 0, snapN = 0; bool snapValid = false; long long snapWide = 0;   // msl_sf_map_snapshot / _restore
@@ -105,13 +111,27 @@ void set_map_ptrs(msl_sf *h) {
 // The asynchronous live-count snapshots only ever LOWER liveBound; whenever the map is replaced from outside the keyframe chain
 // (upload, restore) the ones still pending describe the old map and must be ignored.
 void drop_live_snapshots(msl_sf *h) {
-    for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;
+    for (int i = 0; i < msl_sf::NSNAP; i++) h->snapLive[i] = false;   // (their running totals -- the churn estimate -- stay valid)
 }
 
 int sync_all(msl_sf *h) {
     if (h->ownStreams && h->copyStream) MSL_HIP_TRY(hipStreamSynchronize(h->copyStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
+    return MSL_OK;
+}
+
+// The device-side control block of the map stage: bases of the slot arrays and of the map's side arrays / lists (what only a few waves of a
+// k_fuse launch read).  Rewritten whenever one of them is reallocated; the streams are idle then, and the window state it also holds
+// (extents, deletion counts) is all zero between windows.
+int write_ctl(msl_sf *h) {
+    DeferCtl dc;
+    memset(&dc, 0, sizeof(dc));
+    const SfDev &D = h->dev;
+    dc.flagStride = D.flagStride; dc.candOk = h->d_candOk; dc.fused = h->d_fused; dc.cand = h->d_cand;
+    dc.aux.map = D.map; dc.aux.cap = D.cap; dc.aux.delU = D.delU; dc.aux.delUCount = D.delUCount; dc.aux.delList = D.delList;
+    dc.aux.blockSums = D.blockSums; dc.aux.blockUpd = D.blockUpd; dc.aux.blkStride = h->blkStride;
+    MSL_HIP_TRY(hipMemcpy(h->d_dc, &dc, sizeof(dc), hipMemcpyHostToDevice));
     return MSL_OK;
 }
 
@@ -160,7 +180,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_rpStore = nrp; h->mapCap = cap;
     h->blkStride = bst;
     set_map_ptrs(h);
-    return MSL_OK;
+    return write_ctl(h);
 }
 
 void free_slots(msl_sf *h) {
@@ -199,17 +219,12 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     MSL_HIP_TRY(hipMalloc(&h->d_changed, sizeof(int) * 8 * slots));
     MSL_HIP_TRY(hipMemset(h->d_seeds, 0, sizeof(msl_seed) * ns * slots));
     MSL_HIP_TRY(hipMemset(h->d_index, 0, sizeof(unsigned short) * npx * slots));
-    MSL_HIP_TRY(hipMemset(h->d_fused, 0, fs * slots));     // (the bytes behind the lattice stay 0: the map stage scans whole 16-byte words)
+    MSL_HIP_TRY(hipMemset(h->d_fused, 1, fs * slots));     // (the bytes behind the lattice stay 1 = "spawns nothing": the map stage scans whole 16-byte words)
     MSL_HIP_TRY(hipMemset(h->d_candOk, 0, fs * slots));
     D.frames = h->d_frames; D.seeds = h->d_seeds; D.seedsTmp = h->d_seedsTmp; D.cand = h->d_cand; D.candOk = h->d_candOk; D.fused = h->d_fused; D.tex = h->d_tex; D.fuseRec = h->d_fuseRec;
     D.index = h->d_index; D.amap = h->d_amap; D.tmin = h->d_tmin; D.chunkAbort = h->d_chunkAbort; D.changed = h->d_changed;
     D.arec = h->d_arec + 1; D.pxInv = h->d_pxInv; D.wl = h->d_wl; D.wlCount = h->d_wlCount;
-    {   // what the deferred map stage needs of the slot arrays (static until the next reallocation)
-        DeferCtl dc;
-        memset(&dc, 0, sizeof(dc));
-        dc.flagStride = D.flagStride; dc.candOk = h->d_candOk; dc.fused = h->d_fused; dc.cand = h->d_cand;
-        MSL_HIP_TRY(hipMemcpy(h->d_dc, &dc, sizeof(dc), hipMemcpyHostToDevice));
-    }
+    { const int rc = write_ctl(h); if (rc != MSL_OK) return rc; }
     h->maxBatch = maxBatch;
     h->lastSlot = 0;            // the debug accessors must never index beyond the reallocated slot buffers
     h->evMapValid[0] = h->evMapValid[1] = false;
@@ -258,9 +273,16 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         for (int i = 0; i < msl_sf::NSNAP; i++)
             if (h->snapBusy[i] && hipEventQuery(h->snapEv[i]) == hipSuccess) {
                 h->snapBusy[i] = false;
-                const size_t cand = (size_t)h->h_snap[i] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
-                if (cand < h->liveBound) h->liveBound = cand;
-                if (h->snapKf[i] >= h->liveKnownKf) { h->liveKnown = (size_t)h->h_snap[i]; h->liveKnownKf = h->snapKf[i]; }   // completed snapshots are visited in array order, not age order
+                const long long *sn = h->h_snap + (size_t)i * msl_sf::SNAPW;
+                if (h->snapLive[i]) {
+                    const size_t cand = (size_t)sn[0] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
+                    if (cand < h->liveBound) h->liveBound = cand;
+                    if (h->snapKf[i] >= h->liveKnownKf) { h->liveKnown = (size_t)sn[0]; h->liveKnownKf = h->snapKf[i]; }   // completed snapshots are visited in array order, not age order
+                }
+                if (h->snapKf[i] > h->churnAt) {   // running totals: new ctr[8], deleted ctr[9], keyframes ctr[11]
+                    if (h->churnNew >= 0 && sn[11] > h->churnKf) h->churn = (double)((sn[8] - h->churnNew) + (sn[9] - h->churnDel)) / (double)(sn[11] - h->churnKf);
+                    h->churnNew = sn[8]; h->churnDel = sn[9]; h->churnKf = sn[11]; h->churnAt = h->snapKf[i];
+                }
             }
         if (h->liveBound + need > h->mapCap) {
             int rc = read_ctr(h);
@@ -357,28 +379,32 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     const int nSubHint = (int)(known / SUB_ITEMS);
     // Map stage.  Deferred compaction (the default for resident batches; MSL_SF_DEFER=0 turns it off): windows of <= DEFER_WIN keyframes, ONE
     // launch per keyframe, the window's compactions replayed at its end (msl_sf_map.hip).  Classic (k_fuse + k_compact per keyframe): single
-    // keyframes, the host-vector drop-in, and the first keyframe after the map was replaced from outside -- k_compact takes any number of stale
-    // or deleted slots with all its workgroups, the replay's single wave is built for the steady state.
-    static const bool deferOff = getenv("MSL_SF_DEFER") && !strcmp(getenv("MSL_SF_DEFER"), "0");
+    // keyframes, the host-vector drop-in, the first keyframe after the map was replaced from outside, and batches enqueued while the recent
+    // churn (spawned + deleted surfels per keyframe, from the asynchronous counter snapshots) is high -- k_compact takes any number of stale or
+    // deleted slots with all its workgroups, the replay's single wave is built for the steady state.  Both leave identical maps.
+    static const char *deferEnv = getenv("MSL_SF_DEFER");   // "0": never; "1": always (tests); unset: unless the recent churn is high
+    static const bool deferOff = deferEnv && !strcmp(deferEnv, "0"), deferForce = deferEnv && !strcmp(deferEnv, "1");
+    constexpr double CHURN_MAX = 96.0;   // spawned + deleted surfels per keyframe up to which the one-wave replay beats k_compact (bench.py --map moving: 670)
+    const bool churny = !deferForce && h->churn > CHURN_MAX;
     auto classic = [&](int f) {
-        P.kf = 0; P.blockUpd = D.blockUpd;
+        P.kf = 0;
         map_launch_fuse(h->prof, sm, P, f, h->h_frames[slot0 + f], nSubGrid, nSubHint, false);
         map_launch_compact(h->prof, sm, P, f, compact);
     };
     int f = 0;
     const int fProbe = n / 2;   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
-    if (!compact || deferOff || n < 2) {
+    if (!compact || deferOff || churny || n < 2) {
         for (; f < n; f++) { classic(f); if (f == fProbe) map_launch_empty_pair(h->prof, sm); }
     } else {
         if (h->classicNext) { classic(0); f = 1; if (fProbe == 0) map_launch_empty_pair(h->prof, sm); }
         while (f < n) {
             const int w = std::min(DEFER_WIN, n - f);
             for (int q = 0; q < w; q++) {
-                P.kf = q; P.prevSlotAbs = slot0 + f + q - 1; P.blockUpd = D.blockUpd + (size_t)q * h->blkStride;
+                P.kf = q; P.prevSlotAbs = slot0 + f + q - 1;
                 map_launch_fuse(h->prof, sm, P, f + q, h->h_frames[slot0 + f + q], nSubGrid, nSubHint, true);
                 if (f + q == fProbe) map_launch_empty_pair(h->prof, sm);
             }
-            P.kf = w; P.prevSlotAbs = slot0 + f + w - 1; P.blockUpd = D.blockUpd;
+            P.kf = w; P.prevSlotAbs = slot0 + f + w - 1;
             map_launch_replay(h->prof, sm, P, w, (unsigned)h->blkStride);
             f += w;
         }
@@ -388,9 +414,9 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     if (compact && h->h_snap) {   // snapshot of the live count after this batch (picked up by a later call, never waited for)
         const int i = h->snapNext;
         if (!h->snapBusy[i]) {
-            MSL_HIP_TRY(hipMemcpyAsync(&h->h_snap[i], h->d_ctr, sizeof(long long), hipMemcpyDeviceToHost, sm));
+            MSL_HIP_TRY(hipMemcpyAsync(h->h_snap + (size_t)i * msl_sf::SNAPW, h->d_ctr, sizeof(long long) * msl_sf::SNAPW, hipMemcpyDeviceToHost, sm));
             MSL_HIP_TRY(hipEventRecord(h->snapEv[i], sm));
-            h->snapKf[i] = h->kfEnq; h->snapBusy[i] = true; h->snapNext = (i + 1) % msl_sf::NSNAP;
+            h->snapKf[i] = h->kfEnq; h->snapBusy[i] = true; h->snapLive[i] = true; h->snapNext = (i + 1) % msl_sf::NSNAP;
         }
     }
     MSL_HIP_TRY(hipGetLastError());
@@ -432,7 +458,7 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     ok = ok && hipMalloc(&h->d_ctr, sizeof(long long) * 32) == hipSuccess;   // 16 counters (read_ctr) + [16..18] the published live counts
     ok = ok && hipMemset(h->d_ctr, 0, sizeof(long long) * 32) == hipSuccess;
     ok = ok && hipHostMalloc(&h->h_ctr, sizeof(long long) * 16) == hipSuccess;
-    ok = ok && hipHostMalloc(&h->h_snap, sizeof(long long) * msl_sf::NSNAP) == hipSuccess;
+    ok = ok && hipHostMalloc(&h->h_snap, sizeof(long long) * msl_sf::NSNAP * msl_sf::SNAPW) == hipSuccess;
     for (int i = 0; i < msl_sf::NSNAP && ok; i++) ok = hipEventCreateWithFlags(&h->snapEv[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc(&h->d_new, sizeof(msl_surfel) * D.nseeds) == hipSuccess;
     ok = ok && hipMalloc(&h->d_tickets, sizeof(unsigned) * 8) == hipSuccess && hipMemset(h->d_tickets, 0, sizeof(unsigned) * 8) == hipSuccess;   // [0..1] tickets, [3] change-list length, [4..6] the rotating hand-over counts
@@ -870,7 +896,7 @@ int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {
     MSL_HIP_TRY(hipMemcpy(out, h->d_seeds + ns * h->lastSlot, sizeof(msl_seed) * ns, hipMemcpyDeviceToHost));
     std::vector<uint8_t> fused(ns);
     MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + (size_t)h->dev.flagStride * h->lastSlot, ns, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < ns; i++) out[i].fused = fused[i];
+    for (size_t i = 0; i < ns; i++) out[i].fused = fused[i] & 1;   // (2 = invalid candidate, not a fusion)
     return MSL_OK;
 }
 int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {

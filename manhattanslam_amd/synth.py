@@ -388,6 +388,28 @@ def surfel_map_dense(n, ref=0, seed=11, w=640, h=480, intr=TUM1, scene=None, k_l
     return m
 
 
+MOVING_STEP = 8        # "moving" regime: keyframe f looks along camera_pose(8 f): a 4 degree pan per keyframe, 256 degrees over 64 keyframes
+MOVING_PERIOD = 10.0   # degrees of azimuth: the pre-seeded map lacks MOVING_HOLE degrees of every MOVING_PERIOD (ahead of the first view)
+MOVING_HOLE = 4.0
+
+
+def surfel_map_moving(n, ref=0, seed=11, w=640, h=480, intr=TUM1, scene=None, n_keyframes=64, **kw):
+    """The pre-seeded map of the moving-camera regime: surfel_map_dense over the whole sweep of keyframes MOVING_STEP * (0 .. n_keyframes - 1)
+    (so that about a third of it is in view all along), with vertical stripes of the room left UNMAPPED ahead of the first view: the surfels
+    whose azimuth about the room centre falls into the first MOVING_HOLE degrees of every MOVING_PERIOD are removed.  A pan then meets what a
+    real one meets (src/SurfelFusion.cpp:285-331, src/SurfelMapping.cpp:366-391): every keyframe the strip entering the image holds
+    superpixels that no surfel projects into -- they spawn new surfels, a hundred or more per keyframe --, and the flipped / floating
+    surfels of the mapped stripes that enter are deleted, about as many; holes are refilled, the tail moves, the array grows."""
+    k_hi = MOVING_STEP * (n_keyframes - 1) + 128
+    m = surfel_map_dense(int(n * MOVING_PERIOD / (MOVING_PERIOD - 0.8 * MOVING_HOLE)), ref=ref, seed=seed, w=w, h=h, intr=intr, scene=scene, k_lo=-150, k_hi=k_hi, **kw)
+    az = np.rad2deg(np.arctan2(m["px"].astype(np.float64), m["pz"].astype(np.float64)))     # camera_pose(k) looks along azimuth 0.5 k degrees
+    first_view = 0.5 * np.rad2deg(2 * np.arctan(0.5 * w / abs(intr["fx"])))
+    ahead = (az - first_view) % 360.0
+    hole = ((ahead % MOVING_PERIOD) < MOVING_HOLE) & (ahead < 0.5 * k_hi + 40.0) & (((az + 180.0) % 360.0 - 180.0) > first_view)
+    m = m[~hole]
+    return m[:n] if len(m) >= n else m
+
+
 def in_view_fraction(m, k, w=640, h=480, intr=TUM1, near=0.5, far=30.0):
     """Share of the surfels m that keyframe k's fuse step finds in range and inside the image (src/SurfelFusion.cpp:196-207)."""
     T = np.linalg.inv(_pose_matrix(k))
@@ -413,16 +435,20 @@ def bench_inputs(rank, D, n_surfels, W, H, intr, variant="A", dropout=0.02, need
     sc = clutter_scene() if scene == "clutter" else ROOM_ONLY
     grays, depths, poses = [], [], []
     member = None
+    kstep = MOVING_STEP if map_kind == "moving" else 1
     for f in range(D):
         if scene == "clutter":
-            g, depth, member, pose, _ = clutter_frame(f, w=W, h=H, intr=intr, seed=sd["frame"], scene=sc)
+            g, depth, member, pose, _ = clutter_frame(kstep * f, w=W, h=H, intr=intr, seed=sd["frame"], scene=sc)
         else:
-            g, depth, member, pose = surfel_frame(f, w=W, h=H, intr=intr, variant=variant, seed=sd["frame"], dropout=dropout)
+            g, depth, member, pose = surfel_frame(kstep * f, w=W, h=H, intr=intr, variant=variant, seed=sd["frame"], dropout=dropout)
         # one gray image per frame, used by both stages: the textured ORB frame (the wall checker alone has too few corners)
         grays.append(orb_frame(sd["orb"] + f, W, H) if need_orb_texture else g)
         depths.append(depth)
         poses.append(pose)
-    if map_kind == "dense":
+    if map_kind == "moving":
+        # (three times the flipped / floating shares of the stationary map: the deletions of a keyframe come from the mapped stripes that ENTER the view)
+        smap = surfel_map_moving(n_surfels, ref=0, seed=sd["map"], w=W, h=H, intr=intr, scene=sc, n_keyframes=D, flip=3 * flip, floating=3 * floating, min_update_times=5)
+    elif map_kind == "dense":
         smap = surfel_map_dense(n_surfels, ref=0, seed=sd["map"], w=W, h=H, intr=intr, scene=sc, flip=flip, floating=floating, min_update_times=5,
                                 order=map_order)
     else:

@@ -185,3 +185,40 @@ def test_dense_in_view_full_size_map_batched_matches_oracle(oracle, order):
     c = g.counters()
     assert c["n_live_after"] == len(mo) and c["n_updated"] > 250_000, c
     g.close()
+
+
+def test_moving_camera_full_size_map_matches_oracle(oracle):
+    """The moving-camera regime of `bench.py --map moving` at full size (round 5): 1 M live surfels, a 4 degree pan per keyframe over a dense map with
+    unmapped stripes, 64 keyframes in two calls of 32 -- i.e. two deferred-compaction windows behind a classic first keyframe.  Every keyframe spawns
+    and deletes hundreds of surfels (initializeSurfels, hole refill, tail moves, array growth: src/SurfelFusion.cpp:285-331,
+    src/SurfelMapping.cpp:366-391); the map after each call and the running totals are the oracle's, keyframe by keyframe."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    nkf, B = 64, 32
+    gray, depth, member, poses, m = synth.bench_inputs(0, nkf, 1_000_000, 640, 480, synth.TUM1, map_kind="moving", need_orb_texture=False)
+    m = m.astype(SURFEL_DTYPE)
+    assert 0.12 < synth.in_view_fraction(m, synth.MOVING_STEP * 20) < 0.4
+    g.set_batch_capacity(B)
+    g.map_reserve(len(m) + 400_000)
+    g.map_upload(m); o.map_set(m)
+    c0 = g.debug_ctr()
+    n_before = len(m)
+    new_tot = del_tot = 0
+    for call in range(nkf // B):
+        refs = np.arange(call * B, call * B + B)
+        sl = slice(call * B, call * B + B)
+        g.fuse_resident_batch(refs, gray[sl], depth[sl], member, poses[sl], member_shared=True)
+        for k in range(call * B, call * B + B):
+            o.fuse_map(k, gray[k], depth[k], member, poses[k])
+            mo_k = o.map_get()
+            spawned = int(((mo_k["updateTimes"] == 1) & (mo_k["lastUpdate"] == k)).sum())
+            new_tot += spawned; del_tot += spawned - (len(mo_k) - n_before)
+            n_before = len(mo_k)
+        assert_surfels_close(g.map_download(), o.map_get(), f"moving map after call {call}")
+    c1 = g.debug_ctr()
+    kf = int(c1[11] - c0[11])
+    assert kf == nkf
+    # (a surfel spawned and deleted within one keyframe cannot happen, so the oracle-side counts are exact)
+    assert int(c1[8] - c0[8]) == new_tot and int(c1[9] - c0[9]) == del_tot, (c1[8] - c0[8], new_tot, c1[9] - c0[9], del_tot)
+    assert new_tot / nkf >= 100 and (del_tot - 12000) / nkf >= 100, (new_tot / nkf, del_tot / nkf)   # surfels_new_per_keyframe >= 100 (and as many deletions beyond the first view's)
+    g.close()

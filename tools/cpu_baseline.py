@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-surfel", action="store_true")
     ap.add_argument("--keyframe-every", type=int, default=1)
-    ap.add_argument("--map", default="dense", choices=["dense", "sparse"])
+    ap.add_argument("--map", default="dense", choices=["dense", "sparse", "moving"])
     ap.add_argument("--map-order", default="creation", choices=["creation", "random"])
     ap.add_argument("--scene", default="room", choices=["room", "clutter"])
     args = ap.parse_args()

@@ -3,7 +3,7 @@
 # WRITE_SIZE passes), kernel statistics of configurations 2-5, the SQ counter groups, and the bench lines of the same build (default with its
 # CPU baseline, configurations 2-5 with theirs, the 8 M-surfel run whose map exceeds the 256 MB Infinity Cache).
 # Usage: tools/profile_all.sh <tag>
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 tools/profile.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
@@ -25,8 +25,10 @@ python bench.py --map-order random --cpu-frames 0 --steps 8 > gpurun_out/bench_$
 python bench.py --sequences-per-gpu 2 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_two_sequences.json 2> gpurun_out/bench_${TAG}_two_sequences.err
 python bench.py --config 3 --map sparse --cpu-frames 0 --steps 8 > gpurun_out/bench_${TAG}_config3_sparse.json 2> gpurun_out/bench_${TAG}_config3_sparse.err
 MSL_PEAC_CLUSTER=device python bench.py --config 4 --cpu-frames 0 --steps 4 --no-breakdown > gpurun_out/bench_${TAG}_config4_device_cluster.json 2> gpurun_out/bench_${TAG}_config4_device_cluster.err
-# round 4: the opt-in merged launch (one wave compacts keyframe j - 1 inside keyframe j's fuse launch), SurfelFusion alone on both maps
-MSL_SF_MERGED=1 python bench.py --config 3 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_merged.json 2> gpurun_out/bench_${TAG}_config3_merged.err
-MSL_SF_MERGED=1 python bench.py --config 3 --map sparse --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_sparse_merged.json 2> gpurun_out/bench_${TAG}_config3_sparse_merged.err
+# round 5: the classic two-launch chain instead of the deferred compaction, SurfelFusion alone and the whole front end; the moving-camera regime
+MSL_SF_DEFER=0 python bench.py --config 3 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_classic.json 2> gpurun_out/bench_${TAG}_config3_classic.err
+MSL_SF_DEFER=0 python bench.py --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_classic.json 2> gpurun_out/bench_${TAG}_classic.err
+python bench.py --map moving --cpu-frames 0 --steps 8 > gpurun_out/bench_${TAG}_moving.json 2> gpurun_out/bench_${TAG}_moving.err
+python bench.py --config 3 --map moving --cpu-frames 0 --steps 8 > gpurun_out/bench_${TAG}_config3_moving.json 2> gpurun_out/bench_${TAG}_config3_moving.err
 ls gpurun_out/prof_$TAG gpurun_out/pmc_$TAG | head -20
 for f in gpurun_out/bench_$TAG*.json; do echo $f; tail -c 300 $f; echo; done
