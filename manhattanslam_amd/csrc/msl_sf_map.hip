@@ -140,6 +140,9 @@ __device__ __forceinline__ void st16(void *p, u32x4 v) {
 struct FuseFrame {
     float inv[12];   // rows 0..2 of pose.inverse(), inv[3 c + r] = invPose[4 c + r] (the fourth row is never used)
     int ref;
+#ifdef MSL_FUSE_KARG_POSE
+    float rot[9];
+#endif
     const FrameDev *frame;   // the keyframe's device record: the pose itself (only the update path of phase B rotates a normal back into the world)
 };
 struct FuseArgs {
@@ -149,6 +152,9 @@ struct FuseArgs {
     const uint2 *tex; const float4 *fuseRec; uint8_t *fused;   // this keyframe's slot
     HotPk *hot; ColdRec *cold;
     long long *ctr;
+#ifdef MSL_FUSE_KARG_BLK
+    unsigned *blockSums, *blockUpd;
+#endif
     DeferCtl *dc;                  // extents and deletion counts of a deferred window; and what only a few waves per launch need (DeferCtl::aux):
                                    // side arrays of wide records, deletion lists, capacity -- loaded where they are used instead of living in scalar
                                    // registers through the whole kernel
@@ -160,6 +166,9 @@ __host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
     A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
     A.hot = P.map.hot; A.cold = P.map.cold; A.ctr = P.ctr;
     A.dc = P.dc;
+#ifdef MSL_FUSE_KARG_BLK
+    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd + (size_t)(deferred ? P.kf : 0) * (P.cap / SUB_ITEMS + 4100);
+#endif
     (void)deferred;
     return A;
 }
@@ -167,6 +176,9 @@ __host__ inline FuseFrame fuse_frame(const FrameDev &F, const FrameDev *dev) {
     FuseFrame f;
     for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) f.inv[3 * c + r] = F.invPose[4 * c + r];
     f.ref = F.ref; f.frame = dev;
+#ifdef MSL_FUSE_KARG_POSE
+    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) f.rot[3 * c + r] = F.pose[4 * c + r];
+#endif
     return f;
 }
 // mul4 / mul3 of msl_sf.h on the packed rows: the same products and the same association
@@ -209,15 +221,15 @@ __device__ __forceinline__ unsigned spawn_count(const FuseArgs &P, unsigned lane
 }
 // Pass 2 (only when the keyframe spawned something that lands in this sub-block): slot i of the sub-block takes new surfel k = i - E0; its seed is
 // the (k - excl[owner])-th spawning seed of the lane whose range contains it.
-__device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, long long sb, unsigned lane, unsigned K, unsigned excl) {
+__device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, long long c0, int nj, unsigned lane, unsigned K, unsigned excl) {
     const DeferCtl *dc = P.dc;
     const int fs = dc->flagStride;
     const uint8_t *fusedP = dc->fused + (size_t)P.prevSlot * fs;
     const int per = fs >> 6, nch = per >> 4;
     const msl_surfel *cand = dc->cand + (size_t)P.prevSlot * P.nseeds;
 #pragma unroll 1
-    for (int j = 0; j < SUB_ITEMS / 64; j++) {
-        const long long i = sb * SUB_ITEMS + 64 * j + lane, kS = i - E0;
+    for (int j = 0; j < nj; j++) {
+        const long long i = c0 + 64 * j + lane, kS = i - E0;
         const bool on = kS >= 0 && kS < (long long)K;
         const unsigned k = on ? (unsigned)kS : 0u;
         // owner: the last lane whose exclusive prefix is <= k (its inclusive prefix then exceeds k)
@@ -273,6 +285,10 @@ __device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, lo
 //   surfels of keyframe kf - 1 behind the array (emit_pending, frontier waves only) and works on the extent that results.
 template <bool DEFER>
 __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F, int nSubHint, unsigned waveIdx, int G) {
+    constexpr int KPL = SUB_ITEMS / 64;        // records per lane; a wave owns WSPAN = SUB_ITEMS consecutive surfels (2 per lane, twice the waves: k_fuse itself
+                                               // 1.4 us shorter alone and 2.8 us in the timed region, the front end 4 % slower -- the per-wave overhead is VALU time
+                                               // the frame-batched kernels lose)
+    constexpr long long WSPAN = 64 * KPL;
     struct { HotPk *hot; ColdRec *cold; } M = {P.hot, P.cold};
     const FuseAux *aux = &P.dc->aux;
     const unsigned lane0 = threadIdx.x;
@@ -306,42 +322,42 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         // loop and kept in registers / scratch for its whole body)
         unsigned lane = lane0;
         asm volatile("" : "+v"(lane));
-        const long long c0 = sb * SUB_ITEMS;
+        const long long c0 = sb * WSPAN;
         long long n = 0;
 #define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
         const long long rel = c0 - E0;   // (everything in terms of this difference: E0 + nseeds would be one more loop-invariant register pair)
         if (pending) {
             if (rel >= (long long)P.nseeds) return;   // beyond anything keyframe kf - 1 can have spawned
             n = E0;   // (not a frontier wave: every record of this sub-block lies below the extent)
-            if (rel + SUB_ITEMS > 0) {
+            if (rel + WSPAN > 0) {
                 // A frontier wave: it needs the new surfels of keyframe kf - 1 first.  One word of each of its hot records is requested now and only
                 // consumed behind the flag scan -- the records' cache lines travel beside the flag words and wait in the caches for the loads proper
                 // below, so that in the steady state (nothing spawned) the scan costs this wave, the first of the launch and the one with the most
                 // survivors, a cache hit instead of a round trip.  (Plain loads the compiler counts: a load hidden in inline asm would break its
                 // s_waitcnt accounting for the flag words.)
-                unsigned pf[4];
+                unsigned pf[KPL];
 #pragma unroll
-                for (int k = 0; k < 4; k++) pf[k] = M.hot[c0 + REC_LOCAL(k)].tl;
+                for (int k = 0; k < KPL; k++) pf[k] = M.hot[c0 + REC_LOCAL(k)].tl;
                 unsigned excl;
                 const unsigned K = spawn_count(P, lane, excl);
-                asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+                for (int k = 0; k < KPL; k++) asm volatile("" ::"v"(pf[k]));
                 n = E0 + (long long)K;
-                if (sb == (E0 >> 8) && lane == 0) P.dc->ext[P.kf] = n;   // (exactly one sub-block contains E0)
+                if (c0 <= E0 && lane == 0) P.dc->ext[P.kf] = n;   // (exactly one sub-block contains E0)
                 if (c0 >= n) return;
-                if (K) emit_records(P, E0, sb, lane, K, excl);
+                if (K) emit_records(P, E0, c0, KPL, lane, K, excl);
             }
         } else if (sb >= nSubHint && c0 >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
         // lane l owns records l, 64 + l, 128 + l, 192 + l of the sub-block: the survivors' rank order (k, lane) is then the array order, so
         // neighbouring lanes of phase B work on neighbouring records and their gathers and stores share cache lines
-        HotPk hq[4];
+        HotPk hq[KPL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) hq[k] = M.hot[c0 + REC_LOCAL(k)];
+        for (int k = 0; k < KPL; k++) hq[k] = M.hot[c0 + REC_LOCAL(k)];
         if (!pending) n = P.ctr[0];
         unsigned stp = 0;  // two bits per record: 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
-        float pzv[4];
-        unsigned offT[4];
+        float pzv[KPL];
+        unsigned offT[KPL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < KPL; k++) {
             const long long i = c0 + REC_LOCAL(k);
             const float x = hq[k].px, y = hq[k].py, z = hq[k].pz;
             const unsigned tl = hq[k].tl;
@@ -364,9 +380,9 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
             offT[k] = (unsigned)(pVc * P.W + pUc);
         }
-        uint2 tx[4];
+        uint2 tx[KPL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) tx[k] = tex[offT[k]];
+        for (int k = 0; k < KPL; k++) tx[k] = tex[offT[k]];
         // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
         // round trip back into up to four dependent ones
         asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
@@ -375,7 +391,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         unsigned fl = 0;   // bit k: record k deleted in phase A; bit 4 + k: record k survives into phase B
         unsigned cntDel = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < KPL; k++) {
             const unsigned st = (stp >> (2 * k)) & 3u;
             const bool occluded = st == 3u && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
             const bool del = st == 1u || st == 2u || occluded;
@@ -408,17 +424,17 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         if (cntDel) {   // rare: a handful of slots per keyframe
             unsigned base = list_base(cntDel);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < KPL; k++) {
                 const bool d = (fl >> k) & 1u;
                 const unsigned long long m = __ballot(d);
                 hand_over(d, m, base, c0 + REC_LOCAL(k)); base += (unsigned)__popcll(m);
             }
         }
         // ---- survivors -> (round, lane): one push per k.  word = local index, valid bit, superpixel << 16 ----
-        unsigned rcv[4], bk[4];
+        unsigned rcv[KPL], bk[KPL];
         unsigned total = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < KPL; k++) {
             const bool sv = (fl >> (4 + k)) & 1u;
             const unsigned long long m = __ballot(sv);
             const unsigned c = (unsigned)__popcll(m), rs = lane_rank(m);
@@ -433,7 +449,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         for (unsigned r = 0; r < rounds; r++) {   // one round for <= 64 survivors
             unsigned item = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < KPL; k++) {
                 const unsigned rk = (bk[k] + ((lane - bk[k]) & 63u)) >> 6;   // round of the survivor this lane received from k (if any)
                 if ((rcv[k] & 0x100u) && rk == r) item = rcv[k];
             }
@@ -478,7 +494,11 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                         const float newNormLength = sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
                         fusedNx = fusedNx / newNormLength; fusedNy = fusedNy / newNormLength; fusedNz = fusedNz / newNormLength;
                         float newNormW[3];
+#ifdef MSL_FUSE_KARG_POSE
+                        mul3r(F.rot, fusedNx, fusedNy, fusedNz, newNormW);
+#else
                         mul3(F.frame->pose, fusedNx, fusedNy, fusedNz, newNormW);
+#endif
                         int ut = (int)(h.tl >> 20);   // (a survivor is never a hole; HOT_WIDE: the side array)
                         if (__builtin_expect(h.tl == HOT_WIDE, 0)) ut = aux->map.utlWide[2 * i];
                         unsigned tlNew = tl_pack(ut + 1, ref);             // updateTimes + 1, lastUpdate = reference index (:275-276)
@@ -515,11 +535,16 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             }
         }
         if (lane == 0) {   // per-sub-block counts: deleted (classic: the slow paths of k_compact, the host-vector download), updated (deferred: the keyframe's slice)
+#ifdef MSL_FUSE_KARG_BLK
+            if (!DEFER) P.blockSums[sb] = cntDel + cntDelB;
+            P.blockUpd[sb] = nupd;
+#else
             if (!DEFER) aux->blockSums[sb] = cntDel + cntDelB;
             aux->blockUpd[(size_t)(DEFER ? P.kf : 0) * aux->blkStride + sb] = nupd;
+#endif
         }
         // (normally) nothing beyond the grid; a deferred launch decides at the head of the loop (the new surfels may reach into the next sub-block)
-        if (pending ? rel + (long long)G * SUB_ITEMS >= (long long)P.nseeds : (sb + G) * SUB_ITEMS >= n) return;
+        if (pending ? rel + (long long)G * WSPAN >= (long long)P.nseeds : (sb + G) * WSPAN >= n) return;
     }
 #undef REC_LOCAL
 }
@@ -821,7 +846,7 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x < F) {
         const int f = (int)blockIdx.x;
-        const long long nblk = (P.dc->ext[f] + SUB_ITEMS - 1) / SUB_ITEMS;
+        const long long nblk = (P.dc->ext[f] + SUB_ITEMS - 1) / SUB_ITEMS;   // (one count per k_fuse wave)
         const unsigned *bu = P.blockUpd + (size_t)f * blkStride;
         unsigned u = 0;
         for (long long b = lane; b < nblk; b += 64) u += bu[b];
@@ -838,7 +863,7 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
     unsigned excl;
     const unsigned K = spawn_count(A, lane, excl);
     if (q == 0 && lane == 0) P.dc->ext[F] = E0 + (long long)K;
-    if (K && sb * SUB_ITEMS < E0 + (long long)K) emit_records(A, E0, sb, lane, K, excl);
+    if (K && sb * SUB_ITEMS < E0 + (long long)K) emit_records(A, E0, sb * SUB_ITEMS, SUB_ITEMS / 64, lane, K, excl);
 }
 
 // k_replay: the window's F compactions, replayed symbolically by ONE wave.
@@ -865,6 +890,7 @@ struct ReplayLds {
     unsigned locK[RP_HASH], locV[RP_HASH], vposK[RP_HASH], vposV[RP_HASH];   // LDS tables (open addressing; locV = element + 1 | stamp << 26)
 };
 __device__ __forceinline__ unsigned rp_hash(unsigned key) { return (key * 2654435761u) >> 21; }   // 11 bits
+static_assert(SUB_ITEMS == 256, "k_fuse: four records per lane");
 static_assert(RP_HASH == 2048, "rp_hash yields 11 bits");
 
 // LDS = true: the window's explicit placements live in two LDS hash tables (few deletions: the steady state; no global round trips inside the
