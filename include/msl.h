@@ -36,6 +36,13 @@ extern "C" {
 #endif
 
 #define MSL_API __attribute__((visibility("default")))
+/* No exception ever crosses this boundary: every entry point is noexcept and turns a failure inside the library (std::bad_alloc, a failed
+ * thread spawn, ...) into a status code ("all noexcept, int return"). */
+#ifdef __cplusplus
+#define MSL_NOEXCEPT noexcept
+#else
+#define MSL_NOEXCEPT
+#endif
 
 typedef enum msl_status {
     MSL_OK = 0,
@@ -43,7 +50,9 @@ typedef enum msl_status {
     MSL_ERR_NO_DEVICE = -2,    /* no usable HIP device (no CPU fallback exists)  */
     MSL_ERR_HIP = -3,          /* a HIP runtime call failed                      */
     MSL_ERR_CAPACITY = -4,     /* caller-provided output capacity too small      */
-    MSL_ERR_OVERFLOW = -5      /* an internal device-side bound was exceeded     */
+    MSL_ERR_OVERFLOW = -5,     /* an internal device-side bound was exceeded     */
+    MSL_ERR_NOMEM = -6,        /* host memory exhausted inside the library       */
+    MSL_ERR_INTERNAL = -7      /* any other exception caught at the boundary     */
 } msl_status;
 
 typedef enum msl_mem {
@@ -87,10 +96,10 @@ typedef struct msl_seed {
     uint8_t fused, stable, use, _pad;
 } msl_seed;
 
-MSL_API const char *msl_last_error(void);
-MSL_API const char *msl_version(void);
+MSL_API const char *msl_last_error(void) MSL_NOEXCEPT;
+MSL_API const char *msl_version(void) MSL_NOEXCEPT;
 /* Number of usable gfx950 devices (0 if none / HIP unavailable). */
-MSL_API int msl_device_count(void);
+MSL_API int msl_device_count(void) MSL_NOEXCEPT;
 
 /* ------------------------------------------------------------------------------------------
  * ORB extractor
@@ -101,26 +110,26 @@ typedef struct msl_orb msl_orb;
  * the frame size, max_batch the number of frames one msl_orb_extract_batch call may carry. */
 MSL_API msl_orb *msl_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
                                 int minThFAST, int max_width, int max_height, int max_batch,
-                                int device);
-MSL_API void msl_orb_destroy(msl_orb *h);
+                                int device) MSL_NOEXCEPT;
+MSL_API void msl_orb_destroy(msl_orb *h) MSL_NOEXCEPT;
 
 /* Scale tables of include/ORBextractor.h:58-80; each out array holds nlevels floats (NULL = skip). */
 MSL_API int msl_orb_scale_tables(const msl_orb *h, float *scaleFactors, float *invScaleFactors,
-                                 float *levelSigma2, float *invLevelSigma2);
+                                 float *levelSigma2, float *invLevelSigma2) MSL_NOEXCEPT;
 /* mnFeaturesPerLevel (src/ORBextractor.cc:433-445). */
-MSL_API int msl_orb_features_per_level(const msl_orb *h, int32_t *out);
+MSL_API int msl_orb_features_per_level(const msl_orb *h, int32_t *out) MSL_NOEXCEPT;
 /* Upper bound on keypoints per frame: nfeatures + 2*nlevels (the one-by-one phase of DistributeOctTree overshoots a level's quota by at most 2,
  * src/ORBextractor.cc:691-696); for frames at least ~4 times as wide as high with a small budget the first quadtree round alone returns up to
  * 4 * round(width / height) nodes per level (:536-552, 575-640), and the capacity of an extractor created for such a frame size includes them. */
-MSL_API int msl_orb_capacity(const msl_orb *h);
-MSL_API int msl_orb_levels(const msl_orb *h);
+MSL_API int msl_orb_capacity(const msl_orb *h) MSL_NOEXCEPT;
+MSL_API int msl_orb_levels(const msl_orb *h) MSL_NOEXCEPT;
 
 /* Replaces ORBextractor::operator() (src/ORBextractor.cc:813-870) for one CV_8UC1 frame held in
  * host memory.  stride is in bytes.  On return *n_out keypoints (level order 0..L-1, in-level
  * order = quadtree list order) and n_out*32 descriptor bytes are in the caller's host buffers.
  * An empty image (width==0||height==0||gray==NULL) returns MSL_OK with *n_out = 0 (:815-816). */
 MSL_API int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride,
-                            msl_keypoint *kps, uint8_t *desc32, int cap, int *n_out);
+                            msl_keypoint *kps, uint8_t *desc32, int cap, int *n_out) MSL_NOEXCEPT;
 
 /* Frame-batched variant (throughput path).  Frame f starts at gray + f*frame_stride.  Outputs for
  * frame f are written at kps + f*cap, desc32 + f*cap*32, n_out[f].  in_mem/out_mem say whether
@@ -129,7 +138,7 @@ MSL_API int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int heig
 MSL_API int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int width,
                                   int height, size_t row_stride, size_t frame_stride,
                                   msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
-                                  int32_t *n_out, msl_mem out_mem);
+                                  int32_t *n_out, msl_mem out_mem) MSL_NOEXCEPT;
 /* ---- widening, SURVEY.md 8(f) rank 1: the Frame steps that consume the ORB output right after the join
  * (src/Frame.cc:107-153): UndistortKeyPoints (:437-463), ComputeStereoFromRGBD (:495-513), AssignFeaturesToGrid
  * (:155-168, PosInGrid :418-427), fused behind the extraction so the keypoints never leave HBM in between. ---- */
@@ -142,7 +151,7 @@ typedef struct msl_frame_params {
 #define MSL_FRAME_GRID_ROWS 48     /* include/Frame.h:53-54 */
 #define MSL_FRAME_GRID_COLS 64
 /* ComputeImageBounds: fills minX..maxY from fx..k3 and the image size (host arithmetic only). */
-MSL_API int msl_frame_image_bounds(msl_frame_params *p, int width, int height);
+MSL_API int msl_frame_image_bounds(msl_frame_params *p, int width, int height) MSL_NOEXCEPT;
 /* msl_orb_extract_batch plus, per keypoint i of frame f (outputs at index f*cap + i, same memory space as kps):
  *   kps_un_xy[2i..2i+1] = mvKeysUn[i].pt      depth_out[i] = mvDepth[i] (-1 if the depth pixel is <= 0)
  *   uright_out[i] = mvuRight[i]               grid_cell[i] = posX * 48 + posY of mGrid[posX][posY], or -1 (PosInGrid false)
@@ -151,10 +160,10 @@ MSL_API int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const f
                                         size_t gray_row_stride, size_t gray_frame_stride, size_t depth_row_stride,
                                         size_t depth_frame_stride, msl_mem in_mem, const msl_frame_params *params,
                                         msl_keypoint *kps, uint8_t *desc32, float *kps_un_xy, float *depth_out, float *uright_out,
-                                        int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem);
-MSL_API int msl_orb_sync(msl_orb *h);
+                                        int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem) MSL_NOEXCEPT;
+MSL_API int msl_orb_sync(msl_orb *h) MSL_NOEXCEPT;
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's own. */
-MSL_API int msl_orb_set_stream(msl_orb *h, void *hip_stream);
+MSL_API int msl_orb_set_stream(msl_orb *h, void *hip_stream) MSL_NOEXCEPT;
 
 
 /* ------------------------------------------------------------------------------------------
@@ -165,8 +174,8 @@ typedef struct msl_sf msl_sf;
 /* Replaces SurfelFusion::SurfelFusion (src/SurfelFusion.cpp:29-38).  Any width, height >= 16: like the reference, the superpixel lattice is
  * (width / 8) x (height / 8), truncated; the pixels right of / below the last whole cell still take part in every per-pixel step. */
 MSL_API msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy,
-                              float fuseFar, float fuseNear, int device);
-MSL_API void msl_sf_destroy(msl_sf *h);
+                              float fuseFar, float fuseNear, int device) MSL_NOEXCEPT;
+MSL_API void msl_sf_destroy(msl_sf *h) MSL_NOEXCEPT;
 
 /* Host-vector mode == SurfelFusion::fuseInitializeMap (src/SurfelFusion.cpp:40-73).
  * gray: CV_8UC1 w*h; depth: CV_32FC1 metres; member: CV_32SC1 ceil(w/2)*ceil(h/2), -1 = no plane; strides
@@ -175,7 +184,7 @@ MSL_API void msl_sf_destroy(msl_sf *h);
 MSL_API int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride,
                         const float *depth, size_t depth_stride, const int32_t *member,
                         size_t member_stride, const float pose_colmajor[16], msl_surfel *local,
-                        size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new);
+                        size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new) MSL_NOEXCEPT;
 
 /* The same with hints.  MSL_SF_LOCAL_UNCHANGED: local[0 .. n_local) is byte for byte what the previous msl_sf_fuse / msl_sf_fuse_ex call on this
  * handle left there (a caller that keeps the new surfels in a list of their own, or that has not run SurfelMapping::fuseMap's refill yet); the
@@ -186,19 +195,19 @@ MSL_API int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray,
 MSL_API int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride,
                            const float *depth, size_t depth_stride, const int32_t *member,
                            size_t member_stride, const float pose_colmajor[16], msl_surfel *local,
-                           size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags);
+                           size_t n_local, msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags) MSL_NOEXCEPT;
 
 /* Device-resident map mode: the live surfel map stays in HBM between keyframes. */
-MSL_API int msl_sf_map_reserve(msl_sf *h, size_t capacity);
-MSL_API int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n);
-MSL_API int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out);
-MSL_API int msl_sf_map_size(msl_sf *h, size_t *n_out);
+MSL_API int msl_sf_map_reserve(msl_sf *h, size_t capacity) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_size(msl_sf *h, size_t *n_out) MSL_NOEXCEPT;
 /* Replay support (bench.py's stationary sequence, tests): msl_sf_map_snapshot keeps a device-side copy of the resident map and its
  * live count (synchronous); msl_sf_map_restore puts that copy back, asynchronously on the map stream, ordered after every keyframe
  * enqueued so far -- a device-to-device copy of the records, no host traffic.  (No reference counterpart: Tracking::Reset does not
  * touch the surfel vectors, SURVEY.md App. D.) */
-MSL_API int msl_sf_map_snapshot(msl_sf *h);
-MSL_API int msl_sf_map_restore(msl_sf *h);
+MSL_API int msl_sf_map_snapshot(msl_sf *h) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_restore(msl_sf *h) MSL_NOEXCEPT;
 
 /* fuseInitializeMap + the SurfelMapping::fuseMap slot refill / tail compaction
  * (src/SurfelMapping.cpp:353-392) on the resident map.  Image pointers may be host or device
@@ -211,7 +220,7 @@ MSL_API int msl_sf_map_restore(msl_sf *h);
 MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8_t *gray,
                                  size_t gray_stride, const float *depth, size_t depth_stride,
                                  const int32_t *member, size_t member_stride, msl_mem img_mem,
-                                 const float pose_colmajor[16]);
+                                 const float pose_colmajor[16]) MSL_NOEXCEPT;
 /* ---- widening, SURVEY.md 8(f) rank 4: map maintenance on the resident map (so SurfelMapping::moveAddSurfels and Stop() need
  * no full download/upload).  All three are synchronous and keep the reference's element order. ----
  * msl_sf_map_detach: the inner loop of moveAddSurfels (src/SurfelMapping.cpp:207-224) for one leaving pose: every live surfel
@@ -220,13 +229,13 @@ MSL_API int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8
  * msl_sf_map_append: mvLocalSurfels.insert(end, ...) of re-entering poses (src/SurfelMapping.cpp:291-296).
  * msl_sf_map_export: the local-surfel filter of SurfelMapping::Stop (src/SurfelMapping.cpp:67-84): surfels with
  *   updateTimes >= min_update_times, in map order. */
-MSL_API int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out);
-MSL_API int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n);
-MSL_API int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out);
+MSL_API int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) MSL_NOEXCEPT;
+MSL_API int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out) MSL_NOEXCEPT;
 /* System::saveSurfels (src/System.cc:296-382) on the cloud of SurfelMapping::Stop (src/SurfelMapping.cpp:62-104): msl_sf_map_export(min_update_times)
  * followed by the caller's inactive surfels, written as the reference's ASCII PLY (vertex: x y z nx ny nz red green blue alpha quality radius; one
  * camera element).  (The map-plane points Stop() appends are Map data outside this library; pass them through `inactive` if wanted.) */
-MSL_API int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path);
+MSL_API int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path) MSL_NOEXCEPT;
 
 /* ---- widening, SURVEY.md 8(f) rank 2: the data-parallel front of the PEAC plane extractor (producer of membershipImg) ----
  * msl_peac_block_stats: for n_frames raw 16-bit depth images
@@ -250,7 +259,7 @@ typedef struct msl_peac_stats {
 MSL_API int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
                                  int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, int window_w,
                                  int window_h, double depth_alpha, double depth_change_tol, int init_loose, double *cloud_out,
-                                 msl_peac_stats *stats_out, msl_mem out_mem);
+                                 msl_peac_stats *stats_out, msl_mem out_mem) MSL_NOEXCEPT;
 
 /* The rest of the plane extractor: the producer of SurfelFusion's inputPlaneMembershipImg (BASELINE config 4).
  * msl_peac_params = the members of ahc::PlaneFitter (include/peac/AHCPlaneFitter.hpp:122-131, 157-161) and ahc::ParamSet
@@ -286,19 +295,19 @@ typedef struct msl_peac_params {
     double similarity_th_merge, similarity_th_refine;             /* cos 60 deg, cos 30 deg */
     double depth_alpha, depth_change_tol;                         /* T_dz */
 } msl_peac_params;
-MSL_API void msl_peac_default_params(msl_peac_params *p);
+MSL_API void msl_peac_default_params(msl_peac_params *p) MSL_NOEXCEPT;
 MSL_API int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
                                int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
-                               const msl_peac_params *params, msl_peac_block *blocks_out, msl_mem out_mem);
+                               const msl_peac_params *params, msl_peac_block *blocks_out, msl_mem out_mem) MSL_NOEXCEPT;
 MSL_API int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
                                       int height, int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
-                                      const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
+                                      const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) MSL_NOEXCEPT;
 /* The host stage of msl_peac_membership_batch alone (graph initialisation, clustering, erosion, region growing; persistent worker threads, one
  * frame per thread at a time), on block fits the caller already has (blocks: HOST, [n_frames][Nh * Nw] as msl_peac_block_fit returns them) and the
  * HOST depth images they came from.  No device is touched: this is the part of the extractor that is sequential by construction. */
 MSL_API int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
                                             int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
-                                            const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out);
+                                            const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) MSL_NOEXCEPT;
 /* Everything the reference's PlaneDetection hands on after runPlaneDetection (include/PlaneExtractor.h:57-62, src/PlaneExtractor.cpp:77-80):
  * msl_peac_membership_batch's outputs plus, per frame,
  *   planes_out         HOST [n_frames][max_planes]      plane_filter.extractedPlanes[i]: normal, centre, MSE, N (src/Frame.cc:626-632 reads them);
@@ -315,11 +324,11 @@ typedef struct msl_peac_plane { double normal[3], center[3], mse; int32_t N, _pa
 MSL_API int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
                                    int n_frames, msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor,
                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,
-                                   msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out, double *cloud_out);
+                                   msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out, double *cloud_out) MSL_NOEXCEPT;
 MSL_API int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes,
                                          int width, int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
                                          const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out, int max_planes,
-                                         msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out);
+                                         msl_peac_plane *planes_out, int32_t *vertex_offsets_out, int32_t *vertex_indices_out) MSL_NOEXCEPT;
 
 /* ---- widening, SURVEY.md 8(f) rank 3: Hamming matching by projection, the next consumer of the ORB descriptors ----
  * msl_match_by_projection_batch: n_pairs independent calls of
@@ -353,19 +362,19 @@ typedef struct msl_match_params {
  * AND outputs are device memory (msl_match_sync / msl_match_set_stream as for the other handles); with host memory on either side it returns when the
  * caller's buffers are its own again. */
 typedef struct msl_match msl_match;
-MSL_API msl_match *msl_match_create(int device);
-MSL_API void msl_match_destroy(msl_match *h);
-MSL_API int msl_match_sync(msl_match *h);
-MSL_API int msl_match_set_stream(msl_match *h, void *hip_stream);
+MSL_API msl_match *msl_match_create(int device) MSL_NOEXCEPT;
+MSL_API void msl_match_destroy(msl_match *h) MSL_NOEXCEPT;
+MSL_API int msl_match_sync(msl_match *h) MSL_NOEXCEPT;
+MSL_API int msl_match_set_stream(msl_match *h, void *hip_stream) MSL_NOEXCEPT;
 MSL_API int msl_match_by_projection(msl_match *h, int n_pairs, int cap, const msl_match_params *params,
                                     const msl_keypoint *cur_kps, const float *cur_un_xy, const float *cur_uright,
                                     const int32_t *cur_grid_cell, const uint8_t *cur_desc, const int32_t *n_cur,
                                     const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
                                     const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
                                     const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out,
-                                    int32_t *nmatches, msl_mem out_mem);
+                                    int32_t *nmatches, msl_mem out_mem) MSL_NOEXCEPT;
 /* ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:835-849) for n descriptor pairs (host arrays, synchronous; parity hook for the popcount path). */
-MSL_API int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out);
+MSL_API int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) MSL_NOEXCEPT;
 /* Device-indexed convenience forms of the two calls above: a lazily created handle per device shared by all callers (serialised), always
  * synchronous; device-resident inputs must be complete, or enqueued on the legacy default stream, when the call is made. */
 MSL_API int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params,
@@ -374,23 +383,23 @@ MSL_API int msl_match_by_projection_batch(int device, int n_pairs, int cap, cons
                                           const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
                                           const int32_t *last_octave, const float *last_angle, const int32_t *n_last,
                                           const float *Tcw_cur, const float *Tcw_last, msl_mem mem, int32_t *match_out,
-                                          int32_t *nmatches, msl_mem out_mem);
-MSL_API int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out);
+                                          int32_t *nmatches, msl_mem out_mem) MSL_NOEXCEPT;
+MSL_API int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) MSL_NOEXCEPT;
 
 /* Batched form: n_frames keyframes in order, semantically n_frames consecutive msl_sf_fuse_resident calls.
  * Keyframe f's images start at base + f * <frame_stride> bytes (member_frame_stride may be 0: one shared
  * membership image); refs[n_frames] and poses (16 * n_frames floats, column-major Twc each) are host arrays.
  * generateSuperPixels() of all keyframes of a batch runs frame-batched on a second stream and overlaps the
  * per-keyframe map stage of the previous batch.  n_frames <= the capacity set below (default 1). */
-MSL_API int msl_sf_set_batch_capacity(msl_sf *h, int max_frames);
+MSL_API int msl_sf_set_batch_capacity(msl_sf *h, int max_frames) MSL_NOEXCEPT;
 MSL_API int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray,
                                        size_t gray_stride, size_t gray_frame_stride, const float *depth,
                                        size_t depth_stride, size_t depth_frame_stride, const int32_t *member,
                                        size_t member_stride, size_t member_frame_stride, msl_mem img_mem,
-                                       const float *poses_colmajor);
-MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]);
-MSL_API int msl_sf_sync(msl_sf *h);
-MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream);
+                                       const float *poses_colmajor) MSL_NOEXCEPT;
+MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) MSL_NOEXCEPT;
+MSL_API int msl_sf_sync(msl_sf *h) MSL_NOEXCEPT;
+MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream) MSL_NOEXCEPT;
 
 
 #ifdef __cplusplus

@@ -108,6 +108,7 @@ SIGNATURES = {
     "msl_sf_profile_stride": (_i, [_vp, _i]),
     "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),
     "msl_sf_kernel_name": (C.c_char_p, [_i]),
+    "msl_debug_throw": (_i, [_i]),
 }
 MSL_ORB_NKERNELS = 6
 MSL_SF_NKERNELS = 12

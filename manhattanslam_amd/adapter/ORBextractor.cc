@@ -5,6 +5,12 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <cstdlib>
+
+// The GPU this process uses: the reference has no notion of a device, so the adapters take it from the environment (MSL_DEVICE, default 0);
+// one process per GPU (bench.py's ranks, a multi-sequence server) sets it per process.
+static int msl_device_from_env() { const char *e = std::getenv("MSL_DEVICE"); return e ? std::atoi(e) : 0; }
+
 
 namespace ORB_SLAM2 {
 
@@ -33,7 +39,7 @@ ORBextractor::~ORBextractor() { msl_orb_destroy(mHandle); }
 void ORBextractor::ensureHandle(int w, int h) {
     if (mHandle && w <= mW && h <= mH) return;
     msl_orb_destroy(mHandle);
-    mHandle = msl_orb_create(nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, w, h, /*max_batch=*/1, /*device=*/0);
+    mHandle = msl_orb_create(nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, w, h, /*max_batch=*/1, msl_device_from_env());
     if (!mHandle) throw std::runtime_error(std::string("msl_orb_create: ") + msl_last_error());
     mW = w; mH = h;
     const int cap = msl_orb_capacity(mHandle);

@@ -10,6 +10,9 @@
 #include "opencv2/opencv.hpp"
 #include <Eigen/Eigen>
 #include "msl.h"
+#include <cstdlib>
+
+inline int msl_device_env() { const char *e = std::getenv("MSL_DEVICE"); return e ? std::atoi(e) : 0; }
 
 typedef Eigen::Vector3d VertexType;
 typedef cv::Vec3d VertexColour;
@@ -56,7 +59,7 @@ public:
 private:
     cv::Mat depth16_;   // the raw depth image of the last readDepthImage
     float fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0, depthMapFactor_ = 0;
-    int device_ = 0;
+    int device_ = msl_device_env();   // MSL_DEVICE (default 0)
 };
 
 #endif  // PLANEEXTRACTOR_H

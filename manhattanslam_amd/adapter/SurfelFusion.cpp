@@ -3,6 +3,12 @@
 
 #include <stdexcept>
 #include <string>
+#include <cstdlib>
+
+// The GPU this process uses: the reference has no notion of a device, so the adapters take it from the environment (MSL_DEVICE, default 0);
+// one process per GPU (bench.py's ranks, a multi-sequence server) sets it per process.
+static int msl_device_from_env() { const char *e = std::getenv("MSL_DEVICE"); return e ? std::atoi(e) : 0; }
+
 
 static_assert(sizeof(msl_surfel) == sizeof(Surfel), "msl_surfel must mirror struct Surfel (include/Surfel.h)");
 
@@ -11,7 +17,7 @@ static void check(int rc, const char *what) {
 }
 
 SurfelFusion::SurfelFusion(int width, int height, float _fx, float _fy, float _cx, float _cy, float _fuseFar, float _fuseNear)
-    : mHandle(msl_sf_create(width, height, _fx, _fy, _cx, _cy, _fuseFar, _fuseNear, /*device=*/0)), imageWidth(width),
+    : mHandle(msl_sf_create(width, height, _fx, _fy, _cx, _cy, _fuseFar, _fuseNear, msl_device_from_env())), imageWidth(width),
       imageHeight(height) {
     if (!mHandle) throw std::runtime_error(std::string("msl_sf_create: ") + msl_last_error());
 }

@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <new>
 
 #include "../../include/msl.h"
 #include "../../include/msl_debug.h"
@@ -27,6 +29,18 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 int bind_device(int device);  // hipSetDevice + gfx950 check; returns msl_status
+
+// Exception barrier of the C ABI: every extern "C" entry point is `noexcept { try { ... } MSL_ABI_CATCH_* }` -- the library uses std::vector,
+// new and std::thread behind it, and nothing may unwind into a C (cgo / JNI / ctypes) caller.
+#define MSL_ABI_CATCH_(fail)                                                                                                       \
+    catch (const std::bad_alloc &) { ::msl::set_error("out of host memory inside the library"); fail; }                             \
+    catch (const std::exception &e_) { ::msl::set_error("internal error: %s", e_.what()); fail; }                                   \
+    catch (...) { ::msl::set_error("internal error (unknown exception)"); fail; }
+#define MSL_ABI_CATCH_INT  catch (const std::bad_alloc &) { ::msl::set_error("out of host memory inside the library"); return MSL_ERR_NOMEM; } \
+    catch (const std::exception &e_) { ::msl::set_error("internal error: %s", e_.what()); return MSL_ERR_INTERNAL; }                 \
+    catch (...) { ::msl::set_error("internal error (unknown exception)"); return MSL_ERR_INTERNAL; }
+#define MSL_ABI_CATCH_PTR  MSL_ABI_CATCH_(return nullptr)
+#define MSL_ABI_CATCH_VOID MSL_ABI_CATCH_(return)
 
 // Event-pair profiler: one (start, stop) pair per launch of the selected kernels, drained at sync points.
 // set_mode(0) = off, set_mode(-1) = every kernel, otherwise a bit mask of kernel ids.

@@ -21,6 +21,7 @@ int bind_device(int device) {
         return MSL_ERR_NO_DEVICE;
     }
     if (device < 0 || device >= n) { set_error("device %d out of range (have %d)", device, n); return MSL_ERR_INVALID; }
+    if (device >= 16) { set_error("device %d: the library keeps per-device state (default handles, scratch) for devices 0 .. 15 only", device); return MSL_ERR_INVALID; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { set_error("hipGetDeviceProperties failed"); return MSL_ERR_HIP; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -81,9 +82,10 @@ void KernelProfiler::destroy() {
 }  // namespace msl
 
 extern "C" {
-const char *msl_last_error(void) { return msl::g_err; }
-const char *msl_version(void) { return "manhattanslam_amd 0.1 (gfx950)"; }
-int msl_device_count(void) {
+const char *msl_last_error(void) noexcept { try { return msl::g_err; } MSL_ABI_CATCH_PTR }
+const char *msl_version(void) noexcept { try { return "manhattanslam_amd 0.1 (gfx950)"; } MSL_ABI_CATCH_PTR }
+int msl_device_count(void) noexcept {
+    try {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     int ok = 0;
@@ -92,5 +94,6 @@ int msl_device_count(void) {
         if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
     }
     return ok;
+    } MSL_ABI_CATCH_(return 0)
 }
 }

@@ -466,23 +466,28 @@ int run_distance(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, in
 
 extern "C" {
 
-msl_match *msl_match_create(int device) {
+msl_match *msl_match_create(int device) noexcept {
+    try {
     if (bind_device(device) != MSL_OK) return nullptr;
     msl_match *h = new (std::nothrow) msl_match();
     if (!h) { set_error("msl_match_create: out of memory"); return nullptr; }
     h->device = device;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { set_error("msl_match_create: hipStreamCreate failed"); delete h; return nullptr; }
     return h;
+    } MSL_ABI_CATCH_PTR
 }
 
-void msl_match_destroy(msl_match *h) {
+void msl_match_destroy(msl_match *h) noexcept {
+    try {
     if (!h) return;
     (void)bind_device(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_handle(h);
+    } MSL_ABI_CATCH_VOID
 }
 
-int msl_match_set_stream(msl_match *h, void *hip_stream) {
+int msl_match_set_stream(msl_match *h, void *hip_stream) noexcept {
+    try {
     if (!h) { set_error("msl_match_set_stream: null handle"); return MSL_ERR_INVALID; }
     int rc = bind_device(h->device);
     if (rc != MSL_OK) return rc;
@@ -490,33 +495,39 @@ int msl_match_set_stream(msl_match *h, void *hip_stream) {
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)hip_stream; h->ownStream = false;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_match_sync(msl_match *h) {
+int msl_match_sync(msl_match *h) noexcept {
+    try {
     if (!h) { set_error("msl_match_sync: null handle"); return MSL_ERR_INVALID; }
     int rc = bind_device(h->device);
     if (rc != MSL_OK) return rc;
     M_TRY(hipStreamSynchronize(h->stream));
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_match_by_projection(msl_match *h, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps,
                             const float *cur_un_xy, const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc,
                             const int32_t *n_cur, const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
                             const int32_t *last_octave, const float *last_angle, const int32_t *n_last, const float *Tcw_cur,
-                            const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
+                            const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) noexcept {
+    try {
     return run_projection(h, n_pairs, cap, params, cur_kps, cur_un_xy, cur_uright, cur_grid_cell, cur_desc, n_cur, last_xyz, last_desc, last_flags,
                           last_octave, last_angle, n_last, Tcw_cur, Tcw_last, mem, match_out, nmatches, out_mem);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) { return run_distance(h, a32, b32, n, dist_out); }
+int msl_match_descriptor_distances(msl_match *h, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) noexcept { try { return run_distance(h, a32, b32, n, dist_out); } MSL_ABI_CATCH_INT }
 
 // Device-indexed convenience forms: one lazily created handle per device, serialised by a mutex, always synchronous.
 int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_match_params *params, const msl_keypoint *cur_kps,
                                   const float *cur_un_xy, const float *cur_uright, const int32_t *cur_grid_cell, const uint8_t *cur_desc,
                                   const int32_t *n_cur, const float *last_xyz, const uint8_t *last_desc, const uint8_t *last_flags,
                                   const int32_t *last_octave, const float *last_angle, const int32_t *n_last, const float *Tcw_cur,
-                                  const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) {
+                                  const float *Tcw_last, msl_mem mem, int32_t *match_out, int32_t *nmatches, msl_mem out_mem) noexcept {
+    try {
     std::lock_guard<std::mutex> lock(g_mutex);
     msl_match *h = default_handle(device);
     if (!h) return MSL_ERR_NO_DEVICE;
@@ -526,13 +537,16 @@ int msl_match_by_projection_batch(int device, int n_pairs, int cap, const msl_ma
                             last_octave, last_angle, n_last, Tcw_cur, Tcw_last, mem, match_out, nmatches, out_mem);
     if (rc == MSL_OK) rc = msl_match_sync(h);
     return rc;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) {
+int msl_match_descriptor_distance(int device, const uint8_t *a32, const uint8_t *b32, int n, int32_t *dist_out) noexcept {
+    try {
     std::lock_guard<std::mutex> lock(g_mutex);
     msl_match *h = default_handle(device);
     if (!h) return MSL_ERR_NO_DEVICE;
     return run_distance(h, a32, b32, n, dist_out);
+    } MSL_ABI_CATCH_INT
 }
 #undef M_TRY
 

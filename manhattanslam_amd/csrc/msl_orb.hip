@@ -1404,7 +1404,8 @@ int check_device_error(msl_orb *h) {
 extern "C" {
 
 msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniThFAST, int minThFAST, int max_width,
-                        int max_height, int max_batch, int device) {
+                        int max_height, int max_batch, int device) noexcept {
+    try {
     if (nfeatures < 1 || nlevels < 1 || nlevels > ML || !(scaleFactorF > 1.0f) || iniThFAST < 1 || iniThFAST > 255 ||
         minThFAST < 1 || minThFAST > 255 || max_width < 1 || max_height < 1 || max_batch < 1) {
         set_error("msl_orb_create: invalid argument");
@@ -1459,9 +1460,11 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
     h->prof.nk = MSL_ORB_NKERNELS;
     if (build_geometry(h, max_width, max_height) != MSL_OK) { msl_orb_destroy(h); return nullptr; }
     return h;
+    } MSL_ABI_CATCH_PTR
 }
 
-void msl_orb_destroy(msl_orb *h) {
+void msl_orb_destroy(msl_orb *h) noexcept {
+    try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -1481,9 +1484,11 @@ void msl_orb_destroy(msl_orb *h) {
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->stream && h->ownStream) (void)hipStreamDestroy(h->stream);
     delete h;
+    } MSL_ABI_CATCH_VOID
 }
 
-int msl_orb_scale_tables(const msl_orb *h, float *sf, float *isf, float *s2, float *is2) {
+int msl_orb_scale_tables(const msl_orb *h, float *sf, float *isf, float *s2, float *is2) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     for (int i = 0; i < h->nlevels; i++) {
         if (sf) sf[i] = h->scale[i];
@@ -1492,33 +1497,41 @@ int msl_orb_scale_tables(const msl_orb *h, float *sf, float *isf, float *s2, flo
         if (is2) is2[i] = h->invSigma2[i];
     }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_orb_features_per_level(const msl_orb *h, int32_t *out) {
+int msl_orb_features_per_level(const msl_orb *h, int32_t *out) noexcept {
+    try {
     if (!h || !out) return MSL_ERR_INVALID;
     for (int i = 0; i < h->nlevels; i++) out[i] = h->perLevel[i];
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_orb_capacity(const msl_orb *h) { return h ? h->outCap : MSL_ERR_INVALID; }
-int msl_orb_levels(const msl_orb *h) { return h ? h->nlevels : MSL_ERR_INVALID; }
+int msl_orb_capacity(const msl_orb *h) noexcept { try { return h ? h->outCap : MSL_ERR_INVALID; } MSL_ABI_CATCH_INT }
+int msl_orb_levels(const msl_orb *h) noexcept { try { return h ? h->nlevels : MSL_ERR_INVALID; } MSL_ABI_CATCH_INT }
 
-int msl_orb_set_stream(msl_orb *h, void *hip_stream) {
+int msl_orb_set_stream(msl_orb *h, void *hip_stream) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->ownStream) (void)hipStreamDestroy(h->stream);
     h->stream = (hipStream_t)hip_stream; h->ownStream = false;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_sync(msl_orb *h) {
+int msl_orb_sync(msl_orb *h) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     return check_device_error(h);
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int width, int height, size_t row_stride,
                           size_t frame_stride, msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
-                          int32_t *n_out, msl_mem out_mem) {
+                          int32_t *n_out, msl_mem out_mem) noexcept {
+    try {
     if (!h || !n_out || n_frames < 0) { set_error("msl_orb_extract_batch: invalid argument"); return MSL_ERR_INVALID; }
     if (n_frames == 0) return MSL_OK;
     if (!gray || width == 0 || height == 0) {  // empty image: silent return (src/ORBextractor.cc:815-816)
@@ -1563,6 +1576,7 @@ int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int wid
                                  h->stream));
     if (out_mem == MSL_MEM_HOST) return check_device_error(h);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 // The reference's call pattern: one frame per call, host buffers in and out, the result needed before the caller goes on (src/Frame.cc:100,
@@ -1620,7 +1634,8 @@ static int extract_one_host(msl_orb *h, const uint8_t *gray, int width, int heig
 }
 
 int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size_t stride, msl_keypoint *kps,
-                    uint8_t *desc32, int cap, int *n_out) {
+                    uint8_t *desc32, int cap, int *n_out) noexcept {
+    try {
     if (!n_out) { set_error("msl_orb_extract: n_out is NULL"); return MSL_ERR_INVALID; }
     if (h && gray && width > 0 && height > 0 && width <= h->maxW && height <= h->maxH && stride >= (size_t)width && kps && desc32)
         return extract_one_host(h, gray, width, height, stride, kps, desc32, cap, n_out);
@@ -1629,6 +1644,7 @@ int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int height, size
                                          cap, &n, MSL_MEM_HOST);
     *n_out = n;
     return rc;
+    } MSL_ABI_CATCH_INT
 }
 
 // host twin of the device undistortion (same expression order), used by ComputeImageBounds only
@@ -1652,7 +1668,8 @@ static void undistort_point_host(const msl_frame_params &p, float xin, float yin
     *yo = (float)(yy * ww);
 }
 
-int msl_frame_image_bounds(msl_frame_params *p, int width, int height) {   // ComputeImageBounds, src/Frame.cc:465-494
+int msl_frame_image_bounds(msl_frame_params *p, int width, int height) noexcept {
+    try {   // ComputeImageBounds, src/Frame.cc:465-494
     if (!p || width < 1 || height < 1 || p->fx == 0 || p->fy == 0) { set_error("msl_frame_image_bounds: invalid argument"); return MSL_ERR_INVALID; }
     if (p->k1 != 0.0) {
         const float c[4][2] = {{0.f, 0.f}, {(float)width, 0.f}, {0.f, (float)height}, {(float)width, (float)height}};
@@ -1664,12 +1681,14 @@ int msl_frame_image_bounds(msl_frame_params *p, int width, int height) {   // Co
         p->minX = 0.0f; p->maxX = (float)width; p->minY = 0.0f; p->maxY = (float)height;
     }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *depth, int n_frames, int width, int height,
                                 size_t gray_row_stride, size_t gray_frame_stride, size_t depth_row_stride, size_t depth_frame_stride,
                                 msl_mem in_mem, const msl_frame_params *params, msl_keypoint *kps, uint8_t *desc32, float *kps_un_xy,
-                                float *depth_out, float *uright_out, int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem) {
+                                float *depth_out, float *uright_out, int32_t *grid_cell, int cap, int32_t *n_out, msl_mem out_mem) noexcept {
+    try {
     if (!h || !gray || !depth || !params || !kps || !desc32 || !kps_un_xy || !depth_out || !uright_out || !grid_cell || !n_out ||
         n_frames < 1 || n_frames > h->maxBatch || width < 1 || height < 1 || width > h->maxW || height > h->maxH ||
         gray_row_stride < (size_t)width || depth_row_stride < (size_t)width * 4 || (depth_row_stride & 3) ||
@@ -1725,23 +1744,29 @@ int msl_orb_extract_frame_batch(msl_orb *h, const uint8_t *gray, const float *de
     MSL_HIP_TRY(hipMemcpy2DAsync(grid_cell, sizeof(int) * cap, h->d_gridCell, sizeof(int) * outCap, sizeof(int) * outCap, n_frames, kind, h->stream));
     if (out_mem == MSL_MEM_HOST) return check_device_error(h);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_debug_stamps(msl_orb *h, uint64_t *out, int n) {
+int msl_orb_debug_stamps(msl_orb *h, uint64_t *out, int n) noexcept {
+    try {
     if (!h || !out || n < 0 || n > 200) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
     MSL_HIP_TRY(hipMemcpy(out, reinterpret_cast<unsigned char *>(h->d_err) + 128, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out) {
+int msl_orb_debug_level_size(const msl_orb *h, int level, int *w, int *h_out) noexcept {
+    try {
     if (!h || level < 0 || level >= h->nlevels) return MSL_ERR_INVALID;
     *w = h->dev.lv[level].w; *h_out = h->dev.lv[level].h;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out) {
+int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *out) noexcept {
+    try {
     if (!h || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) return MSL_ERR_INVALID;
     if (level == 0 && !blurred) { set_error("level 0 is the caller's image"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));
@@ -1751,9 +1776,11 @@ int msl_orb_debug_level(msl_orb *h, int frame, int level, int blurred, uint8_t *
                                  : h->d_pyr + (size_t)frame * h->dev.pyrStride + G.off;
     MSL_HIP_TRY(hipMemcpy2D(out, G.w, src, G.pitch, G.w, G.h, hipMemcpyDeviceToHost));
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys, int cap, int *n_out) {
+int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys, int cap, int *n_out) noexcept {
+    try {
     if (!h || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1768,24 +1795,29 @@ int msl_orb_debug_candidates(msl_orb *h, int frame, int level, int32_t *xys, int
         xys[3 * i] = (int)(k[i] & 0xFFF) + 16; xys[3 * i + 1] = (int)((k[i] >> 12) & 0xFFF) + 16; xys[3 * i + 2] = (int)(k[i] >> 24);
     }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_orb_profile_enable(msl_orb *h, int on) {
+int msl_orb_profile_enable(msl_orb *h, int on) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
     h->prof.drain();
     h->prof.set_mode(on);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_orb_profile_read(msl_orb *h, float *ms, int32_t *launches) {
+int msl_orb_profile_read(msl_orb *h, float *ms, int32_t *launches) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     MSL_HIP_TRY(hipStreamSynchronize(h->stream));
     h->prof.drain();
     for (int i = 0; i < MSL_ORB_NKERNELS; i++) { if (ms) ms[i] = h->prof.ms[i]; if (launches) launches[i] = h->prof.launches[i]; }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-const char *msl_orb_kernel_name(int k) { return (k >= 0 && k < MSL_ORB_NKERNELS) ? kKernelNames[k] : ""; }
+const char *msl_orb_kernel_name(int k) noexcept { try { return (k >= 0 && k < MSL_ORB_NKERNELS) ? kKernelNames[k] : ""; } MSL_ABI_CATCH_PTR }
 
 }  // extern "C"

@@ -33,6 +33,8 @@
 #include <mutex>
 #include <queue>
 #include <thread>
+#include <exception>
+#include <stdexcept>
 #include <functional>
 #include <condition_variable>
 #include <atomic>
@@ -70,6 +72,9 @@ __host__ __device__ inline double hypot_pos(double x, double y) {   // Eigen::nu
 // Wilkinson shift and the 2-epsilon deflation test, eigenvalues sorted increasingly with their vectors)
 // VECTORS = false leaves out the accumulation of the rotations (q never feeds back into the diagonal / sub-diagonal updates, so the eigenvalues are the
 // same bits either way): the clustering only needs the smallest eigenvalue of every candidate merge and the vectors of the one it accepts.
+// The diagonal, the sub-diagonal and the rotation matrix are named scalars and every "array" access with a run-time index is a select: the device
+// kernels keep them in registers (round 5: the indexed local arrays of rounds 1-4 lived in 80 bytes of scratch memory per lane).  Same operations in
+// the same order as before, so the same bits (tests/test_peac_host.py compares against the oracle and the SIMD-lane form).
 template <bool VECTORS>
 __host__ __device__ inline void eig33sym_t(const double K[3][3], double s[3], double V[3][3]) {
     double a00 = K[0][0], a10 = K[1][0], a11 = K[1][1], a20 = K[2][0], a21 = K[2][1], a22 = K[2][2];
@@ -77,7 +82,7 @@ __host__ __device__ inline void eig33sym_t(const double K[3][3], double s[3], do
     if (scale == 0) scale = 1;
     a00 /= scale; a10 /= scale; a11 /= scale; a20 /= scale; a21 /= scale; a22 /= scale;
     double d0 = a00, d1, d2, e0, e1;
-    double q[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double q00 = 1, q01 = 0, q02 = 0, q10 = 0, q11 = 1, q12 = 0, q20 = 0, q21 = 0, q22 = 1;
     const double tiny = 2.2250738585072014e-308;   // std::numeric_limits<double>::min()
     const double v1norm2 = a20 * a20;
     if (v1norm2 <= tiny) {
@@ -89,59 +94,81 @@ __host__ __device__ inline void eig33sym_t(const double K[3][3], double s[3], do
         const double qq = 2.0 * m01 * a21 + m02 * (a22 - a11);
         d1 = a11 + m02 * qq; d2 = a22 - m02 * qq;
         e0 = beta; e1 = a21 - m01 * qq;
-        if (VECTORS) { q[1][1] = m01; q[1][2] = m02; q[2][1] = m02; q[2][2] = -m01; }
+        if (VECTORS) { q11 = m01; q12 = m02; q21 = m02; q22 = -m01; }
     }
-    double dg[3] = {d0, d1, d2}, sb[2] = {e0, e1};
+    // dg[i] = (d0, d1, d2)[i], sb[i] = (e0, e1)[i]
+    auto DG = [&](int i) -> double { return i == 0 ? d0 : (i == 1 ? d1 : d2); };
+    auto SB = [&](int i) -> double { return i == 0 ? e0 : e1; };
+    auto setDG = [&](int i, double v) { if (i == 0) d0 = v; else if (i == 1) d1 = v; else d2 = v; };
+    auto setSB = [&](int i, double v) { if (i == 0) e0 = v; else e1 = v; };
     int end = 2, start = 0, iter = 0;
     const double precision = 2.0 * 2.220446049250313e-16;
     while (end > 0) {
         for (int i = start; i < end; ++i)
-            if (fabs(sb[i]) <= (fabs(dg[i]) + fabs(dg[i + 1])) * precision || fabs(sb[i]) <= tiny) sb[i] = 0;
-        while (end > 0 && sb[end - 1] == 0.0) end--;
+            if (fabs(SB(i)) <= (fabs(DG(i)) + fabs(DG(i + 1))) * precision || fabs(SB(i)) <= tiny) setSB(i, 0);
+        while (end > 0 && SB(end - 1) == 0.0) end--;
         if (end <= 0) break;
         if (++iter > 30 * 3) break;
         start = end - 1;
-        while (start > 0 && sb[start - 1] != 0) start--;
-        const double td = (dg[end - 1] - dg[end]) * 0.5, e = sb[end - 1];
-        double mu = dg[end];
+        while (start > 0 && SB(start - 1) != 0) start--;
+        const double td = (DG(end - 1) - DG(end)) * 0.5, e = SB(end - 1);
+        double mu = DG(end);
         if (td == 0.0) mu -= fabs(e);
         else if (e != 0.0) {
             const double e2 = e * e, h = hypot_pos(td, e);
             if (e2 == 0.0) mu -= e / ((td + (td > 0.0 ? h : -h)) / e);
             else mu -= e2 / (td + (td > 0.0 ? h : -h));
         }
-        double x = dg[start] - mu, z = sb[start];
+        double x = DG(start) - mu, z = SB(start);
         for (int k = start; k < end && z != 0.0; ++k) {
             double c, sn;   // Givens rotation that annihilates z against x
             if (x == 0.0) { c = 0.0; sn = z < 0.0 ? 1.0 : -1.0; }
             else if (fabs(x) > fabs(z)) { const double t = z / x; double u = sqrt(1.0 + t * t); if (x < 0.0) u = -u; c = 1.0 / u; sn = -t * c; }
             else { const double t = x / z; double u = sqrt(1.0 + t * t); if (z < 0.0) u = -u; sn = -1.0 / u; c = -t * sn; }
-            const double sdk = sn * dg[k] + c * sb[k];
-            const double dkp1 = sn * sb[k] + c * dg[k + 1];
-            dg[k] = c * (c * dg[k] - sn * sb[k]) - sn * (c * sb[k] - sn * dg[k + 1]);
-            dg[k + 1] = sn * sdk + c * dkp1;
-            sb[k] = c * sdk - sn * dkp1;
-            if (k > start) sb[k - 1] = c * sb[k - 1] - sn * z;
-            x = sb[k];
-            if (k < end - 1) { z = -sn * sb[k + 1]; sb[k + 1] = c * sb[k + 1]; }
-            if (VECTORS)
-                for (int r = 0; r < 3; r++) {
-                    const double xi = q[r][k], yi = q[r][k + 1];
-                    q[r][k] = c * xi - sn * yi;
-                    q[r][k + 1] = sn * xi + c * yi;
+            const double dk = DG(k), dk1 = DG(k + 1), sk = SB(k);
+            const double sdk = sn * dk + c * sk;
+            const double dkp1 = sn * sk + c * dk1;
+            setDG(k, c * (c * dk - sn * sk) - sn * (c * sk - sn * dk1));
+            setDG(k + 1, sn * sdk + c * dkp1);
+            const double skNew = c * sdk - sn * dkp1;
+            setSB(k, skNew);
+            if (k > start) setSB(k - 1, c * SB(k - 1) - sn * z);
+            x = skNew;
+            if (k < end - 1) { const double s1 = SB(k + 1); z = -sn * s1; setSB(k + 1, c * s1); }
+            if (VECTORS) {   // columns k, k + 1 of q (k is 0 or 1)
+                if (k == 0) {
+                    const double x0 = q00, y0 = q01, x1 = q10, y1 = q11, x2 = q20, y2 = q21;
+                    q00 = c * x0 - sn * y0; q01 = sn * x0 + c * y0;
+                    q10 = c * x1 - sn * y1; q11 = sn * x1 + c * y1;
+                    q20 = c * x2 - sn * y2; q21 = sn * x2 + c * y2;
+                } else {
+                    const double x0 = q01, y0 = q02, x1 = q11, y1 = q12, x2 = q21, y2 = q22;
+                    q01 = c * x0 - sn * y0; q02 = sn * x0 + c * y0;
+                    q11 = c * x1 - sn * y1; q12 = sn * x1 + c * y1;
+                    q21 = c * x2 - sn * y2; q22 = sn * x2 + c * y2;
                 }
+            }
         }
     }
-    for (int i = 0; i < 2; ++i) {   // selection sort, columns follow
+    // selection sort, columns follow: i = 0 picks the smallest of (d0, d1, d2), i = 1 the smaller of the remaining two
+    {
         int k = 0;
-        for (int j = 1; j < 3 - i; j++) if (dg[i + j] < dg[i + k]) k = j;
-        if (k > 0) {
-            const double t = dg[i]; dg[i] = dg[k + i]; dg[k + i] = t;
-            if (VECTORS) for (int r = 0; r < 3; r++) { const double u = q[r][i]; q[r][i] = q[r][k + i]; q[r][k + i] = u; }
+        if (d1 < d0) k = 1;
+        if (d2 < (k == 0 ? d0 : d1)) k = 2;
+        if (k == 1) {
+            const double t = d0; d0 = d1; d1 = t;
+            if (VECTORS) { double u = q00; q00 = q01; q01 = u; u = q10; q10 = q11; q11 = u; u = q20; q20 = q21; q21 = u; }
+        } else if (k == 2) {
+            const double t = d0; d0 = d2; d2 = t;
+            if (VECTORS) { double u = q00; q00 = q02; q02 = u; u = q10; q10 = q12; q12 = u; u = q20; q20 = q22; q22 = u; }
+        }
+        if (d2 < d1) {
+            const double t = d1; d1 = d2; d2 = t;
+            if (VECTORS) { double u = q01; q01 = q02; q02 = u; u = q11; q11 = q12; q12 = u; u = q21; q21 = q22; q22 = u; }
         }
     }
-    for (int i = 0; i < 3; i++) s[i] = dg[i] * scale;
-    if (VECTORS) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) V[r][c] = q[r][c];
+    s[0] = d0 * scale; s[1] = d1 * scale; s[2] = d2 * scale;
+    if (VECTORS) { V[0][0] = q00; V[0][1] = q01; V[0][2] = q02; V[1][0] = q10; V[1][1] = q11; V[1][2] = q12; V[2][0] = q20; V[2][1] = q21; V[2][2] = q22; }
 }
 __host__ __device__ inline void eig33sym(const double K[3][3], double s[3], double V[3][3]) { eig33sym_t<true>(K, s, V); }
 
@@ -1109,18 +1136,34 @@ public:
         const int nWorkers = std::min(nFrames - 1, maxWorkers_);
         while ((int)ws_.size() < nWorkers + 1) ws_.emplace_back(new FrameSegmenter);
         std::atomic<int> next{0};
+        // An exception inside a worker (std::bad_alloc in a workspace, ...) must not terminate the process: the first one is kept, the other
+        // frames are abandoned, every started thread is joined, and the caller's thread rethrows it -- into the C ABI's exception barrier.
+        std::exception_ptr failure;
+        std::mutex failMutex;
         auto work = [&](FrameSegmenter &ws) {
-            for (;;) {
-                const int f = next.fetch_add(1);
-                if (f >= nFrames) break;
-                fn(f, ws);
+            try {
+                for (;;) {
+                    const int f = next.fetch_add(1);
+                    if (f >= nFrames) break;
+                    fn(f, ws);
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(failMutex);
+                if (!failure) failure = std::current_exception();
+                next.store(nFrames);
             }
         };
         std::vector<std::thread> threads;
         threads.reserve(nWorkers);
-        for (int t = 0; t < nWorkers; t++) threads.emplace_back([&, t]() { work(*ws_[t + 1]); });
+        try {
+            for (int t = 0; t < nWorkers; t++) threads.emplace_back([&, t]() { work(*ws_[t + 1]); });
+        } catch (...) {   // thread creation failed (std::system_error): the threads that did start finish the work together with the caller
+            std::lock_guard<std::mutex> g(failMutex);
+            if (getenv("MSL_PEAC_STRICT_THREADS") && !failure) failure = std::current_exception();
+        }
         work(*ws_[0]);
         for (auto &th : threads) th.join();
+        if (failure) std::rethrow_exception(failure);
     }
 
 private:
@@ -1249,18 +1292,21 @@ int device_fit(int device, const uint16_t *depth, size_t strideBytes, size_t fra
 
 extern "C" {
 
-void msl_peac_default_params(msl_peac_params *p) {   // ahc::ParamSet / ahc::PlaneFitter defaults (AHCParamSet.hpp:68-76, AHCPlaneFitter.hpp:157-161)
+void msl_peac_default_params(msl_peac_params *p) noexcept {
+    try {   // ahc::ParamSet / ahc::PlaneFitter defaults (AHCParamSet.hpp:68-76, AHCPlaneFitter.hpp:157-161)
     if (!p) return;
     p->window_w = 10; p->window_h = 10; p->min_support = 3000; p->max_step = 100000; p->do_refine = 1; p->erode_type = 2; p->init_loose = 0; p->_pad = 0;
     p->depth_sigma = 1.6e-6; p->std_tol_init = 5; p->std_tol_merge = 8; p->z_near = 500; p->z_far = 4000;
     p->angle_near = ((15.0) * M_PI / 180.0); p->angle_far = ((90.0) * M_PI / 180.0);
     p->similarity_th_merge = std::cos(((60.0) * M_PI / 180.0)); p->similarity_th_refine = std::cos(((30.0) * M_PI / 180.0));
     p->depth_alpha = 0.04; p->depth_change_tol = 0.02;
+    } MSL_ABI_CATCH_VOID
 }
 
 int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                        msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
-                       msl_peac_block *blocks_out, msl_mem out_mem) {
+                       msl_peac_block *blocks_out, msl_mem out_mem) noexcept {
+    try {
     if (!params || !blocks_out) { set_error("msl_peac_block_fit: invalid argument"); return MSL_ERR_INVALID; }
     std::lock_guard<std::mutex> lock(g_scratchMutex);
     msl_peac_block *dBlocks = nullptr;
@@ -1272,11 +1318,13 @@ int msl_peac_block_fit(int device, const uint16_t *depth, size_t depth_stride_by
     if (out_mem == MSL_MEM_HOST) PEAC_TRY(hipMemcpyAsync(blocks_out, dBlocks, sizeof(msl_peac_block) * nBlocks * n_frames, hipMemcpyDeviceToHost, st));
     PEAC_TRY(hipStreamSynchronize(st));
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                          msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, int window_w, int window_h, double depth_alpha,
-                         double depth_change_tol, int init_loose, double *cloud_out, msl_peac_stats *stats_out, msl_mem out_mem) {
+                         double depth_change_tol, int init_loose, double *cloud_out, msl_peac_stats *stats_out, msl_mem out_mem) noexcept {
+    try {
     if (!stats_out) { set_error("msl_peac_block_stats: invalid argument"); return MSL_ERR_INVALID; }
     msl_peac_params prm;
     msl_peac_default_params(&prm);
@@ -1315,6 +1363,7 @@ int msl_peac_block_stats(int device, const uint16_t *depth, size_t depth_stride_
         PEAC_TRY(hipStreamSynchronize(st));
     }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 }  // extern "C"
@@ -1461,23 +1510,28 @@ extern "C" {
 
 int msl_peac_membership_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                               msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
-                              int32_t *membership_out, int32_t *n_planes_out) {
+                              int32_t *membership_out, int32_t *n_planes_out) noexcept {
+    try {
     return membership_impl(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, params,
                            membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
+    } MSL_ABI_CATCH_INT
 }
 int msl_peac_extract_batch(int device, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height, int n_frames,
                            msl_mem mem, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
                            int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
-                           int32_t *vertex_indices_out, double *cloud_out) {
+                           int32_t *vertex_indices_out, double *cloud_out) noexcept {
+    try {
     if (!planes_out) { set_error("msl_peac_extract_batch: planes_out is NULL (use msl_peac_membership_batch for the image alone)"); return MSL_ERR_INVALID; }
     return membership_impl(device, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, mem, fx, fy, cx, cy, depth_map_factor, params,
                            membership_out, n_planes_out, max_planes, planes_out, vertex_offsets_out, vertex_indices_out, cloud_out);
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width, int height,
                                  int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor, const msl_peac_params *params,
                                  int32_t *membership_out, int32_t *n_planes_out, int max_planes, msl_peac_plane *planes_out, int32_t *vertex_offsets_out,
-                                 int32_t *vertex_indices_out) {
+                                 int32_t *vertex_indices_out) noexcept {
+    try {
     if (!blocks || !depth || !params || !membership_out || params->min_support < 1 || params->window_w < 1 || params->window_h < 1 || width < 2 || height < 2 ||
         n_frames < 0 || depth_stride_bytes < (size_t)width * 2 || (planes_out && max_planes < 1) || ((vertex_offsets_out || vertex_indices_out) && !planes_out) ||
         ((vertex_offsets_out != nullptr) != (vertex_indices_out != nullptr)) || (vertex_indices_out && !params->do_refine)) {
@@ -1497,26 +1551,32 @@ int msl_peac_extract_from_blocks(const msl_peac_block *blocks, const uint16_t *d
     segment_frames(*params, blocks, nBlocks, half.data(), cw, ch, n_frames, fx, fy, cx, cy, depth_map_factor, membership_out, n_planes_out,
                    sinks.empty() ? nullptr : sinks.data());
     return check_sinks(sinks, max_planes);
+    } MSL_ABI_CATCH_INT
 }
 int msl_peac_membership_from_blocks(const msl_peac_block *blocks, const uint16_t *depth, size_t depth_stride_bytes, size_t frame_stride_bytes, int width,
                                     int height, int n_frames, float fx, float fy, float cx, float cy, float depth_map_factor,
-                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) {
+                                    const msl_peac_params *params, int32_t *membership_out, int32_t *n_planes_out) noexcept {
+    try {
     return msl_peac_extract_from_blocks(blocks, depth, depth_stride_bytes, frame_stride_bytes, width, height, n_frames, fx, fy, cx, cy, depth_map_factor, params,
                                         membership_out, n_planes_out, 0, nullptr, nullptr, nullptr);
+    } MSL_ABI_CATCH_INT
 }
 
 // Where a call of n_frames keyframes clusters: 1 = on the device (one wave per frame, ~13-20 ms per call whatever the number of frames), 0 = on
 // the host workers (~2 ms per frame and worker).  The device wins once a call holds more than about eight frames per worker this process may
 // use -- and the worker count is the CPU budget divided by LOCAL_WORLD_SIZE, so the 8 ranks of a node (2 workers each on a 16-CPU allowance)
 // take the device path for config 4's 128-keyframe calls instead of collapsing onto shared host cores.  MSL_PEAC_CLUSTER=host / device forces one side.
-int msl_debug_peac_cluster_on_device(int n_frames) {
+int msl_debug_peac_cluster_on_device(int n_frames) noexcept {
+    try {
     const char *mode = getenv("MSL_PEAC_CLUSTER");
     if (mode && !strcmp(mode, "host")) return 0;
     if (mode && !strcmp(mode, "device")) return 1;
     return n_frames > 8 * SegPool::get().workers() ? 1 : 0;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) {
+int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) noexcept {
+    try {
     if (n == 0) return MSL_OK;
     const int level = host_simd_level();
     if (!stats || !mse_out || !(lanes == 0 || lanes == 2 || lanes == 4 || lanes == 8 || lanes == 16)) { set_error("msl_debug_peac_mse: invalid argument"); return MSL_ERR_INVALID; }
@@ -1533,6 +1593,20 @@ int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double 
         for (int l = 0; l < lanes && i0 + l < n; l++) mse_out[i0 + l] = out[l];
     }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
+}
+
+
+// Test hook of the exception barrier (tests/test_abi.py): raises the given failure INSIDE the library, behind the boundary.
+//   0: std::bad_alloc  1: std::runtime_error  2: a non-standard exception  3: std::bad_alloc in a worker thread of the plane extractor's pool
+int msl_debug_throw(int kind) noexcept {
+    try {
+        if (kind == 0) throw std::bad_alloc();
+        if (kind == 1) throw std::runtime_error("msl_debug_throw");
+        if (kind == 2) throw 42;
+        if (kind == 3) SegPool::get().run(4, [](int f, FrameSegmenter &) { if (f == 2) throw std::bad_alloc(); });
+        return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 }  // extern "C"

@@ -429,7 +429,8 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
 
 extern "C" {
 
-msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy, float fuseFar, float fuseNear, int device) {
+msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float cy, float fuseFar, float fuseNear, int device) noexcept {
+    try {
     if (width < 16 || height < 16 || fx == 0 || fy == 0 || (width / SP) * (height / SP) >= IDX_PLANE || (long long)width * height >= (1ll << 31)) {
         set_error("msl_sf_create: width/height must be >= 16 with fewer than 65534 superpixels, fx and fy non-zero");
         return nullptr;
@@ -481,9 +482,11 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
     h->prof.nk = MSL_SF_NKERNELS;
     if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
     return h;
+    } MSL_ABI_CATCH_PTR
 }
 
-void msl_sf_destroy(msl_sf *h) {
+void msl_sf_destroy(msl_sf *h) noexcept {
+    try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->copyStream) (void)hipStreamSynchronize(h->copyStream);
@@ -502,9 +505,11 @@ void msl_sf_destroy(msl_sf *h) {
     if (h->copyStream) (void)hipStreamDestroy(h->copyStream);
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
     delete h;
+    } MSL_ABI_CATCH_VOID
 }
 
-int msl_sf_set_stream(msl_sf *h, void *hip_stream) {
+int msl_sf_set_stream(msl_sf *h, void *hip_stream) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -512,32 +517,39 @@ int msl_sf_set_stream(msl_sf *h, void *hip_stream) {
     if (h->ownStreams) { (void)hipStreamDestroy(h->preStream); (void)hipStreamDestroy(h->mapStream); }
     h->preStream = h->mapStream = (hipStream_t)hip_stream; h->ownStreams = false;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_set_batch_capacity(msl_sf *h, int max_frames) {
+int msl_sf_set_batch_capacity(msl_sf *h, int max_frames) noexcept {
+    try {
     if (!h || max_frames < 1 || max_frames > 4096) { set_error("msl_sf_set_batch_capacity: invalid argument"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
     if (max_frames == h->maxBatch) return MSL_OK;
     return alloc_slots(h, max_frames);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_sync(msl_sf *h) {
+int msl_sf_sync(msl_sf *h) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     return check_err(h);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_reserve(msl_sf *h, size_t capacity) {
+int msl_sf_map_reserve(msl_sf *h, size_t capacity) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     if (capacity <= h->mapCap) return MSL_OK;
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     return map_realloc(h, capacity, (size_t)h->h_ctr[0]);
+    } MSL_ABI_CATCH_INT
 }
 
 static int ensure_aos(msl_sf *h, size_t n) {
@@ -550,7 +562,8 @@ static int ensure_aos(msl_sf *h, size_t n) {
     return MSL_OK;
 }
 
-int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
+int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) noexcept {
+    try {
     if (!h || (n && !host)) return MSL_ERR_INVALID;
     h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
@@ -573,9 +586,11 @@ int msl_sf_map_upload(msl_sf *h, const msl_surfel *host, size_t n) {
     h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq; h->classicNext = true;
     drop_live_snapshots(h);   // a count recorded before the upload would otherwise lower the bound below n
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_snapshot(msl_sf *h) {
+int msl_sf_map_snapshot(msl_sf *h) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
@@ -598,9 +613,11 @@ int msl_sf_map_snapshot(msl_sf *h) {
     }
     h->snapN = n; h->snapValid = true; h->snapWide = h->h_ctr[13];
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_restore(msl_sf *h) {
+int msl_sf_map_restore(msl_sf *h) noexcept {
+    try {
     if (!h || !h->snapValid) { set_error("msl_sf_map_restore: no snapshot"); return MSL_ERR_INVALID; }
     h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
@@ -625,18 +642,22 @@ int msl_sf_map_restore(msl_sf *h) {
     h->liveBound = n; h->liveKnown = n; h->liveKnownKf = h->kfEnq; h->classicNext = true;
     drop_live_snapshots(h);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_size(msl_sf *h, size_t *n_out) {
+int msl_sf_map_size(msl_sf *h, size_t *n_out) noexcept {
+    try {
     if (!h || !n_out) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     *n_out = (size_t)h->h_ctr[0];
     return check_err(h);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) {
+int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) noexcept {
+    try {
     if (!h || !n_out) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
@@ -653,6 +674,7 @@ int msl_sf_map_download(msl_sf *h, msl_surfel *host, size_t cap, size_t *n_out) 
         MSL_HIP_TRY(hipStreamSynchronize(s));
     }
     return check_err(h);
+    } MSL_ABI_CATCH_INT
 }
 
 static int map_select(msl_sf *h, int mode, int arg, bool mark, msl_surfel *out, size_t cap, size_t *n_out, const char *what) {
@@ -684,17 +706,16 @@ static int map_select(msl_sf *h, int mode, int arg, bool mark, msl_surfel *out, 
     return MSL_OK;
 }
 
-int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out) {
-    return map_select(h, 0, pose_index, true, out, cap, n_out, "msl_sf_map_detach");
-}
-int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out) {
-    return map_select(h, 1, min_update_times, false, out, cap, n_out, "msl_sf_map_export");
-}
+int msl_sf_map_detach(msl_sf *h, int pose_index, msl_surfel *out, size_t cap, size_t *n_out) noexcept { try {
+    return map_select(h, 0, pose_index, true, out, cap, n_out, "msl_sf_map_detach"); } MSL_ABI_CATCH_INT }
+int msl_sf_map_export(msl_sf *h, int min_update_times, msl_surfel *out, size_t cap, size_t *n_out) noexcept { try {
+    return map_select(h, 1, min_update_times, false, out, cap, n_out, "msl_sf_map_export"); } MSL_ABI_CATCH_INT }
 // System::saveSurfels (src/System.cc:296-382) for the cloud SurfelMapping::Stop builds (src/SurfelMapping.cpp:62-104): the local surfels
 // seen at least min_update_times times (filtered on the device, map order), then the caller's inactive surfels.  ASCII PLY with the
 // element / property layout the reference hands to tinyply; NaN positions are skipped (:311-312); alpha = 1, quality = weight,
 // radius = size * 1000 (SurfelMapping.cpp:80).  Number formatting is that of a default std::ostream (tinyply itself is a third party).
-int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path) {
+int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactive, size_t n_inactive, const char *path) noexcept {
+    try {
     if (!h || !path || (n_inactive && !inactive)) { set_error("msl_sf_export_ply: invalid argument"); return MSL_ERR_INVALID; }
     size_t n = 0;
     int rc = msl_sf_map_export(h, min_update_times, nullptr, 0, &n);
@@ -722,9 +743,11 @@ int msl_sf_export_ply(msl_sf *h, int min_update_times, const msl_surfel *inactiv
     }
     os << "0 0 0 1 0 0 0 1 0 0 0 1 0 0 0 0 0 " << (int)count << " 1 0 0\n";
     return os.fail() ? MSL_ERR_INVALID : MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
+int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) noexcept {
+    try {
     if (!h || (n && !surfels)) { set_error("msl_sf_map_append: invalid argument"); return MSL_ERR_INVALID; }
     h->mirrorValid = false;
     MSL_HIP_TRY(hipSetDevice(h->device));
@@ -745,34 +768,41 @@ int msl_sf_map_append(msl_sf *h, const msl_surfel *surfels, size_t n) {
     MSL_HIP_TRY(hipStreamSynchronize(s));
     h->liveBound = cur + n; h->liveKnown = cur + n; h->liveKnownKf = h->kfEnq; h->classicNext = true;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray, size_t gray_stride,
                                size_t gray_frame_stride, const float *depth, size_t depth_stride, size_t depth_frame_stride,
                                const int32_t *member, size_t member_stride, size_t member_frame_stride, msl_mem img_mem,
-                               const float *poses_colmajor) {
+                               const float *poses_colmajor) noexcept {
+    try {
     if (!h) { set_error("msl_sf_fuse_resident_batch: NULL handle"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));
     return run_batch(h, n_frames, refs, gray, gray_stride, gray_frame_stride, depth, depth_stride, depth_frame_stride, member, member_stride,
                      member_frame_stride, img_mem, poses_colmajor, true);
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_sf_fuse_resident(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth,
                          size_t depth_stride, const int32_t *member, size_t member_stride, msl_mem img_mem,
-                         const float pose_colmajor[16]) {
+                         const float pose_colmajor[16]) noexcept {
+    try {
     if (!h) { set_error("msl_sf_fuse_resident: NULL handle"); return MSL_ERR_INVALID; }
     MSL_HIP_TRY(hipSetDevice(h->device));
     const int32_t ref = referenceFrameIndex;
     return run_batch(h, 1, &ref, gray, gray_stride, 0, depth, depth_stride, 0, member, member_stride, 0, img_mem, pose_colmajor, true);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) {
+int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) noexcept {
+    try {
     if (!h || !counters) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     counters[0] = h->h_ctr[4]; counters[1] = h->h_ctr[1]; counters[2] = h->h_ctr[2]; counters[3] = h->h_ctr[3]; counters[4] = h->h_ctr[0];
     return check_err(h);
+    } MSL_ABI_CATCH_INT
 }
 
 // Host-vector mode.  The caller's vector is the map for this call; what travels is kept to what has to:
@@ -783,7 +813,8 @@ int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) {
 //        one copy each, small gaps bridged; more than 64 runs collapse into fewer by bridging larger gaps).
 int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
                    const int32_t *member, size_t member_stride, const float pose_colmajor[16], msl_surfel *local, size_t n_local,
-                   msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags) {
+                   msl_surfel *new_out, size_t new_cap, size_t *n_new, unsigned flags) noexcept {
+    try {
     if (!h || !pose_colmajor || !n_new || (n_local && !local)) { set_error("msl_sf_fuse: invalid argument"); return MSL_ERR_INVALID; }
     if (new_cap < (size_t)h->dev.nseeds || !new_out) { set_error("msl_sf_fuse: new_cap must be >= (w/8)*(h/8) = %d", h->dev.nseeds); return MSL_ERR_CAPACITY; }
     MSL_HIP_TRY(hipSetDevice(h->device));
@@ -878,16 +909,20 @@ int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size
     MSL_HIP_TRY(hipStreamSynchronize(s));
     h->mirrorValid = true; h->mirrorN = n_local;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_sf_fuse(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
                 const int32_t *member, size_t member_stride, const float pose_colmajor[16], msl_surfel *local, size_t n_local,
-                msl_surfel *new_out, size_t new_cap, size_t *n_new) {
+                msl_surfel *new_out, size_t new_cap, size_t *n_new) noexcept {
+    try {
     return msl_sf_fuse_ex(h, referenceFrameIndex, gray, gray_stride, depth, depth_stride, member, member_stride, pose_colmajor, local, n_local, new_out,
                           new_cap, n_new, 0u);
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {
+int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) noexcept {
+    try {
     if (!h || !out) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -898,27 +933,33 @@ int msl_sf_debug_seeds(msl_sf *h, msl_seed *out) {
     MSL_HIP_TRY(hipMemcpy(fused.data(), h->d_fused + (size_t)h->dev.flagStride * h->lastSlot, ns, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < ns; i++) out[i].fused = fused[i] & 1;   // (2 = invalid candidate, not a fusion)
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) {
+int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) noexcept {
+    try {
     if (!h || !out) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = read_ctr(h);
     if (rc != MSL_OK) return rc;
     for (int i = 0; i < 16; i++) out[i] = h->h_ctr[i];
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words) {
+int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words) noexcept {
+    try {
     if (!h || !out || which < 0 || which > 1 || offset_words + n_words > h->mapCap) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
     MSL_HIP_TRY(hipMemcpy(out, (which == 0 ? h->d_srcOf : h->d_delList) + offset_words, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 // What an event pair carried by a dispatch (hipExtLaunchKernelGGL) reports for a kernel that does nothing: n launches of an empty kernel with
 // `grid` single-wave workgroups on the map stream.  bench.py quotes it next to the roofline kernel's event time: rocprofv3's kernel duration
 // (first wave start to last wave end) is shorter than the event time by about this much.
-int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us) {
+int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us) noexcept {
+    try {
     if (!h || !mean_us || n < 1 || grid < 1) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -932,8 +973,10 @@ int msl_sf_debug_event_overhead(msl_sf *h, int grid, int n, float *mean_us) {
     for (auto &e : ev) (void)hipEventDestroy(e);
     *mean_us = (float)(tot * 1e3 / n);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_sf_debug_index(msl_sf *h, int32_t *out) {
+int msl_sf_debug_index(msl_sf *h, int32_t *out) noexcept {
+    try {
     if (!h || !out) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -943,9 +986,11 @@ int msl_sf_debug_index(msl_sf *h, int32_t *out) {
     MSL_HIP_TRY(hipMemcpy(tmp.data(), h->d_index + (size_t)h->dev.pxStride * h->lastSlot, sizeof(unsigned short) * npx, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < npx; i++) out[i] = tmp[i];
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
-int msl_sf_profile_enable(msl_sf *h, int on) {
+int msl_sf_profile_enable(msl_sf *h, int on) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -953,13 +998,17 @@ int msl_sf_profile_enable(msl_sf *h, int on) {
     h->prof.drain();
     h->prof.set_mode(on);
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_sf_profile_stride(msl_sf *h, int stride) {
+int msl_sf_profile_stride(msl_sf *h, int stride) noexcept {
+    try {
     if (!h || stride < 1) return MSL_ERR_INVALID;
     h->prof.stride = stride;
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {
+int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) noexcept {
+    try {
     if (!h) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
@@ -967,8 +1016,9 @@ int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) {
     h->prof.drain();
     for (int i = 0; i < MSL_SF_NKERNELS; i++) { if (ms) ms[i] = h->prof.ms[i]; if (launches) launches[i] = h->prof.launches[i]; }
     return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
-int msl_debug_div100(const float *x_host, double *out_host, size_t n) { return sp_debug_div100(x_host, out_host, n); }
-const char *msl_sf_kernel_name(int k) { return (k >= 0 && k < MSL_SF_NKERNELS) ? kSfNames[k] : ""; }
+int msl_debug_div100(const float *x_host, double *out_host, size_t n) noexcept { try { return sp_debug_div100(x_host, out_host, n); } MSL_ABI_CATCH_INT }
+const char *msl_sf_kernel_name(int k) noexcept { try { return (k >= 0 && k < MSL_SF_NKERNELS) ? kSfNames[k] : ""; } MSL_ABI_CATCH_PTR }
 
 }  // extern "C"

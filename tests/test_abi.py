@@ -77,3 +77,40 @@ def test_synth_is_deterministic():
     assert all(np.array_equal(x, y) for x, y in zip(g1, g2))
     m = synth.surfel_map(1000)
     assert m.dtype.itemsize == 56 and np.array_equal(m, synth.surfel_map(1000))
+
+
+def test_no_exception_crosses_the_c_boundary(tmp_path):
+    """every entry point is noexcept and returns a status.  (1) every declaration of both headers carries MSL_NOEXCEPT and a C++17
+    compiler agrees (noexcept is part of the function type); (2) every extern "C" definition of the library is `noexcept { try { ... } MSL_ABI_CATCH_* }`;
+    (3) failures raised INSIDE the library -- std::bad_alloc, another std::exception, a non-standard one, std::bad_alloc in a worker thread of the
+    plane extractor's pool -- come back as MSL_ERR_NOMEM / MSL_ERR_INTERNAL with a message; the process lives on."""
+    import subprocess
+    from manhattanslam_amd import _lib
+    names = []
+    for hname in ("msl.h", "msl_debug.h"):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", hname)).read(), flags=re.S)
+        decls = re.findall(r"^MSL_API[^;]*;", src, flags=re.M)
+        assert decls and all(d.rstrip(";").rstrip().endswith("MSL_NOEXCEPT") for d in decls), [d for d in decls if "MSL_NOEXCEPT" not in d]
+        names += re.findall(r"MSL_API[^;(]*?\b(msl_\w+)\s*\(", src)
+    cpp = tmp_path / "noexcept_check.cpp"
+    cpp.write_text('#include "msl.h"\n#include "msl_debug.h"\n'
+                   "template <class R, class... A> constexpr bool ne(R (*)(A...) noexcept) { return true; }\n"
+                   "template <class R, class... A> constexpr bool ne(R (*)(A...)) { return false; }\n" +
+                   "".join(f'static_assert(ne(&{n}), "{n} is not noexcept");\n' for n in sorted(set(names))))
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(cpp)], check=True)
+    subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-x", "c", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "include", "msl_debug.h")], check=True)
+    csrc = os.path.join(ROOT, "manhattanslam_amd", "csrc")
+    allsrc = ""
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith(".hip"):
+            src = open(os.path.join(csrc, f)).read()
+            assert src.count(" noexcept {") == src.count("MSL_ABI_CATCH_"), f      # every noexcept entry has its try / catch
+            allsrc += src
+    for n in sorted(set(names)):
+        assert re.search(r"\b%s\s*\([^;{}]*\)\s*noexcept\s*\{" % n, allsrc), f"{n}: no noexcept definition behind the barrier"
+    lib = _lib.lib
+    want = {0: -6, 1: -7, 2: -7, 3: -6}     # MSL_ERR_NOMEM, MSL_ERR_INTERNAL
+    for kind, rc in want.items():
+        assert lib.msl_debug_throw(kind) == rc, kind
+        assert lib.msl_last_error()
+    assert lib.msl_debug_throw(99) == 0
