@@ -629,6 +629,12 @@ MSLO_API size_t mslo_fuse_map_compact(msl_surfel *local, size_t n_local, const m
     return l.size();
 }
 MSLO_API void mslo_inverse4f(const float *m, float *inv) { inverse4<float>(m, inv); }
+// For the differential tests (tests/test_oracle_differential.py): the double instantiation the plane fit uses, and getHuberNorm on a point list
+MSLO_API void mslo_inverse4d(const double *m, double *inv) { inverse4<double>(m, inv); }
+MSLO_API void mslo_huber_norm(const float *points_xyz, int n, float *nxyzb) {
+    std::vector<float> pts(points_xyz, points_xyz + 3 * (size_t)n);
+    Fusion::getHuberNorm(nxyzb[0], nxyzb[1], nxyzb[2], nxyzb[3], pts);
+}
 // the pinned (float chain) and the alternative (C ::fabs(double)) reading of src/SurfelFusion.cpp:488
 MSLO_API float mslo_update_diff(float a0, float a1, float b0, float b1, float c0, float c1, int double_overload) {
     return double_overload ? update_diff_double_overload(a0, a1, b0, b1, c0, c1) : update_diff(a0, a1, b0, b1, c0, c1);
