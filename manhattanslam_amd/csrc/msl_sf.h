@@ -19,23 +19,44 @@ constexpr int PROP_ROUNDS = 6;          // worklist relaxation rounds before the
 constexpr unsigned short IDX_NONE = 0xFFFF, IDX_PLANE = 0xFFFE;
 constexpr int LIST_D = 256;             // fastest compaction path: k_fuse hands over the few deleted slots directly
 constexpr int SCAN_ITEMS = 1024;        // surfels per workgroup and pass in the map-maintenance kernels (k_select_*)
-constexpr int SUB_ITEMS = 256;          // sub-block: the surfels one k_fuse wave owns = granularity of the deleted / updated partials
+// Sub-block: the surfels one k_fuse wave owns = the granularity of the deleted / updated partials.  128 (two records per lane) since round 5:
+// the wave with the most survivors fuses them in two rounds of gathers instead of four, which is what bounds the kernel -- on the dense map, whole
+// front end, same box: 256 -> 128 -> 64 surfels per wave: k_fuse 16.2 -> 14.8 -> 14.7 us in the timed region (13.2 alone either way), frames/s
+// 22 300 -> 22 080 -> 21 380 (every wave carries ~130 instructions of fixed cost, VALU time the frame-batched kernels lose).
+#ifndef MSL_SUB_ITEMS
+#define MSL_SUB_ITEMS 128
+#endif
+constexpr int SUB_ITEMS = MSL_SUB_ITEMS;
 constexpr int DEFER_WIN = 32;           // keyframes per deferred-compaction window (one replay per window)
+// FuseRec (what k_fuse reads of a seed: three 16-byte words) as one 48-byte record per seed, or as three planes of 16-byte words
+#ifndef MSL_FUSEREC_PLANES
+#define MSL_FUSEREC_PLANES 0
+#endif
+__host__ __device__ inline size_t fuserec_index(int nseeds, unsigned seed, int word) {
+#if MSL_FUSEREC_PLANES
+    return (size_t)word * (size_t)nseeds + seed;
+#else
+    (void)nseeds; return 3 * (size_t)seed + (size_t)word;
+#endif
+}
 
 // Device-resident surfel map, split hot/cold.  The fuse kernel streams only the hot records (what decides a surfel's fate for the ones that
 // leave early) and touches the cold record of those it updates.
 // Hot record, 16 bytes (round 5; 20 bytes before): position + ONE word for updateTimes / lastUpdate, so that a record is one aligned
 // dwordx4 access and an updated record is written back as a whole 16-byte piece of a sector.
-//   tl bit 31 clear: bits 30..20 = updateTimes (0 .. 2047), bits 19..0 = lastUpdate (0 .. 1048575)
+//   tl bit 31 clear: bits 30..20 = updateTimes (0 .. 2047), bits 19..0 = lastUpdate as a 20-bit two's complement number (-524288 .. 524287:
+//                    maps seeded "a few keyframes before keyframe 0", like bench.py's, carry small negative indices)
 //   tl == HOT_WIDE : the exact ints live in utlWide[2 i], utlWide[2 i + 1] (values outside those ranges; only maps uploaded by the caller or
-//                    sequences beyond 2047 fusions of one surfel / a million keyframes) -- every accessor honours it
+//                    sequences beyond 2047 fusions of one surfel / half a million keyframes) -- every accessor honours it
 //   tl == HOT_HOLE : deferred compaction only: a slot deleted earlier in the current window, already in the deletion log (never survives a
 //                    window: the replay fills or truncates every hole)
 struct alignas(16) HotPk { float px, py, pz; unsigned tl; };
 struct HotRec { float px, py, pz; int updateTimes, lastUpdate; };   // the unpacked form kernels compute with
 constexpr unsigned HOT_WIDE = 0x80000000u, HOT_HOLE = 0xFFFFFFFFu;
-__host__ __device__ inline bool tl_fits(int ut, int lu) { return (unsigned)ut < 2048u && (unsigned)lu < (1u << 20); }
-__host__ __device__ inline unsigned tl_pack(int ut, int lu) { return ((unsigned)ut << 20) | (unsigned)lu; }
+__host__ __device__ inline bool tl_fits(int ut, int lu) { return (unsigned)ut < 2048u && (unsigned)(lu + (1 << 19)) < (1u << 20); }
+__host__ __device__ inline unsigned tl_pack(int ut, int lu) { return ((unsigned)ut << 20) | ((unsigned)lu & 0xFFFFFu); }
+__host__ __device__ inline int tl_ut(unsigned tl) { return (int)(tl >> 20); }                 // (of a record with bit 31 clear)
+__host__ __device__ inline int tl_lu(unsigned tl) { return (int)(tl << 12) >> 12; }
 // 32 bytes, 32-byte aligned: a fused surfel touches exactly one 32-byte sector of its cold record.  r, g, b always come from a cv::Vec3b
 // (src/SurfelFusion.cpp:484, 551), so they travel as three bytes; a record whose ints do not fit a byte (only possible for maps uploaded by
 // the caller) sets COLD_WIDE and keeps the exact ints in rgbWide[3 i ..].
@@ -83,13 +104,12 @@ struct FuseAux {
     unsigned long long cap;
     unsigned *delU, *delUCount;     // classic: the hand-over list of k_compact and its length
     unsigned *delList;              // deferred: the window's deletion log
-    unsigned *blockSums, *blockUpd; // per-sub-block deleted / updated counts (blockUpd: DEFER_WIN slices of blkStride entries)
-    unsigned long long blkStride;
 };
 // Deferred compaction (round 5): what the fuse launches of one window leave for the replay.
 struct DeferCtl {
     long long ext[DEFER_WIN + 1];   // ext[f]: physical extent of the array the fuse launch of keyframe f works on (= ext[f - 1] + new surfels of f - 1)
-    unsigned delCnt[DEFER_WIN];     // deleted slots keyframe f logged (its log starts at the sum of the counts before it)
+    unsigned delCnt[DEFER_WIN];     // deleted slots keyframe f logged
+    unsigned logBase[DEFER_WIN];    // ... behind the entries of the keyframes before it: logBase[f] = sum of delCnt[0 .. f - 1] (written by launch f)
     unsigned nMoves;                // replay -> gather / scatter
     int flagStride;                 // = SfDev::flagStride
     // bases of the superpixel stage's candidate arrays (all slots; static per allocation): the launch of keyframe kf materialises the new

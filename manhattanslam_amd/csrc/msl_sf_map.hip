@@ -35,7 +35,7 @@ __device__ __forceinline__ void set_wide_flag_ptr(long long *flag, unsigned long
 __device__ __forceinline__ void set_wide_flag(const MapSoA &M, unsigned long long bit) { set_wide_flag_ptr(M.wideFlag, bit); }
 // updateTimes / lastUpdate of a record whose packed word is tl (the side array only for HOT_WIDE: rare)
 __device__ __forceinline__ void tl_unpack(const MapSoA &M, long long i, unsigned tl, int &ut, int &lu) {
-    ut = (int)(tl >> 20); lu = (int)(tl & 0xFFFFFu);
+    ut = tl_ut(tl); lu = tl_lu(tl);
     if (tl & 0x80000000u) {
         if (tl == HOT_WIDE) { ut = M.utlWide[2 * i]; lu = M.utlWide[2 * i + 1]; }
         else { ut = 0; lu = 0; }   // HOT_HOLE
@@ -140,9 +140,6 @@ __device__ __forceinline__ void st16(void *p, u32x4 v) {
 struct FuseFrame {
     float inv[12];   // rows 0..2 of pose.inverse(), inv[3 c + r] = invPose[4 c + r] (the fourth row is never used)
     int ref;
-#ifdef MSL_FUSE_KARG_POSE
-    float rot[9];
-#endif
     const FrameDev *frame;   // the keyframe's device record: the pose itself (only the update path of phase B rotates a normal back into the world)
 };
 struct FuseArgs {
@@ -152,9 +149,9 @@ struct FuseArgs {
     const uint2 *tex; const float4 *fuseRec; uint8_t *fused;   // this keyframe's slot
     HotPk *hot; ColdRec *cold;
     long long *ctr;
-#ifdef MSL_FUSE_KARG_BLK
-    unsigned *blockSums, *blockUpd;
-#endif
+    unsigned *blockSums, *blockUpd;   // per-sub-block deleted (classic) / updated counts (deferred: the keyframe's slice)
+    unsigned *delOut;              // where deleted slots go: classic delU[LIST_D] (k_compact's hand-over list), deferred the window's deletion log
+    unsigned *delCount;            // ... and their count: classic delUCount, deferred DeferCtl::delCnt[kf]
     DeferCtl *dc;                  // extents and deletion counts of a deferred window; and what only a few waves per launch need (DeferCtl::aux):
                                    // side arrays of wide records, deletion lists, capacity -- loaded where they are used instead of living in scalar
                                    // registers through the whole kernel
@@ -166,19 +163,15 @@ __host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
     A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
     A.hot = P.map.hot; A.cold = P.map.cold; A.ctr = P.ctr;
     A.dc = P.dc;
-#ifdef MSL_FUSE_KARG_BLK
-    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd + (size_t)(deferred ? P.kf : 0) * (P.cap / SUB_ITEMS + 4100);
-#endif
-    (void)deferred;
+    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd + (size_t)(deferred ? P.kf : 0) * (P.cap / SUB_ITEMS + 4100);   // (= blkStride of map_realloc)
+    A.delOut = deferred ? P.delList : P.delU;
+    A.delCount = deferred ? &P.dc->delCnt[P.kf < DEFER_WIN ? P.kf : 0] : P.delUCount;
     return A;
 }
 __host__ inline FuseFrame fuse_frame(const FrameDev &F, const FrameDev *dev) {
     FuseFrame f;
     for (int c = 0; c < 4; c++) for (int r = 0; r < 3; r++) f.inv[3 * c + r] = F.invPose[4 * c + r];
     f.ref = F.ref; f.frame = dev;
-#ifdef MSL_FUSE_KARG_POSE
-    for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) f.rot[3 * c + r] = F.pose[4 * c + r];
-#endif
     return f;
 }
 // mul4 / mul3 of msl_sf.h on the packed rows: the same products and the same association
@@ -283,7 +276,7 @@ __device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, lo
 //   updated counts go to blockSums / blockUpd with plain stores.
 // DEFER = true: deleted slots become HOT_HOLE and go to the window's deletion log; the launch of keyframe kf > 0 first materialises the new
 //   surfels of keyframe kf - 1 behind the array (emit_pending, frontier waves only) and works on the extent that results.
-template <bool DEFER>
+template <bool DEFER, bool spawnWave>
 __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F, int nSubHint, unsigned waveIdx, int G) {
     constexpr int KPL = SUB_ITEMS / 64;        // records per lane; a wave owns WSPAN = SUB_ITEMS consecutive surfels (2 per lane, twice the waves: k_fuse itself
                                                // 1.4 us shorter alone and 2.8 us in the timed region, the front end 4 % slower -- the per-wave overhead is VALU time
@@ -300,9 +293,23 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
     const float halfF = 0.5f * cameraF;   // BASELINE * cameraF (:220), exact
     // deferred, keyframe kf > 0: E0 = the extent keyframe kf - 1 worked on; its new surfels follow from there
     const bool pending = DEFER && P.kf > 0;
+    long long E0v = 0;   // (requested here, first used behind the hot records of the wave's first sub-block: the two travel together)
+    if (pending) E0v = P.dc->ext[P.kf - 1];
     long long E0 = 0;
-    if (pending) E0 = P.dc->ext[P.kf - 1];
+    if (DEFER && spawnWave) E0 = ((long long)__builtin_amdgcn_readfirstlane((int)(E0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)E0v);
+    if (spawnWave && !pending) return;   // (the first keyframe of a window has nothing to materialise)
     if (DEFER && !pending && waveIdx == 0 && lane0 == 0) P.dc->ext[0] = P.ctr[0];
+    if (DEFER && !spawnWave && waveIdx == 0 && lane0 == 0) P.dc->logBase[P.kf] = P.kf > 0 ? P.dc->logBase[P.kf - 1] + P.dc->delCnt[P.kf - 1] : 0u;   // where this keyframe's log entries start
+    // The spawn wave (deferred, one per launch, dispatched first): the new surfels of keyframe kf - 1 go to the physical slots E0, E0 + 1, ...; this
+    // wave counts them (one trip over the lattice's flag words), publishes the extent for the next launch, and -- only if there are any -- writes
+    // them and fuses them itself, 256 at a time.  No other wave of the launch ever waits for the count: they work on the slots below E0.
+    unsigned spK = 0;
+    if (DEFER && spawnWave) {
+        unsigned excl;
+        spK = spawn_count(P, lane0, excl);
+        if (lane0 == 0) P.dc->ext[P.kf] = E0 + (long long)spK;
+        if (spK == 0) return;
+    }
     // Wave g owns sub-block G - 1 - g (the newest surfels -- nearly all in view: most phase-B work -- are dispatched first) and, should the
     // map have outgrown the grid, G - 1 - g + G, ... (grid-stride; normally one iteration).  The grid covers the host's last KNOWN live count
     // plus a margin, not its upper bound.  Sub-blocks below nSubHint load at once; above it the wave reads the live count first and leaves if
@@ -310,82 +317,104 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
     // Workgroups are dispatched round-robin over the 8 XCDs: give each XCD runs of FUSE_CHUNK consecutive sub-blocks (neighbouring surfels
     // project to neighbouring pixels, so an XCD's L2 fetches a part of the texel map instead of all of it; small enough runs keep the XCDs
     // balanced -- whole eighths of the map were 2 x slower).
-    constexpr unsigned FUSE_CHUNK = 16;
+#ifndef MSL_FUSE_CHUNK
+#define MSL_FUSE_CHUNK 16
+#endif
+    constexpr unsigned FUSE_CHUNK = MSL_FUSE_CHUNK;
     long long lin = waveIdx;
     {
         constexpr unsigned T = 8u * FUSE_CHUNK;
         const unsigned full = ((unsigned)G / T) * T;
         if (waveIdx < full) { const unsigned grp = waveIdx / T, r = waveIdx % T; lin = (long long)grp * T + (r & 7u) * FUSE_CHUNK + (r >> 3); }
     }
-    for (long long sb = (long long)G - 1 - lin;; sb += G) {
+    for (long long it = 0;; it++) {
         // (the lane number is re-materialised per iteration: values derived from it are then not hoisted out of this -- normally single-trip --
         // loop and kept in registers / scratch for its whole body)
         unsigned lane = lane0;
         asm volatile("" : "+v"(lane));
-        const long long c0 = sb * WSPAN;
-        long long n = 0;
 #define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
-        const long long rel = c0 - E0;   // (everything in terms of this difference: E0 + nseeds would be one more loop-invariant register pair)
-        if (pending) {
-            if (rel >= (long long)P.nseeds) return;   // beyond anything keyframe kf - 1 can have spawned
-            n = E0;   // (not a frontier wave: every record of this sub-block lies below the extent)
-            if (rel + WSPAN > 0) {
-                // A frontier wave: it needs the new surfels of keyframe kf - 1 first.  One word of each of its hot records is requested now and only
-                // consumed behind the flag scan -- the records' cache lines travel beside the flag words and wait in the caches for the loads proper
-                // below, so that in the steady state (nothing spawned) the scan costs this wave, the first of the launch and the one with the most
-                // survivors, a cache hit instead of a round trip.  (Plain loads the compiler counts: a load hidden in inline asm would break its
-                // s_waitcnt accounting for the flag words.)
-                unsigned pf[KPL];
-#pragma unroll
-                for (int k = 0; k < KPL; k++) pf[k] = M.hot[c0 + REC_LOCAL(k)].tl;
-                unsigned excl;
-                const unsigned K = spawn_count(P, lane, excl);
-                for (int k = 0; k < KPL; k++) asm volatile("" ::"v"(pf[k]));
-                n = E0 + (long long)K;
-                if (c0 <= E0 && lane == 0) P.dc->ext[P.kf] = n;   // (exactly one sub-block contains E0)
-                if (c0 >= n) return;
-                if (K) emit_records(P, E0, c0, KPL, lane, K, excl);
-            }
-        } else if (sb >= nSubHint && c0 >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        const long long sb = (long long)G - 1 - lin + it * G;   // regular waves: the sub-block; grid-stride should the map have outgrown the grid
+        long long c0, n = 0, cntIdx;
+        if (DEFER && spawnWave) {
+            c0 = E0 + it * WSPAN;
+            n = E0 + (long long)spK;
+            if (c0 >= n) return;
+            unsigned excl;   // (the per-lane prefix again rather than a register kept through the whole body: this path runs when a keyframe spawned something)
+            (void)spawn_count(P, lane, excl);
+            emit_records(P, E0, c0, KPL, lane, spK, excl);
+            cntIdx = E0 / SUB_ITEMS + 1 + it;   // its updated counts sit behind those of the sub-blocks below E0 (k_defer_tail adds them up)
+        } else {
+            c0 = sb * WSPAN; cntIdx = sb;
+            if (pending) {
+                // (the grid lies inside the capacity, so a wave's FIRST sub-block is requested before the extent has arrived; the slots from E0 on belong
+                // to the spawn wave: sub-blocks wholly beyond E0 leave below, records beyond it inside a sub-block fail the `i < n` test)
+                if (it > 0) {
+                    E0 = ((long long)__builtin_amdgcn_readfirstlane((int)(E0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)E0v);
+                    if (c0 >= E0) return;
+                }
+            } else if (sb >= nSubHint && c0 >= __hip_atomic_load(&P.ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        }
         // lane l owns records l, 64 + l, 128 + l, 192 + l of the sub-block: the survivors' rank order (k, lane) is then the array order, so
         // neighbouring lanes of phase B work on neighbouring records and their gathers and stores share cache lines
         HotPk hq[KPL];
 #pragma unroll
         for (int k = 0; k < KPL; k++) hq[k] = M.hot[c0 + REC_LOCAL(k)];
         if (!pending) n = P.ctr[0];
+        else if (!spawnWave) {
+            E0 = ((long long)__builtin_amdgcn_readfirstlane((int)(E0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)E0v);
+            if (c0 >= E0) return;
+            n = E0;
+        }
         unsigned stp = 0;  // two bits per record: 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
         float pzv[KPL];
         unsigned offT[KPL];
+        // rare: a record with exact ints in the side array, or a slot the window has logged already -- ONE test for the lane's four records
+        unsigned anyTl = 0;
+#pragma unroll
+        for (int k = 0; k < KPL; k++) anyTl |= hq[k].tl;
+        const bool anyHi = __builtin_expect(__ballot(anyTl >> 31) != 0ull, 0);
 #pragma unroll
         for (int k = 0; k < KPL; k++) {
             const long long i = c0 + REC_LOCAL(k);
             const float x = hq[k].px, y = hq[k].py, z = hq[k].pz;
             const unsigned tl = hq[k].tl;
-            int ut = (int)(tl >> 20), lu = (int)(tl & 0xFFFFFu);
+            int ut = tl_ut(tl), lu = tl_lu(tl);
             bool hole = false;
-            if (__builtin_expect(__ballot(tl >> 31) != 0ull, 0)) {   // rare: exact ints in the side array / a slot the window has logged already
+            if (anyHi) {
                 if (tl == HOT_WIDE) { const int *w = aux->map.utlWide; ut = w[2 * i]; lu = w[2 * i + 1]; }
                 else if (tl & 0x80000000u) hole = true;
             }
             float pc[3];
             mul4r(F.inv, x, y, z, 1.0f, pc);
             const bool inRange = !(pc[2] < P.fuseNear || pc[2] > P.fuseFar);
-            const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
-            const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
-            const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
-            const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+            const bool live = i < n && !hole, stale = ref - lu > 5 && ut < 5;
+            // what does not need the projection: stale -> delete (1), already deleted (2), out of range (0)
             int st = 0;
-            if (i < n && !hole) st = (ref - lu > 5 && ut < 5) ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : ((inRange && inImage) ? 3 : 0));
+            if (live) st = stale ? (ut != 0 ? 1 : 2) : (ut == 0 ? 2 : 0);
+            const bool cand = live && !stale && ut != 0 && inRange;
+            unsigned off = 0;
+            // (branch-free on purpose.  Skipping the two divisions, the roundings and the image test for 64-record groups that lie outside the frustum
+            // as a whole -- `if (__ballot(cand))` -- measured 0.5 us SLOWER alone and no faster beside the frame-batched kernels: the kernel is
+            // bound by its chain of memory round trips, not by these instructions)
+            {
+                const float zq = inRange ? pc[2] : 1.0f;   // keeps the (unused) quotients of skipped surfels finite
+                const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
+                const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
+                const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
+                if (cand && inImage) st = 3;
+                const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
+                off = (unsigned)(pVc * P.W + pUc);
+            }
             stp |= (unsigned)st << (2 * k); pzv[k] = pc[2];
-            const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
-            offT[k] = (unsigned)(pVc * P.W + pUc);
+            offT[k] = off;
         }
         uint2 tx[KPL];
 #pragma unroll
         for (int k = 0; k < KPL; k++) tx[k] = tex[offT[k]];
         // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
         // round trip back into up to four dependent ones
-        asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+        if constexpr (KPL == 4) asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+        else asm volatile("" ::"v"(tx[0].x), "v"(tx[KPL - 1].x), "v"(tx[0].y), "v"(tx[KPL - 1].y));
         // ---- classification: deletions of phase A, survivors ----
         // (one bit field per lane instead of eight lane masks: the masks would live in scalar registers, which this kernel is short of)
         unsigned fl = 0;   // bit k: record k deleted in phase A; bit 4 + k: record k survives into phase B
@@ -396,29 +425,27 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const bool occluded = st == 3u && (double)pzv[k] < (double)__uint_as_float(tx[k].x) - 1.0;
             const bool del = st == 1u || st == 2u || occluded;
             if (DEFER) { if (del) M.hot[c0 + REC_LOCAL(k)].tl = HOT_HOLE; }
-            else if (st == 1u || occluded) hot_mark_deleted(aux->map, c0 + REC_LOCAL(k), M.hot[c0 + REC_LOCAL(k)].tl);   // (rare: the word is read again rather than kept)
+            else if (st == 1u || occluded) {   // updateTimes = 0, lastUpdate stays (:201; the host-vector drop-in hands the record back)
+                if (__builtin_expect(hq[k].tl == HOT_WIDE, 0)) aux->map.utlWide[2 * (c0 + REC_LOCAL(k))] = 0;
+                else M.hot[c0 + REC_LOCAL(k)].tl = hq[k].tl & 0xFFFFFu;
+            }
             fl |= del ? (1u << k) : 0u;
             fl |= (st == 3u && !occluded) ? (16u << k) : 0u;
             cntDel += (unsigned)__popcll(__ballot(del));
         }
         // deleted slots: classic -> delU (k_compact's fast path), deferred -> the window's log behind the entries of the keyframes before
+        // (a wave that deletes is rare but often among the last to finish: everything it needs travels in ONE round trip -- the count's atomic and, for
+        // a deferred keyframe, the log position the keyframes before left, dc->logBase[kf - 1] + dc->delCnt[kf - 1])
         auto list_base = [&](unsigned c) -> unsigned {
-            unsigned base = 0;
-            if (DEFER) {
-                for (int q = 0; q < P.kf; q++) base += P.dc->delCnt[q];
-                unsigned b2 = 0;
-                if (lane == 0) b2 = atomicAdd(&P.dc->delCnt[P.kf], c);
-                base += (unsigned)__builtin_amdgcn_readfirstlane((int)b2);
-            } else {
-                if (lane == 0) base = atomicAdd(aux->delUCount, c);
-                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            }
-            return base;
+            unsigned base = 0, prior = 0;
+            if (DEFER && P.kf > 0) prior = P.dc->logBase[P.kf - 1] + P.dc->delCnt[P.kf - 1];
+            if (lane == 0) base = atomicAdd(P.delCount, c);
+            return (unsigned)__builtin_amdgcn_readfirstlane((int)base) + prior;
         };
         auto hand_over = [&](bool d, unsigned long long m, unsigned base, long long i) {
             if (d) {
                 const unsigned j = base + lane_rank(m);
-                if (DEFER ? j < aux->cap : j < (unsigned)LIST_D) (DEFER ? aux->delList : aux->delU)[j] = (unsigned)i;
+                if (DEFER || j < (unsigned)LIST_D) P.delOut[j] = (unsigned)i;   // (the log holds one entry per physical slot at most: it cannot overflow the capacity)
             }
         };
         if (cntDel) {   // rare: a handful of slots per keyframe
@@ -459,9 +486,14 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const unsigned sp = item >> 16;
             const HotPk h = M.hot[i];
             ColdRec c = M.cold[i];
-            const float4 f0 = fuseRec[sp], f1 = fuseRec[P.nseeds + sp], f2 = fuseRec[2 * (size_t)P.nseeds + sp];
+            const float4 f0 = fuseRec[fuserec_index(P.nseeds, sp, 0)], f1 = fuseRec[fuserec_index(P.nseeds, sp, 1)], f2 = fuseRec[fuserec_index(P.nseeds, sp, 2)];
+            // the rotation of the pose (only the update path needs it, to turn the fused normal back into the world): three 12-byte loads from the
+            // keyframe's device record, requested HERE with the records -- left to the compiler they sat behind the tests, one more dependent round
+            // trip in every round (k_fuse 18.1 against 16.5 us under rocprofv3); as kernel arguments they cost nine scalar registers this kernel lacks
+            const float *poseM = F.frame->pose;
+            const float r00 = poseM[0], r10 = poseM[1], r20 = poseM[2], r01 = poseM[4], r11 = poseM[5], r21 = poseM[6], r02 = poseM[8], r12 = poseM[9], r22 = poseM[10];
             // common use of one field per load instruction: all records are in flight together
-            asm volatile("" ::"v"(h.px), "v"(h.tl), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x));
+            asm volatile("" ::"v"(h.px), "v"(h.tl), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x), "v"(r00), "v"(r01), "v"(r02));
             bool upd = false, delB = false;
             if (item && __float_as_uint(f2.w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
                 const float seedDepth = f0.w;
@@ -477,7 +509,9 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                     mul3r(F.inv, c.nx, c.ny, c.nz, nc);
                     const float normDiffCos = nc[0] * f0.x + nc[1] * f0.y + nc[2] * f0.z;
                     if (normDiffCos < MAX_ANGLE_COS) {
-                        if (DEFER) M.hot[i].tl = HOT_HOLE; else hot_mark_deleted(aux->map, i, h.tl);
+                        if (DEFER) M.hot[i].tl = HOT_HOLE;
+                        else if (__builtin_expect(h.tl == HOT_WIDE, 0)) aux->map.utlWide[2 * i] = 0;
+                        else M.hot[i].tl = h.tl & 0xFFFFFu;
                         delB = true;
                     } else {
                         const float oldWeight = c.weight;
@@ -494,11 +528,9 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                         const float newNormLength = sqrtf(fusedNx * fusedNx + fusedNy * fusedNy + fusedNz * fusedNz);
                         fusedNx = fusedNx / newNormLength; fusedNy = fusedNy / newNormLength; fusedNz = fusedNz / newNormLength;
                         float newNormW[3];
-#ifdef MSL_FUSE_KARG_POSE
-                        mul3r(F.rot, fusedNx, fusedNy, fusedNz, newNormW);
-#else
-                        mul3(F.frame->pose, fusedNx, fusedNy, fusedNz, newNormW);
-#endif
+                        newNormW[0] = (r00 * fusedNx + r01 * fusedNy) + r02 * fusedNz;   // mul3(pose, ...): the same products, the same association
+                        newNormW[1] = (r10 * fusedNx + r11 * fusedNy) + r12 * fusedNz;
+                        newNormW[2] = (r20 * fusedNx + r21 * fusedNy) + r22 * fusedNz;
                         int ut = (int)(h.tl >> 20);   // (a survivor is never a hole; HOT_WIDE: the side array)
                         if (__builtin_expect(h.tl == HOT_WIDE, 0)) ut = aux->map.utlWide[2 * i];
                         unsigned tlNew = tl_pack(ut + 1, ref);             // updateTimes + 1, lastUpdate = reference index (:275-276)
@@ -535,16 +567,11 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             }
         }
         if (lane == 0) {   // per-sub-block counts: deleted (classic: the slow paths of k_compact, the host-vector download), updated (deferred: the keyframe's slice)
-#ifdef MSL_FUSE_KARG_BLK
-            if (!DEFER) P.blockSums[sb] = cntDel + cntDelB;
-            P.blockUpd[sb] = nupd;
-#else
-            if (!DEFER) aux->blockSums[sb] = cntDel + cntDelB;
-            aux->blockUpd[(size_t)(DEFER ? P.kf : 0) * aux->blkStride + sb] = nupd;
-#endif
+            if (!DEFER) P.blockSums[cntIdx] = cntDel + cntDelB;
+            P.blockUpd[cntIdx] = nupd;
         }
         // (normally) nothing beyond the grid; a deferred launch decides at the head of the loop (the new surfels may reach into the next sub-block)
-        if (pending ? rel + (long long)G * WSPAN >= (long long)P.nseeds : (sb + G) * WSPAN >= n) return;
+        if (!(DEFER && spawnWave) && (sb + G) * WSPAN >= n) return;   // (n = E0 for a pending launch's regular waves)
     }
 #undef REC_LOCAL
 }
@@ -552,7 +579,10 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
 template <bool DEFER>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fuse(FuseArgs P, FuseFrame F, int nSubHint) {   // by value: kernarg -> SGPRs; 8 waves / SIMD = 64 VGPRs
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
-    fuse_body<DEFER>(P, F, nSubHint, blockIdx.x, (int)gridDim.x);
+    if (DEFER) {
+        if (blockIdx.x == 0) fuse_body<DEFER, true>(P, F, nSubHint, 0u, (int)gridDim.x - 1);   // workgroup 0: the spawn wave (its own instantiation: what it
+        else fuse_body<DEFER, false>(P, F, nSubHint, blockIdx.x - 1u, (int)gridDim.x - 1);     // carries through the loop costs the other waves no register)
+    } else fuse_body<false, false>(P, F, nSubHint, blockIdx.x, (int)gridDim.x);
 }
 
 constexpr int TAIL_MAX_HOPS = 64;   // relay hops resolved per hole before the literal loop takes over (k_compact)
@@ -715,7 +745,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
             unsigned base = 0;
             for (unsigned it = 0; it < nz; it++) {
                 const long long i0 = (long long)s_nzSortIdx[it] * SUB_ITEMS + threadIdx.x;   // one slot per thread: ascending
-                const unsigned f = (i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
+                const unsigned f = (threadIdx.x < (unsigned)SUB_ITEMS && i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
                 unsigned tt;
                 const unsigned w = base + block_excl_scan(f, s_wave, &tt);
                 if (f) s_dl[w] = (unsigned)i0;
@@ -744,7 +774,7 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                     const unsigned base = s_base, cntChunk = s_cntChunk;
                     if (cntChunk == 0) { __syncthreads(); continue; }   // nothing deleted in this sub-block
                     const long long i0 = b * SUB_ITEMS + threadIdx.x;       // one slot per thread keeps the list ascending
-                    const unsigned f = (i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
+                    const unsigned f = (threadIdx.x < (unsigned)SUB_ITEMS && i0 < n && hot_is_deleted(P.map, i0)) ? 1u : 0u;
                     unsigned tt;
                     const unsigned w = base + block_excl_scan(f, s_wave, &tt);   // (its barriers also protect s_base)
                     if (f) st_agent(&P.delList[w], (unsigned)i0);
@@ -846,10 +876,14 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x < F) {
         const int f = (int)blockIdx.x;
-        const long long nblk = (P.dc->ext[f] + SUB_ITEMS - 1) / SUB_ITEMS;   // (one count per k_fuse wave)
+        // keyframe f's counts: one per sub-block below the extent its regular waves worked on, and behind them (from index (E0 >> 8) + 1 on) one per
+        // 256 new surfels of keyframe f - 1 that its spawn wave wrote and fused
+        const long long E0 = f > 0 ? P.dc->ext[f - 1] : P.dc->ext[0], Kp = f > 0 ? P.dc->ext[f] - E0 : 0;
+        const long long nblk = (E0 + SUB_ITEMS - 1) / SUB_ITEMS, x0 = E0 / SUB_ITEMS + 1, x1 = x0 + (Kp + SUB_ITEMS - 1) / SUB_ITEMS;
         const unsigned *bu = P.blockUpd + (size_t)f * blkStride;
         unsigned u = 0;
         for (long long b = lane; b < nblk; b += 64) u += bu[b];
+        for (long long b = x0 + lane; b < x1; b += 64) u += bu[b];
         u = wave_incl_scan(u);
         if (lane == 63) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&P.ctr[10]), (unsigned long long)u);
@@ -858,7 +892,7 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
         return;
     }
     const long long E0 = P.dc->ext[F - 1];
-    const long long q = (long long)blockIdx.x - F, sb = (E0 >> 8) + q;
+    const long long q = (long long)blockIdx.x - F, sb = E0 / SUB_ITEMS + q;
     if (sb * SUB_ITEMS >= E0 + P.nseeds) return;
     unsigned excl;
     const unsigned K = spawn_count(A, lane, excl);
@@ -890,8 +924,8 @@ struct ReplayLds {
     unsigned locK[RP_HASH], locV[RP_HASH], vposK[RP_HASH], vposV[RP_HASH];   // LDS tables (open addressing; locV = element + 1 | stamp << 26)
 };
 __device__ __forceinline__ unsigned rp_hash(unsigned key) { return (key * 2654435761u) >> 21; }   // 11 bits
-static_assert(SUB_ITEMS == 256, "k_fuse: four records per lane");
 static_assert(RP_HASH == 2048, "rp_hash yields 11 bits");
+static_assert(SUB_ITEMS == 256 || SUB_ITEMS == 128 || SUB_ITEMS == 64, "k_fuse: four or two records per lane; k_compact lists a sub-block with one thread per slot");
 
 // LDS = true: the window's explicit placements live in two LDS hash tables (few deletions: the steady state; no global round trips inside the
 // keyframe loop).  LDS = false: dense global tables indexed by position / element (any number of deletions; agent-scope accesses).
@@ -1316,7 +1350,7 @@ namespace sf {
 void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred) {
     const FuseArgs A = fuse_args(P, slot, deferred);
     const FuseFrame FF = fuse_frame(F, P.frames + slot);
-    if (deferred) MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<true>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
+    if (deferred) MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<true>, dim3((unsigned)nSubGrid + 1u), dim3(64), A, FF, nSubHint);
     else MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<false>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
 }
 void map_launch_compact(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, bool resident) {

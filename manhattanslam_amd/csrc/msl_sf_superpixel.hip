@@ -967,12 +967,10 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         seedWeight = get_weight(S.meanDepth);
     }
     {
-        // three planes of 16-byte words (round 5; one 48-byte record per seed before): neighbouring lanes of k_fuse fuse neighbouring
-        // superpixels, so each of its three loads covers consecutive words instead of every third one
-        float4 *fr = P.fuseRec + (size_t)slot * P.nseeds * 3 + seedI;
-        fr[0] = make_float4(S.normX, S.normY, S.normZ, S.meanDepth);
-        fr[P.nseeds] = make_float4(pw[0], pw[1], pw[2], seedWeight);
-        fr[2 * (size_t)P.nseeds] = make_float4(seedSize, S.meanIntensity, __uint_as_float(rgb_pack(S.r, S.g, S.b)), __uint_as_float(valid ? 1u : 0u));
+        float4 *fr = P.fuseRec + (size_t)slot * P.nseeds * 3;
+        fr[fuserec_index(P.nseeds, seedI, 0)] = make_float4(S.normX, S.normY, S.normZ, S.meanDepth);
+        fr[fuserec_index(P.nseeds, seedI, 1)] = make_float4(pw[0], pw[1], pw[2], seedWeight);
+        fr[fuserec_index(P.nseeds, seedI, 2)] = make_float4(seedSize, S.meanIntensity, __uint_as_float(rgb_pack(S.r, S.g, S.b)), __uint_as_float(valid ? 1u : 0u));
     }
     if (ok) {
         float nw[3];

@@ -130,7 +130,6 @@ int write_ctl(msl_sf *h) {
     const SfDev &D = h->dev;
     dc.flagStride = D.flagStride; dc.candOk = h->d_candOk; dc.fused = h->d_fused; dc.cand = h->d_cand;
     dc.aux.map = D.map; dc.aux.cap = D.cap; dc.aux.delU = D.delU; dc.aux.delUCount = D.delUCount; dc.aux.delList = D.delList;
-    dc.aux.blockSums = D.blockSums; dc.aux.blockUpd = D.blockUpd; dc.aux.blkStride = h->blkStride;
     MSL_HIP_TRY(hipMemcpy(h->d_dc, &dc, sizeof(dc), hipMemcpyHostToDevice));
     return MSL_OK;
 }
@@ -382,10 +381,15 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // keyframes, the host-vector drop-in, the first keyframe after the map was replaced from outside, and batches enqueued while the recent
     // churn (spawned + deleted surfels per keyframe, from the asynchronous counter snapshots) is high -- k_compact takes any number of stale or
     // deleted slots with all its workgroups, the replay's single wave is built for the steady state.  Both leave identical maps.
-    static const char *deferEnv = getenv("MSL_SF_DEFER");   // "0": never; "1": always (tests); unset: unless the recent churn is high
+    static const char *deferEnv = getenv("MSL_SF_DEFER");   // "0": never; "1": always (the parity tests); unset: the policy below
     static const bool deferOff = deferEnv && !strcmp(deferEnv, "0"), deferForce = deferEnv && !strcmp(deferEnv, "1");
     constexpr double CHURN_MAX = 96.0;   // spawned + deleted surfels per keyframe up to which the one-wave replay beats k_compact (bench.py --map moving: 670)
-    const bool churny = !deferForce && h->churn > CHURN_MAX;
+    // Policy.  The deferred chain is 8 us per keyframe shorter (22.6 against 31 us alone), which pays exactly when the map chain is the critical
+    // path: a handle on ONE caller-provided stream (superpixel stage and map stage back to back: 20.8 k against 19.0 k keyframes/s).  With the
+    // handle's own two streams the frame-batched superpixel stage is the longer one; k_fuse launches that follow each other without the idle
+    // stretch of k_compact in between only take issue slots from it (front end 22 010 against 22 330 frames/s, k_fuse 18.8 against 16.3 us in the
+    // timed region), so that shape keeps the classic pair.
+    const bool churny = !deferForce && (h->churn > CHURN_MAX || sp != sm);
     auto classic = [&](int f) {
         P.kf = 0;
         map_launch_fuse(h->prof, sm, P, f, h->h_frames[slot0 + f], nSubGrid, nSubHint, false);

@@ -124,6 +124,25 @@ def test_inverse4_matches_numpy():
         assert np.abs(inv.reshape(4, 4).T - ref).max() < 1e-6
 
 
+def _same_records(a, b):
+    """Bit-identical structured arrays, except that a NaN equals a NaN whatever its sign / payload: which of the two operands' NaNs an x86 instruction
+    hands on (and the sign of a freshly made one) follows the compiler's operand order, which changes with unrelated edits of the oracle; the
+    reference's own NaNs are no more defined than that."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.dtype != b.dtype or a.shape != b.shape:
+        return False
+    for name in a.dtype.names:
+        x, y = a[name], b[name]
+        if x.dtype.kind == "f":
+            same = (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
+        else:
+            same = x == y
+        if not np.all(same):
+            return False
+    return True
+
+
+
 def test_golden_surfel():
     g = np.load(os.path.join(GOLD, "surfel_640x480_B.npz"))
     k = int(g["frame"])
@@ -132,9 +151,9 @@ def test_golden_surfel():
     local = synth.surfel_map(int(g["n_local"]), ref=k).astype(SURFEL_DTYPE)
     sf = _mk()
     lo, no = sf.fuse(k, gray, depth, member, pose, local)
-    assert no.tobytes() == g["new_surfels"].tobytes()
-    assert lo[g["changed_index"]].tobytes() == g["changed_surfels"].tobytes()
-    assert sf.seeds().tobytes() == g["seeds"].tobytes()
+    assert _same_records(no, g["new_surfels"])
+    assert _same_records(lo[g["changed_index"]], g["changed_surfels"])
+    assert _same_records(sf.seeds(), g["seeds"])
     assert hashlib.sha256(sf.index().tobytes()).hexdigest() == str(g["index_sha256"])
 
 
@@ -207,9 +226,9 @@ def test_golden_clutter():
     assert hashlib.sha256(local.tobytes()).hexdigest() == str(g["map_sha256"])
     sf = _mk()
     lo, no = sf.fuse(k, gray, depth, member, pose, local)
-    assert no.tobytes() == g["new_surfels"].tobytes()
-    assert lo[g["changed_index"]].tobytes() == g["changed_surfels"].tobytes()
-    assert sf.seeds().tobytes() == g["seeds"].tobytes()
+    assert _same_records(no, g["new_surfels"])
+    assert _same_records(lo[g["changed_index"]], g["changed_surfels"])
+    assert _same_records(sf.seeds(), g["seeds"])
     assert hashlib.sha256(sf.index().tobytes()).hexdigest() == str(g["index_sha256"])
     I = synth.TUM1
     mem, npl, _ = oracle_lib.peac_run(synth.depth_u16(depth), I["fx"], I["fy"], I["cx"], I["cy"], np.float32(1.0 / 5000.0))
