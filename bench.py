@@ -505,6 +505,8 @@ def main():
                    "keyframes_per_pass": nkf * nsub, "keyframe_every": kfe, "distinct_frames": D,
                    "stationary": bool(reseed) or not do_sf,
                    "map_reseed": "msl_sf_map_restore (device-to-device, inside the timed region) at the start of every pass" if reseed else "none",
+                   "map_stage": ("deferred compaction (MSL_SF_DEFER=1: one k_fuse launch per keyframe, windows of 32 replayed)" if os.environ.get("MSL_SF_DEFER") == "1"
+                                 else "classic chain (k_fuse + k_compact per keyframe: the library's choice for a handle with its own two streams)") if do_sf else None,
                    "seeded_surfels": args.surfels if do_sf else 0, "n_live_surfels": int(n_live_avg),
                    "map": (f"{map_kind} ({'~35 % of the map inside the frustum of every keyframe, SURVEY.md 8(d) config 3' if map_kind == 'dense' else 'a 4 degree pan per keyframe over a dense map with unmapped stripes (synth.surfel_map_moving): 25-34 % in view, every keyframe spawns and deletes hundreds of surfels' if map_kind == 'moving' else 'area-uniform over the room, ~6 % in view'}"
                            f"{', array order = ' + args.map_order if map_kind == 'dense' else ''})") if do_sf else None,

@@ -9,8 +9,8 @@
 //                                                   the map was replaced from outside)
 //   deferred : k_fuse<true> x F -> k_defer_tail -> k_replay -> k_gather -> k_scatter      (round 5) ONE launch per keyframe.
 //              fuseSurfelsKernel treats every surfel independently of its array position, so inside a window of F <= 32 keyframes nothing
-//              is moved: a keyframe's new surfels are appended physically behind the array (by the first waves of the NEXT keyframe's fuse
-//              launch, which fuse them right away), deleted slots stay as holes and are logged.  The window's placements and tail moves
+//              is moved: a keyframe's new surfels are appended physically behind the array (by the "spawn wave" of the NEXT keyframe's fuse
+//              launch, which fuses them right away), deleted slots stay as holes and are logged.  The window's placements and tail moves
 //              (new surfel k -> k-th largest hole else appended; back-to-front refill, SurfelMapping.cpp:372-390) are then replayed
 //              SYMBOLICALLY by one wave over the logs -- virtual position <-> element, only for the few positions that differ from the
 //              identity -- and applied as one gather + scatter, which leaves the array exactly as F classic keyframes would have.
@@ -136,7 +136,8 @@ __device__ __forceinline__ void st16(void *p, u32x4 v) {
 
 // What k_fuse reads of the handle and of the keyframe: slim copies of SfDev / FrameDev with the slot offsets folded in on the host.  The
 // whole structs are ~150 dwords of kernel arguments = scalar registers the compiler loads up front and then spills around the hot loop;
-// what only the few frontier waves of a deferred launch need (the previous keyframe's candidate arrays) stays in memory (DeferCtl::emit).
+// what only the spawn wave of a deferred launch needs (the previous keyframe's candidate arrays) and the side arrays of wide records stay in
+// memory (DeferCtl).
 struct FuseFrame {
     float inv[12];   // rows 0..2 of pose.inverse(), inv[3 c + r] = invPose[4 c + r] (the fourth row is never used)
     int ref;
@@ -186,11 +187,11 @@ __device__ __forceinline__ void mul3r(const float *m, float v0, float v1, float 
 
 // ---- new surfels of the previous keyframe, materialised by the fuse launch that follows it (deferred compaction) ----------------------
 // initializeSurfels (:285-331): every seed whose candidate is valid and that no fusion consumed spawns a surfel, in seed order.  New surfel
-// k of the keyframe before (slot P.prevSlot) goes to the physical slot E0 + k (E0 = the extent that keyframe's fuse launch worked on).  A "frontier"
-// wave -- one whose sub-block reaches beyond E0 -- scans the `fused` bytes of the whole lattice (lane l owns the `per` consecutive seeds from
-// l * per on).  A seed spawns iff its byte is 0: kb_seed_init clears it, kb_seed_plane sets 2 where the candidate is invalid (candOk = 0), a
-// fusion sets 1; the padding behind the lattice holds 1.  The wave writes the records that fall into ITS sub-block and then fuses them like any
-// others.  All 64 lanes must call these.
+// k of the keyframe before (slot P.prevSlot) goes to the physical slot E0 + k (E0 = the extent that keyframe's fuse launch worked on).  The
+// spawn wave of the next launch (workgroup 0; k_defer_tail for a window's last keyframe) scans the `fused` bytes of the whole lattice (lane l
+// owns the `per` consecutive seeds from l * per on).  A seed spawns iff its byte is 0: kb_seed_init clears it, kb_seed_plane sets 2 where the
+// candidate is invalid (candOk = 0), a fusion sets 1; the padding behind the lattice holds 1.  It publishes the new extent, writes the records
+// 128 at a time and fuses them like any others.  All 64 lanes must call these.
 __device__ __forceinline__ unsigned spawn_word(unsigned fw) { return ~(fw | (fw >> 1)) & 0x01010101u; }   // one bit per byte that is 0
 // Pass 1: this lane's number of spawning seeds; the wave-wide exclusive prefix and the total K come from one scan.
 __device__ __forceinline__ unsigned spawn_count(const FuseArgs &P, unsigned lane, unsigned &excl) {
@@ -260,27 +261,25 @@ __device__ __forceinline__ void emit_records(const FuseArgs &P, long long E0, lo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the wave reads these records back right away
 }
 
-// k_fuse (:167-283): ONE WAVE per sub-block of 256 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever a
-// SIMD has a free slot and registers -- next to the LDS-heavy frame-batched kernels workgroups with LDS waited for it.
-//   Phase A (streaming): lane l owns the surfels l, 64 + l, 128 + l, 192 + l of the sub-block (four 16-byte hot records; a load instruction
-//     covers 64 consecutive records = 1 KB).  Stale / deleted / out of range / out of image surfels finish here; the in-view ones need ONE
-//     8-byte gather each ({depth, superpixel index} texel written by kb_seed_plane) for the occlusion test.  The four gathers of a lane leave
-//     together (branch-free, clamped addresses).
+// k_fuse (:167-283): ONE WAVE per sub-block of SUB_ITEMS = 128 consecutive surfels, no LDS and no workgroup barrier, so a wave starts wherever
+// a SIMD has a free slot and 64 registers -- next to the LDS-heavy frame-batched kernels workgroups with LDS waited for it.
+//   Phase A (streaming): lane l owns the surfels l and 64 + l of the sub-block (16-byte hot records; a load instruction covers 64
+//     consecutive records = 1 KB).  Stale / deleted / out of range / out of image surfels finish here; the in-view ones need ONE 8-byte
+//     gather each ({depth, superpixel index} texel written by kb_seed_plane) for the occlusion test.  The gathers of a lane leave together
+//     (branch-free, clamped addresses).
 //   Hand-over inside the wave: survivor number s (rank by (k, lane) = array order) goes to lane s % 64, round s / 64, with one
 //     ds_permute_b32 per k -- a push through the LDS crossbar that allocates no LDS.  Non-survivors push an empty word to the remaining
 //     lanes, so every k is a permutation of the 64 lanes and no two lanes ever target the same destination.
 //   Phase B (gathers): per round one survivor per lane, neighbouring lanes = neighbouring surfels; its hot record (just streamed: cache
-//     hit), 32-byte cold record and the three 16-byte words of its seed are requested together, so <= 64 survivors per sub-block cost one
-//     round trip.
+//     hit), 32-byte cold record, the 48-byte record of its seed and the pose's rotation are requested together, so <= 64 survivors cost
+//     one round trip and a sub-block wholly in view two.
 // DEFER = false (classic): deleted slots are handed to k_compact in delU (one atomic per wave that deleted something), per-sub-block deleted /
 //   updated counts go to blockSums / blockUpd with plain stores.
-// DEFER = true: deleted slots become HOT_HOLE and go to the window's deletion log; the launch of keyframe kf > 0 first materialises the new
-//   surfels of keyframe kf - 1 behind the array (emit_pending, frontier waves only) and works on the extent that results.
+// DEFER = true: deleted slots become HOT_HOLE and go to the window's deletion log; the regular waves of keyframe kf > 0 work on the slots below
+//   E0 (the extent keyframe kf - 1 worked on), the launch's spawn wave (spawnWave = true, its own instantiation) on the new surfels of kf - 1.
 template <bool DEFER, bool spawnWave>
 __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F, int nSubHint, unsigned waveIdx, int G) {
-    constexpr int KPL = SUB_ITEMS / 64;        // records per lane; a wave owns WSPAN = SUB_ITEMS consecutive surfels (2 per lane, twice the waves: k_fuse itself
-                                               // 1.4 us shorter alone and 2.8 us in the timed region, the front end 4 % slower -- the per-wave overhead is VALU time
-                                               // the frame-batched kernels lose)
+    constexpr int KPL = SUB_ITEMS / 64;        // records per lane; a wave owns WSPAN = SUB_ITEMS consecutive surfels (measurements: msl_sf.h)
     constexpr long long WSPAN = 64 * KPL;
     struct { HotPk *hot; ColdRec *cold; } M = {P.hot, P.cold};
     const FuseAux *aux = &P.dc->aux;

@@ -375,8 +375,10 @@ __device__ __forceinline__ int row_incl_scan(int v) {
 template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can stick out over the right edge); the common instantiation stays at 80 VGPRs,
                            // so that three k_fuse waves (64 VGPRs) fit next to its four waves per SIMD -- with 88 only two did (+0.5 us per k_fuse launch)
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
-    __shared__ __attribute__((aligned(16))) float s_depth[16][256];
-    __shared__ __attribute__((aligned(16))) float s_term[16][256];   // in-range: 2*residual; Huber tails: +-inf markers
+    // rows of 256 + 16 words: the two seeds of a 32-lane half read / write entry l + 16 t of their own row together (ds_*_b32: bank = word address mod
+    // 32); with a row stride of 256 words both rows started on the same bank (round 4: 32 % of the kernel's LDS cycles were bank conflicts)
+    __shared__ __attribute__((aligned(16))) float s_depth[16][272];
+    __shared__ __attribute__((aligned(16))) float s_term[16][272];   // in-range: 2*residual; Huber tails: +-inf markers
     __shared__ float s_mean[16];
     __shared__ int s_cnt[16], s_done[16];
     int slot, blk;
@@ -620,7 +622,7 @@ __device__ __forceinline__ double group_sum_d(double v) {
 // LDS: one pool per wave.  The four seeds of a wave form a 2x2 block of the seed lattice, so their 16x16 windows cover
 // 24x24 = 576 distinct pixels; every pixel belongs to one seed, hence the four ordered lists hold <= 576 entries in total
 // (+ 3 x 3 for 16-byte alignment of each list) instead of 4 x 256.  14 KB per wave: 11 waves per CU instead of 5.
-constexpr int PLANE_POOL = 24 * 24 + 12;
+constexpr int PLANE_POOL = 24 * 24 + 12 + 2 * 28;   // + the bank-phase gaps in front of the second list of each half
 template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} -- a window quad can stick out over the right edge (instantiated separately: the common
                            // geometry carries none of that code)
 __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
@@ -722,13 +724,18 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         SECTION_STAMP();   // 1a: window loads arrived, ownership tests
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
-        {   // list bases inside the pool, each rounded up to 4 entries
+        {   // list bases inside the pool: multiples of 4 entries (16-byte reads of the sequential sums), and the second list of each 32-lane half
+            // 16 banks away from the first one (mod 32) -- the loops below read entry base + l + 16 t with ds_read_b32, whose lane groups are the two
+            // halves of the wave and whose bank is the word address mod 32: with arbitrary bases the two seeds of a half collided on every access
+            // (round 4: 27 % of the kernel's LDS cycles were bank conflicts)
             const int pad = (nvalid + 3) & ~3;
             const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64), n3 = __shfl(pad, 48, 64);
-            base = g == 0 ? 0 : g == 1 ? n0 : g == 2 ? n0 + n1 : n0 + n1 + n2;
-            poolUsed = n0 + n1 + n2 + n3;
-            // the <= 3 padding entries behind a list take part in the wave-wide pass below: give them a valid pixel (row 0, column 0)
-            if (l < pad - nvalid) { s_pool[2][base + nvalid + l] = 0.0f; s_pool[3][base + nvalid + l] = 0.0f; s_pool[4][base + nvalid + l] = 0.0f; s_pool[5][base + nvalid + l] = 0.0f; }
+            const int b1 = n0 + ((16 - n0) & 31), b2 = b1 + n1, b3 = b2 + n2 + ((16 - n2) & 31);   // b1 = 16 (mod 32) relative to b0 = 0; b3 likewise to b2
+            base = g == 0 ? 0 : g == 1 ? b1 : g == 2 ? b2 : b3;
+            poolUsed = b3 + n3;
+            // the padding entries behind a list (<= 3 + 28) take part in the wave-wide pass below: give them a valid pixel (row 0, column 0)
+            const int padEnd = g == 0 ? b1 : g == 1 ? b2 : g == 2 ? b3 : b3 + n3;
+            for (int q = base + nvalid + l; q < padEnd; q += 16) { s_pool[2][q] = 0.0f; s_pool[3][q] = 0.0f; s_pool[4][q] = 0.0f; s_pool[5][q] = 0.0f; }
         }
         const int g15 = (lane & 48) | 15;
         int run = base;
