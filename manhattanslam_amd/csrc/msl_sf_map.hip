@@ -67,24 +67,41 @@ __device__ __forceinline__ bool hot_is_deleted(const MapSoA &M, long long i) {
     return tl == HOT_WIDE ? M.utlWide[2 * i] == 0 : (tl == HOT_HOLE || (tl >> 20) == 0);
 }
 
+// Cold records travel as two 16-byte words: a plain struct copy of the 32-byte-aligned ColdRec goes through a private
+// temporary that the compiler parks in LDS (12 KB per workgroup in k_compact before this).
+struct ColdBits { uint4 a, b; };
+__device__ __forceinline__ ColdRec cold_load(const ColdRec *p) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(p);
+    ColdBits v; v.a = q[0]; v.b = q[1];
+    ColdRec c;
+    c.nx = __uint_as_float(v.a.x); c.ny = __uint_as_float(v.a.y); c.nz = __uint_as_float(v.a.z); c.size = __uint_as_float(v.a.w);
+    c.color = __uint_as_float(v.b.x); c.weight = __uint_as_float(v.b.y); c.rgbf = v.b.z; c._spare = v.b.w;
+    return c;
+}
+__device__ __forceinline__ void cold_store(ColdRec *p, const ColdRec &c) {
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    q[0] = make_uint4(__float_as_uint(c.nx), __float_as_uint(c.ny), __float_as_uint(c.nz), __float_as_uint(c.size));
+    q[1] = make_uint4(__float_as_uint(c.color), __float_as_uint(c.weight), c.rgbf, c._spare);
+}
+
 __device__ __forceinline__ void store_surfel(const MapSoA &M, long long i, const msl_surfel &e) {
     HotRec h; h.px = e.px; h.py = e.py; h.pz = e.pz; h.updateTimes = e.updateTimes; h.lastUpdate = e.lastUpdate;
     ColdRec c; c.nx = e.nx; c.ny = e.ny; c.nz = e.nz; c.size = e.size; c.color = e.color; c.weight = e.weight; c._spare = 0;
     if (rgb_fits(e.r, e.g, e.b)) c.rgbf = rgb_pack(e.r, e.g, e.b);
     else { c.rgbf = COLD_WIDE; set_wide_flag(M, 1ull); M.rgbWide[3 * i] = e.r; M.rgbWide[3 * i + 1] = e.g; M.rgbWide[3 * i + 2] = e.b; }
-    hot_store(M, i, h); M.cold[i] = c;
+    hot_store(M, i, h); cold_store(M.cold + i, c);
 }
 __device__ __forceinline__ void load_surfel(const MapSoA &M, long long i, const HotRec &h, msl_surfel &e) {
-    const ColdRec c = M.cold[i];
+    const ColdRec c = cold_load(M.cold + i);
     e.px = h.px; e.py = h.py; e.pz = h.pz; e.nx = c.nx; e.ny = c.ny; e.nz = c.nz; e.size = c.size; e.color = c.color;
     if (c.rgbf & COLD_WIDE) { e.r = M.rgbWide[3 * i]; e.g = M.rgbWide[3 * i + 1]; e.b = M.rgbWide[3 * i + 2]; }
     else { e.r = (int)(c.rgbf & 255u); e.g = (int)((c.rgbf >> 8) & 255u); e.b = (int)((c.rgbf >> 16) & 255u); }
     e.weight = c.weight; e.updateTimes = h.updateTimes; e.lastUpdate = h.lastUpdate;
 }
 __device__ __forceinline__ void move_surfel(const MapSoA &M, long long dst, long long src) {
-    const ColdRec c = M.cold[src];
+    const ColdRec c = cold_load(M.cold + src);
     const HotPk p = M.hot[src];
-    M.hot[dst] = p; M.cold[dst] = c;
+    M.hot[dst] = p; cold_store(M.cold + dst, c);
     if (p.tl == HOT_WIDE) { M.utlWide[2 * dst] = M.utlWide[2 * src]; M.utlWide[2 * dst + 1] = M.utlWide[2 * src + 1]; }
     if (c.rgbf & COLD_WIDE) { M.rgbWide[3 * dst] = M.rgbWide[3 * src]; M.rgbWide[3 * dst + 1] = M.rgbWide[3 * src + 1]; M.rgbWide[3 * dst + 2] = M.rgbWide[3 * src + 2]; }
 }
@@ -164,7 +181,7 @@ __host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
     A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
     A.hot = P.map.hot; A.cold = P.map.cold; A.ctr = P.ctr;
     A.dc = P.dc;
-    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd + (size_t)(deferred ? P.kf : 0) * (P.cap / SUB_ITEMS + 4100);   // (= blkStride of map_realloc)
+    A.blockSums = P.blockSums; A.blockUpd = P.blockUpd + (size_t)(deferred ? P.kf : 0) * (P.cap / SUB_ITEMS + 8200);   // (= blkStride of map_realloc)
     A.delOut = deferred ? P.delList : P.delU;
     A.delCount = deferred ? &P.dc->delCnt[P.kf < DEFER_WIN ? P.kf : 0] : P.delUCount;
     return A;
@@ -620,9 +637,10 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
     const uint4 bs0 = *reinterpret_cast<const uint4 *>(P.blockSums + 4 * threadIdx.x);   // first tile of chunk partials
-    uint4 bu[4];   // the first 4096 per-workgroup updated counts (arrays are padded by >= 4096 zeroed entries)
+    constexpr int NBU = 8;
+    uint4 bu[NBU];   // the first 8192 per-sub-block updated counts = a map of 1 M surfels in one trip (arrays are padded by >= 8192 zeroed entries)
 #pragma unroll
-    for (int q = 0; q < 4; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
+    for (int q = 0; q < NBU; q++) bu[q] = *reinterpret_cast<const uint4 *>(P.blockUpd + TILE * q + 4 * threadIdx.x);
     static_assert(LIST_D == NT, "one hand-over entry per thread");
     const unsigned du = P.delU[threadIdx.x];
     const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
@@ -790,11 +808,11 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     {
         unsigned u = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < NBU; q++) {
             const long long c = TILE * q + 4 * threadIdx.x;
             u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
         }
-        for (long long c2 = 4 * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
+        for (long long c2 = (long long)NBU * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
         u = wave_incl_scan(u);                                   // one LDS atomic per wave instead of 256 on one address
         if ((threadIdx.x & 63) == 63 && u) atomicAdd(&s_upd, u);
     }
@@ -1205,8 +1223,8 @@ __global__ __launch_bounds__(256) void k_gather(SfDev P) {
     for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < nM; j += gridDim.x * 256) {
         const unsigned s = P.srcOf[j];
         const HotPk h = M.hot[s];
-        const ColdRec c = M.cold[s];
-        P.stageHot[j] = h; P.stageCold[j] = c;
+        const ColdRec c = cold_load(M.cold + s);
+        P.stageHot[j] = h; cold_store(P.stageCold + j, c);
         if (h.tl == HOT_WIDE) { P.stageUtl[2 * (size_t)j] = M.utlWide[2 * (size_t)s]; P.stageUtl[2 * (size_t)j + 1] = M.utlWide[2 * (size_t)s + 1]; }
         if (c.rgbf & COLD_WIDE) for (int q = 0; q < 3; q++) P.stageRgb[3 * (size_t)j + q] = M.rgbWide[3 * (size_t)s + q];
     }
@@ -1217,8 +1235,8 @@ __global__ __launch_bounds__(256) void k_scatter(SfDev P) {
     for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < nM; j += gridDim.x * 256) {
         const unsigned d = P.moveDst[j];
         const HotPk h = P.stageHot[j];
-        const ColdRec c = P.stageCold[j];
-        M.hot[d] = h; M.cold[d] = c;
+        const ColdRec c = cold_load(P.stageCold + j);
+        M.hot[d] = h; cold_store(M.cold + d, c);
         if (h.tl == HOT_WIDE) { M.utlWide[2 * (size_t)d] = P.stageUtl[2 * (size_t)j]; M.utlWide[2 * (size_t)d + 1] = P.stageUtl[2 * (size_t)j + 1]; }
         if (c.rgbf & COLD_WIDE) for (int q = 0; q < 3; q++) M.rgbWide[3 * (size_t)d + q] = P.stageRgb[3 * (size_t)j + q];
     }

@@ -138,7 +138,7 @@ int write_ctl(msl_sf *h) {
 int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     cap = (cap + 4095) & ~(size_t)4095;
     float *nstore = nullptr; unsigned *nbs = nullptr, *nbu = nullptr, *ndl = nullptr, *nso = nullptr, *nrp = nullptr;
-    const size_t bst = cap / SUB_ITEMS + 4100;   // per slice; >= 1024 / 4096 padding entries: the compaction reads its first tiles unconditionally
+    const size_t bst = cap / SUB_ITEMS + 8200;   // per slice; >= 1024 / 8192 padding entries: the compaction reads its first tiles unconditionally
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * MAP_WORDS * cap));
         MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * bst));
