@@ -418,8 +418,14 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                 const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
                 const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
                 if (cand && inImage) st = 3;
+#ifdef MSL_FUSE_TEXCLAMP   // (round 4 / early round 5: every record gathers a texel, records outside the view the border texel nearest to their projection)
                 const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
                 off = (unsigned)(pVc * P.W + pUc);
+#else
+                // a record that is not in view needs no texel: all such lanes read texel 0 (ONE line for the whole wave) instead of up to 64 scattered
+                // border texels -- two thirds of the dense map's records, each a separate request to the vector cache
+                off = st == 3 ? (unsigned)(pVInt * P.W + pUInt) : 0u;
+#endif
             }
             stp |= (unsigned)st << (2 * k); pzv[k] = pc[2];
             offT[k] = off;
