@@ -431,12 +431,14 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             offT[k] = off;
         }
         uint2 tx[KPL];
+        {
 #pragma unroll
-        for (int k = 0; k < KPL; k++) tx[k] = tex[offT[k]];
-        // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
-        // round trip back into up to four dependent ones
-        if constexpr (KPL == 4) asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
-        else asm volatile("" ::"v"(tx[0].x), "v"(tx[KPL - 1].x), "v"(tx[0].y), "v"(tx[KPL - 1].y));
+            for (int k = 0; k < KPL; k++) tx[k] = tex[offT[k]];
+            // a common use of all four results: keeps the compiler from sinking each load into its (conditional) consumer, which would turn one
+            // round trip back into up to four dependent ones
+            if constexpr (KPL == 4) asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
+            else asm volatile("" ::"v"(tx[0].x), "v"(tx[KPL - 1].x), "v"(tx[0].y), "v"(tx[KPL - 1].y));
+        }
         // ---- classification: deletions of phase A, survivors ----
         // (one bit field per lane instead of eight lane masks: the masks would live in scalar registers, which this kernel is short of)
         unsigned fl = 0;   // bit k: record k deleted in phase A; bit 4 + k: record k survives into phase B
@@ -507,7 +509,12 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const long long i = c0 + (item & 0xFFu);
             const unsigned sp = item >> 16;
             const HotPk h = M.hot[i];
-            ColdRec c = M.cold[i];
+            // the update reads normal, size and weight of the cold record and overwrites the rest: two loads (a whole-struct copy became three)
+            ColdRec c;
+            {
+                const float4 cn = *reinterpret_cast<const float4 *>(M.cold + i);
+                c.nx = cn.x; c.ny = cn.y; c.nz = cn.z; c.size = cn.w; c.weight = M.cold[i].weight;
+            }
             const float4 f0 = fuseRec[fuserec_index(P.nseeds, sp, 0)], f1 = fuseRec[fuserec_index(P.nseeds, sp, 1)], f2 = fuseRec[fuserec_index(P.nseeds, sp, 2)];
             // the rotation of the pose (only the update path needs it, to turn the fused normal back into the world): three 12-byte loads from the
             // keyframe's device record, requested HERE with the records -- left to the compiler they sat behind the tests, one more dependent round
@@ -515,7 +522,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             const float *poseM = F.frame->pose;
             const float r00 = poseM[0], r10 = poseM[1], r20 = poseM[2], r01 = poseM[4], r11 = poseM[5], r21 = poseM[6], r02 = poseM[8], r12 = poseM[9], r22 = poseM[10];
             // common use of one field per load instruction: all records are in flight together
-            asm volatile("" ::"v"(h.px), "v"(h.tl), "v"(c.nx), "v"(c.color), "v"(f0.x), "v"(f1.x), "v"(f2.x), "v"(r00), "v"(r01), "v"(r02));
+            asm volatile("" ::"v"(h.px), "v"(h.tl), "v"(c.nx), "v"(c.weight), "v"(f0.x), "v"(f1.x), "v"(f2.x), "v"(r00), "v"(r01), "v"(r02));
             bool upd = false, delB = false;
             if (item && __float_as_uint(f2.w) != 0u) {   // seed tests of :214-219 (norm != 0, viewCos >= MAX_ANGLE_COS)
                 const float seedDepth = f0.w;
@@ -571,7 +578,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                         if (newSize < c.size) c.size = newSize;
                         u32x4 hv = {__float_as_uint(fusedPx), __float_as_uint(fusedPy), __float_as_uint(fusedPz), tlNew};
                         u32x4 c0v = {__float_as_uint(c.nx), __float_as_uint(c.ny), __float_as_uint(c.nz), __float_as_uint(c.size)};
-                        u32x4 c1v = {__float_as_uint(c.color), __float_as_uint(c.weight), c.rgbf, c._spare};
+                        u32x4 c1v = {__float_as_uint(c.color), __float_as_uint(c.weight), c.rgbf, 0u};   // (_spare is 0 in every record: store_surfel)
                         st16(M.hot + i, hv);
                         st16(M.cold + i, c0v);
                         st16(reinterpret_cast<u32x4 *>(M.cold + i) + 1, c1v);
