@@ -60,6 +60,27 @@ __device__ __forceinline__ float seq_sum_huber(const float *t, int n, float s) {
     return s;
 }
 
+// The same strictly sequential sums without the LDS round trips: a ROTATING chain over the 16 lanes of a DPP row.  Lane i of the row holds the
+// elements i, 16 + i, 32 + i, ... of the list (one per block of 16); step k of the chain lets every lane compute (value of its left neighbour) +
+// (its element of block k / 16), row_ror:1 making lane 0 the neighbour of lane 15.  Lane k mod 16 then holds exactly s_k = s_(k-1) + e_k -- its
+// neighbour held s_(k-1) after the step before -- while the lanes behind the front hold garbage nobody reads.  Elements beyond the end of a list
+// are +0.0f: s + (+0.0f) == s for every s the chain can hold (it starts at +0.0f, and a float sum is -0.0f only if both operands are), so after
+// any number of whole blocks lane 15 holds the sum of the list in list order, bit for bit what seq_sum_f32 / seq_sum_huber return.  One
+// v_add_f32 with a DPP operand per element, for the four seeds of a wave at once.
+__device__ __forceinline__ float row_ror1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));   // row_ror:1
+}
+__device__ __forceinline__ float chain_block_f32(float s, float t) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) s = row_ror1(s) + t;
+    return s;
+}
+__device__ __forceinline__ float chain_block_huber(float s, float t) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) s = huber_term_add(row_ror1(s), t);
+    return s;
+}
+
 // =============================================================================================
 // Frame-batched superpixel stage
 // =============================================================================================
@@ -377,10 +398,7 @@ template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can 
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     // rows of 256 + 16 words: the two seeds of a 32-lane half read / write entry l + 16 t of their own row together (ds_*_b32: bank = word address mod
     // 32); with a row stride of 256 words both rows started on the same bank (round 4: 32 % of the kernel's LDS cycles were bank conflicts)
-    __shared__ __attribute__((aligned(16))) float s_depth[16][272];
-    __shared__ __attribute__((aligned(16))) float s_term[16][272];   // in-range: 2*residual; Huber tails: +-inf markers
-    __shared__ float s_mean[16];
-    __shared__ int s_cnt[16], s_done[16];
+    __shared__ __attribute__((aligned(16))) float s_depth[16][272];   // the ordered depth lists (the only LDS of the kernel since round 5: 17 KB)
     int slot, blk;
     if (!xcd_slot((P.nseeds + 15) / 16, nSlots, slot, blk)) return;
 #ifdef MSL_FUSE_STAMPS   // section cycle counts of the waves of slot 0, summed into delList[96 ..] (tools/fuse_stamps.py)
@@ -471,57 +489,78 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     }
     __builtin_amdgcn_wave_barrier();
     msl_seed T = S;
-    bool depthLoop = false, aborted = false;
-    if (l == 0) {
-        if (active) {
-            if (cnt == 0) {  // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable
-                atomicMin(&P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)], seedI);
-                aborted = true;
-            } else {
-                const float sumIntensityNum = (float)cnt;
-                const float sumIntensity = (float)sumI / sumIntensityNum, mX = (float)sumX / sumIntensityNum, mY = (float)sumY / sumIntensityNum;
-                const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
-                T.meanIntensity = sumIntensity; T.x = mX; T.y = mY;
-                vec3b(P, F, mY, mX, T.r, T.g, T.b);
-                const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
-                T.stable = (updateDiff < 0.2) ? 1 : 0;
-                if (nd > 0) {
-                    const float sumDepth = seq_sum_f32(s_depth[g], nd, 0.0f);
-                    s_mean[g] = sumDepth / (float)nd;
-                    depthLoop = true;
-                } else {
-                    T.meanDepth = 0.0f;
-                }
+    bool aborted = false;
+    const bool depthLoop = active && cnt != 0 && nd > 0;   // (uniform over the seed's 16 lanes)
+    if (l == 0 && active) {
+        if (cnt == 0) {  // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable
+            atomicMin(&P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)], seedI);
+            aborted = true;
+        } else {
+            const float sumIntensityNum = (float)cnt;
+            const float sumIntensity = (float)sumI / sumIntensityNum, mX = (float)sumX / sumIntensityNum, mY = (float)sumY / sumIntensityNum;
+            const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
+            T.meanIntensity = sumIntensity; T.x = mX; T.y = mY;
+            vec3b(P, F, mY, mX, T.r, T.g, T.b);
+            const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
+            T.stable = (updateDiff < 0.2) ? 1 : 0;
+            if (nd <= 0) T.meanDepth = 0.0f;
+        }
+    }
+    // ---- mean depth and its Huber refinement (:486-512): the sequential sums as rotating chains (above); everything per seed is uniform over its
+    // 16 lanes and lives in registers -- no LDS, no atomics, no barriers in the Newton loop ----
+    const int ndL = depthLoop ? nd : 0;                 // a seed without a depth loop contributes empty lists
+    int nblk = (ndL + 15) >> 4;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) nblk = max(nblk, __shfl_xor(nblk, d, 64));
+    nblk = __builtin_amdgcn_readfirstlane(nblk);       // blocks of the longest list of the wave's four seeds
+    const int g15r = (threadIdx.x & 48) | 15;
+    float meanDepth = 0.0f;
+    {
+        float sd = 0.0f;
+        for (int bq = 0; bq < nblk; bq++) {
+            const int e = l + 16 * bq;
+            sd = chain_block_f32(sd, e < ndL ? s_depth[g][e] : 0.0f);
+        }
+        const float sumDepth = __shfl(sd, g15r, 64);
+        if (depthLoop) meanDepth = sumDepth / (float)nd;
+    }
+    USTAMP();   // 2: means, colour fetch, sequential depth sum
+    bool open = depthLoop;
+    for (int newtonI = 0; newtonI < 5; newtonI++) {
+        if (!__ballot(open)) break;
+        // pass 1: in-range count (sumB) and whether any list of the wave has a Huber tail this step
+        int inr = 0;
+        bool tail = false;
+        for (int bq = 0; bq < nblk; bq++) {
+            const int e = l + 16 * bq;
+            if (open && e < ndL) {
+                const float residual = meanDepth - s_depth[g][e];
+                if (residual < HUBER_RANGE && residual > -HUBER_RANGE) inr++; else tail = true;
             }
         }
-        s_done[g] = depthLoop ? 0 : 1;
-    }
-    __builtin_amdgcn_wave_barrier();
-    USTAMP();   // 2: means, colour fetch, sequential depth sum
-    // Huber mean depth: <= 5 Newton steps (:492-512); terms in parallel, accumulation in list order
-    for (int newtonI = 0; newtonI < 5; newtonI++) {
-        if (s_done[g]) break;
-        if (l == 0) s_cnt[g] = 0;
-        __builtin_amdgcn_wave_barrier();
-        const float meanDepth = s_mean[g];
-        int inr = 0;
-        for (int e = l; e < nd; e += 16) {
-            const float residual = meanDepth - s_depth[g][e];
-            if (residual < HUBER_RANGE && residual > -HUBER_RANGE) { s_term[g][e] = 2 * residual; inr++; }
-            else s_term[g][e] = residual > 0 ? __builtin_inff() : -__builtin_inff();
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) inr += __shfl_xor(inr, d, 16);
+        const bool anyTail = __ballot(tail) != 0ull;
+        // pass 2: the chain over the terms -- in range: 2*residual; a tail element: the +-inf marker huber_term_add() turns into +-HUBER_RANGE
+        float sa = 0.0f;
+        for (int bq = 0; bq < nblk; bq++) {
+            const int e = l + 16 * bq;
+            float t = 0.0f;
+            if (open && e < ndL) {
+                const float residual = meanDepth - s_depth[g][e];
+                if (residual < HUBER_RANGE && residual > -HUBER_RANGE) t = 2 * residual;
+                else t = residual > 0 ? __builtin_inff() : -__builtin_inff();
+            }
+            // no Huber tails anywhere in the wave (the common case): a plain float chain, 1 VALU op per element instead of ~8
+            sa = anyTail ? chain_block_huber(sa, t) : chain_block_f32(sa, t);
         }
-        if (inr) atomicAdd(&s_cnt[g], inr);
-        __builtin_amdgcn_wave_barrier();
-        if (l == 0) {
-            // no Huber tails (the common case): a plain float chain, 1 VALU op per element instead of ~8
-            const float sumA = s_cnt[g] == nd ? seq_sum_f32(s_term[g], nd, 0.0f) : seq_sum_huber(s_term[g], nd, 0.0f);
-            const float sumB = (float)(2 * s_cnt[g]);
-            const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
-            const float m = meanDepth + deltaDepth;
-            s_mean[g] = m;
-            if ((deltaDepth < 0.01 && deltaDepth > -0.01) || newtonI == 4) { s_done[g] = 1; }
+        const float sumA = __shfl(sa, g15r, 64);
+        const float sumB = (float)(2 * inr);
+        const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
+        if (open) {
+            meanDepth = meanDepth + deltaDepth;
+            if ((deltaDepth < 0.01 && deltaDepth > -0.01) || newtonI == 4) open = false;
         }
-        __builtin_amdgcn_wave_barrier();
     }
     USTAMP();   // 3: Newton steps
     if (active && l == 0) {
@@ -529,7 +568,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         if (aborted) {
             P.seeds[si].stable = 0; P.arec[si].stable = 0u; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
         } else {
-            if (depthLoop) T.meanDepth = s_mean[g];
+            if (depthLoop) T.meanDepth = meanDepth;
             msl_seed old = S;
             old._pad = 2;
             P.seedsTmp[si] = old;
@@ -1048,8 +1087,10 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
             prof.end(sp);
             MSL_SF_LAUNCH(prof, SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
         }
-        if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<true>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
-        else MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
+        static const char *updPadEnv = getenv("MSL_UPD_PAD");   // (experiment knob: unused dynamic LDS caps the kernel's workgroups per CU)
+        static const int updPad = updPadEnv ? atoi(updPadEnv) : 0;
+        if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH_LDS(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<true>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), updPad, P, it, n);
+        else MSL_SF_LAUNCH_LDS(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), updPad, P, it, n);
         MSL_SF_LAUNCH(prof, SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
     // 4 KB of (unused) dynamic LDS cap the kernel at 8 waves per CU (it could run 11).  Measured on the whole front end (round 3, same box,
