@@ -562,11 +562,17 @@ def main():
             orb.sync()
             out["orb_only_fps"] = round(4 * F / (time.perf_counter() - t0), 1)
         if do_sf:
-            t0 = time.perf_counter()
-            for _ in range(2):
+            # median of five single passes (each enqueued, then drained): right after the ORB-only passes above ONE pass of this loop now and then
+            # takes 50-60 ms instead of 9.5 (the device, not the enqueue: a queue-scheduling hiccup at the change of the set of busy streams;
+            # the timed region above shows nothing of the kind), which a two-pass mean turned into 7-27 k keyframes/s from run to run
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
                 pass_sf()
-            sf.sync()
-            out["surfel_only_keyframes_per_sec"] = round(2 * nkf * nsub / (time.perf_counter() - t0), 1)
+                sf.sync()
+                ts.append(time.perf_counter() - t0)
+            out["surfel_only_keyframes_per_sec"] = round(nkf * nsub / sorted(ts)[2], 1)
+            out["surfel_only_pass_ms"] = [round(1e3 * t, 2) for t in ts]
             # the same kernel without co-running work: the whole surfel pipeline on ONE stream (no overlap with the batched
             # superpixel stage or ORB), k_fuse timed again.  Reported next to, never instead of, the in-region roofline.
             sf.set_stream(torch.cuda.current_stream().cuda_stream)

@@ -34,7 +34,7 @@ __device__ __forceinline__ double div100_exact(double x) {
 }
 
 // Strictly sequential (left-to-right) float sums over 16-byte aligned LDS arrays; wide LDS reads are issued
-// ahead of the dependent add chain so the chain runs at VALU latency instead of LDS latency.
+// ahead of the dependent add chain so the chain runs at VALU latency instead of LDS latency.  (kb_seed_plane; kb_update_seeds uses the chains below.)
 __device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
     int p = 0;
     for (; p + 8 <= n; p += 8) {
@@ -49,23 +49,13 @@ __device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
 __device__ __forceinline__ float huber_term_add(float s, float t) {
     return __builtin_isinf(t) ? (float)((double)s + (t > 0 ? HUBER_RANGE : -1 * HUBER_RANGE)) : s + t;
 }
-__device__ __forceinline__ float seq_sum_huber(const float *t, int n, float s) {
-    int e = 0;
-    for (; e + 8 <= n; e += 8) {
-        const float4 u = *reinterpret_cast<const float4 *>(t + e), v = *reinterpret_cast<const float4 *>(t + e + 4);
-        s = huber_term_add(s, u.x); s = huber_term_add(s, u.y); s = huber_term_add(s, u.z); s = huber_term_add(s, u.w);
-        s = huber_term_add(s, v.x); s = huber_term_add(s, v.y); s = huber_term_add(s, v.z); s = huber_term_add(s, v.w);
-    }
-    for (; e < n; e++) s = huber_term_add(s, t[e]);
-    return s;
-}
 
 // The same strictly sequential sums without the LDS round trips: a ROTATING chain over the 16 lanes of a DPP row.  Lane i of the row holds the
 // elements i, 16 + i, 32 + i, ... of the list (one per block of 16); step k of the chain lets every lane compute (value of its left neighbour) +
 // (its element of block k / 16), row_ror:1 making lane 0 the neighbour of lane 15.  Lane k mod 16 then holds exactly s_k = s_(k-1) + e_k -- its
 // neighbour held s_(k-1) after the step before -- while the lanes behind the front hold garbage nobody reads.  Elements beyond the end of a list
 // are +0.0f: s + (+0.0f) == s for every s the chain can hold (it starts at +0.0f, and a float sum is -0.0f only if both operands are), so after
-// any number of whole blocks lane 15 holds the sum of the list in list order, bit for bit what seq_sum_f32 / seq_sum_huber return.  One
+// any number of whole blocks lane 15 holds the sum of the list in list order, bit for bit what a left-to-right walk with `s += e` (seq_sum_f32) or huber_term_add returns.  One
 // v_add_f32 with a DPP operand per element, for the four seeds of a wave at once.
 __device__ __forceinline__ float row_ror1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));   // row_ror:1
@@ -391,10 +381,11 @@ __device__ __forceinline__ int row_incl_scan(int v) {
 }
 
 // kb_update_seeds (:428-515): 16 lanes per seed (lane = window row), 16 seeds per workgroup.
-// Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window
-// raster order on the group's first lane, fed by terms the 16 lanes prepare in parallel.
-template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can stick out over the right edge); the common instantiation stays at 80 VGPRs,
-                           // so that three k_fuse waves (64 VGPRs) fit next to its four waves per SIMD -- with 88 only two did (+0.5 us per k_fuse launch)
+// Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window raster order as rotating DPP chains
+// over the seed's 16 lanes (chain_block_f32 above), fed by terms each lane computes from its own elements of the ordered depth list.
+// Round 5: 56 VGPRs and 17 KB of LDS (rounds 2-4: 80 and 35 KB -- the term list, the per-seed LDS scalars and their atomics are gone): 8 instead
+// of 4 workgroups per CU for a kernel whose waves mostly wait (13.5 -> 6.9 us per frame beside the other stages, front end +3.7 %).
+template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can stick out over the right edge)
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     // rows of 256 + 16 words: the two seeds of a 32-lane half read / write entry l + 16 t of their own row together (ds_*_b32: bank = word address mod
     // 32); with a row stride of 256 words both rows started on the same bank (round 4: 32 % of the kernel's LDS cycles were bank conflicts)
@@ -488,8 +479,11 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         sumI += __shfl_xor(sumI, d, 16); cnt += __shfl_xor(cnt, d, 16);
     }
     __builtin_amdgcn_wave_barrier();
-    msl_seed T = S;
-    bool aborted = false;
+    // what this update changes of the seed record (the record itself is read again for the final stores: 12 registers less through the gather above,
+    // where the kernel's register count peaks)
+    float tInt = 0, tX = 0, tY = 0;
+    int tR = 0, tG = 0, tB = 0;
+    bool tStable = false, aborted = false;
     const bool depthLoop = active && cnt != 0 && nd > 0;   // (uniform over the seed's 16 lanes)
     if (l == 0 && active) {
         if (cnt == 0) {  // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable
@@ -499,11 +493,10 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             const float sumIntensityNum = (float)cnt;
             const float sumIntensity = (float)sumI / sumIntensityNum, mX = (float)sumX / sumIntensityNum, mY = (float)sumY / sumIntensityNum;
             const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
-            T.meanIntensity = sumIntensity; T.x = mX; T.y = mY;
-            vec3b(P, F, mY, mX, T.r, T.g, T.b);
+            tInt = sumIntensity; tX = mX; tY = mY;
+            vec3b(P, F, mY, mX, tR, tG, tB);
             const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
-            T.stable = (updateDiff < 0.2) ? 1 : 0;
-            if (nd <= 0) T.meanDepth = 0.0f;
+            tStable = updateDiff < 0.2;
         }
     }
     // ---- mean depth and its Huber refinement (:486-512): the sequential sums as rotating chains (above); everything per seed is uniform over its
@@ -568,14 +561,26 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         if (aborted) {
             P.seeds[si].stable = 0; P.arec[si].stable = 0u; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
         } else {
-            if (depthLoop) T.meanDepth = meanDepth;
-            msl_seed old = S;
-            old._pad = 2;
-            P.seedsTmp[si] = old;
-            T._pad = 0;
-            P.seeds[si] = T;
-            P.tmin[si] = T.stable ? T_INF : 0u;
-            P.arec[si] = assign_rec(T);
+            // the 64-byte record as four 16-byte words (nobody else writes it): words 0-1 x, y; 10-11 meanDepth, meanIntensity; 12-14 r, g, b;
+            // 15 the bytes fused | stable << 8 | use << 16 | _pad << 24.  The old record goes to seedsTmp[] marked _pad = 2 (so the commit pass can
+            // restore it when the chunk turns out to have ended earlier), the new one in place.
+            static_assert(sizeof(msl_seed) == 64 && offsetof(msl_seed, meanDepth) == 40 && offsetof(msl_seed, r) == 48 && offsetof(msl_seed, stable) == 61, "msl_seed layout");
+            const uint4 *src = reinterpret_cast<const uint4 *>(P.seeds + si);
+            uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            uint4 *tmp = reinterpret_cast<uint4 *>(P.seedsTmp + si);
+            tmp[0] = w0; tmp[1] = w1; tmp[2] = w2; tmp[3] = make_uint4(w3.x, w3.y, w3.z, (w3.w & 0x00FFFFFFu) | 0x02000000u);
+            const float tDepth = depthLoop ? meanDepth : 0.0f;   // no valid depth among the seed's pixels: 0 (:489-490)
+            w0.x = __float_as_uint(tX); w0.y = __float_as_uint(tY);
+            w2.z = __float_as_uint(tDepth); w2.w = __float_as_uint(tInt);
+            w3.x = (unsigned)tR; w3.y = (unsigned)tG; w3.z = (unsigned)tB;
+            w3.w = (w3.w & 0x00FF00FFu) | (tStable ? 0x100u : 0u);
+            uint4 *dst = reinterpret_cast<uint4 *>(P.seeds + si);
+            dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
+            P.tmin[si] = tStable ? T_INF : 0u;
+            AssignRec a;
+            a.x = tX; a.y = tY; a.meanIntensity = tInt; a.stable = tStable ? 1u : 0u;
+            a.invDepth = tDepth > 0 ? 1.0 / (double)tDepth : -1.0; a._pad = 0;
+            P.arec[si] = a;
         }
     }
 #ifdef MSL_FUSE_STAMPS
@@ -1087,10 +1092,10 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
             prof.end(sp);
             MSL_SF_LAUNCH(prof, SK_COMMIT_PX, sp, kb_commit_px, flatPx, dim3(256), P, n);
         }
-        static const char *updPadEnv = getenv("MSL_UPD_PAD");   // (experiment knob: unused dynamic LDS caps the kernel's workgroups per CU)
-        static const int updPad = updPadEnv ? atoi(updPadEnv) : 0;
-        if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH_LDS(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<true>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), updPad, P, it, n);
-        else MSL_SF_LAUNCH_LDS(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), updPad, P, it, n);
+        // (8 workgroups per CU: 17 KB of LDS, 56 VGPRs.  Capped at 7 / 6 / 5 by unused dynamic LDS: 23.1 / 23.2 / 22.7 k frames/s against 23.1 k -- no
+        // sweet spot below the maximum, unlike kb_seed_plane; at the 4 of rounds 2-4 the kernel took twice as long)
+        if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<true>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
+        else MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         MSL_SF_LAUNCH(prof, SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
     // 4 KB of (unused) dynamic LDS cap the kernel at 8 waves per CU (it could run 11).  Measured on the whole front end (round 3, same box,
