@@ -1098,11 +1098,12 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
         else MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         MSL_SF_LAUNCH(prof, SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    // 4 KB of (unused) dynamic LDS cap the kernel at 8 waves per CU (it could run 11).  Measured on the whole front end (round 3, same box,
-    // alternating runs): 11 waves 19.6 k frames/s, 10 waves 20.6-20.9 k, 9 waves 21.0-21.1 k, 8 waves 21.3-21.5 k, 7 waves 20.3-20.9 k -- the
-    // kernel alone is no slower with fewer waves (its waves are VALU-latency bound), and the wave slots, registers and LDS it leaves go to the
-    // ORB kernels and to the map stage that run beside it.
-    constexpr unsigned planePad = 4096;
+    // 6 KB of (unused) dynamic LDS cap the kernel at 7 waves per CU (it could run 10).  Measured on the whole front end, alternating runs on one
+    // box -- round 3: 11 waves 19.6 k frames/s, 10 waves 20.6-20.9 k, 9 waves 21.0-21.1 k, 8 waves 21.3-21.5 k, 7 waves 20.3-20.9 k; round 5,
+    // beside the slimmer kb_update_seeds: 10 waves 21.9 k, 9 waves 23.1-23.3 k, 8 waves 22.8-23.1 k, 7 waves 23.3-23.5 k, 6 waves 22.8 k, 5 waves
+    // 22.5 k.  The kernel alone is no slower with fewer waves (its waves are VALU-latency bound), and the wave slots, registers and LDS it leaves
+    // go to the ORB kernels and to the map stage that run beside it.
+    constexpr unsigned planePad = 6144;
     if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<true>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     else MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<false>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     if ((W % SP) || (H % SP)) {   // pixels outside the whole cells (sizes that are not multiples of 8)
