@@ -61,6 +61,10 @@ MSL_API int msl_debug_peac_cluster_on_device(int n_frames) MSL_NOEXCEPT;
 MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) MSL_NOEXCEPT;
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n) MSL_NOEXCEPT;
+/* Test hook: out[q] = the strictly sequential (left-to-right) float sum of the first n[q] <= 256 entries of list q (256 floats each) as the superpixel
+ * kernels evaluate it -- a rotating chain over 16 lanes (msl_sf_superpixel.hip); huber != 0: entries +-inf stand for the Huber tail's DOUBLE constant
+ * +-0.4 (src/SurfelFusion.cpp:494-503).  Host arrays; synchronous. */
+MSL_API int msl_debug_chain_sum(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host) MSL_NOEXCEPT;
 
 #define MSL_SF_NKERNELS 12
 MSL_API int msl_sf_profile_enable(msl_sf *h, int mode) MSL_NOEXCEPT;

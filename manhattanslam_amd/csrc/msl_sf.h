@@ -279,6 +279,7 @@ void map_launch_select_write(hipStream_t st, const SfDev &P, int mode, int arg, 
 void map_launch_collect_changed(hipStream_t st, const SfDev &P, int ref, long long n, unsigned *count, unsigned *idxOut, msl_surfel *recOut, unsigned capOut);
 void map_launch_empty(hipStream_t st, int grid, hipEvent_t a, hipEvent_t b);
 int sp_debug_div100(const float *x_host, double *out_host, size_t n);
+int sp_debug_chain(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host);
 
 }  // namespace sf
 }  // namespace msl

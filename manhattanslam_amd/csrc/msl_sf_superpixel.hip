@@ -1055,6 +1055,24 @@ __global__ __launch_bounds__(256) void kb_tex_strips(SfDev P) {
     P.tex[(size_t)slot * P.pxStride + p] = make_uint2(__float_as_uint(F.depthG()[(size_t)y * P.dstride + x]), P.index[(size_t)slot * P.pxStride + p]);
 }
 
+// Test hook of the rotating chains: list q (<= 256 floats at x + 256 q, n[q] of them valid) is summed by the 16 lanes of row q & 3 of wave q >> 2 exactly
+// the way kb_update_seeds sums a seed's depth list (huber = 0) or its Huber terms (huber = 1: +-inf entries mark tail elements).
+__global__ __launch_bounds__(64) void k_debug_chain(const float *x, const int *n, float *out, int lists, int huber) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const int nq = q < lists ? n[q] : 0;
+    int nblk = (nq + 15) >> 4;
+#pragma unroll
+    for (int d = 32; d >= 16; d >>= 1) nblk = max(nblk, __shfl_xor(nblk, d, 64));
+    nblk = __builtin_amdgcn_readfirstlane(nblk);
+    float s = 0.0f;
+    for (int bq = 0; bq < nblk; bq++) {
+        const int e = l + 16 * bq;
+        const float t = e < nq ? x[(size_t)q * 256 + e] : 0.0f;
+        s = huber ? chain_block_huber(s, t) : chain_block_f32(s, t);
+    }
+    if (q < lists && l == 15) out[q] = s;
+}
+
 __global__ void k_debug_div100(const float *x, double *out, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = div100_exact((double)(x[i] * x[i]));
@@ -1110,6 +1128,20 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
         const int nStrip = (W - P.spW * SP) * P.spH * SP + W * (H - P.spH * SP);
         hipLaunchKernelGGL(kb_tex_strips, dim3((unsigned)((nStrip + 255) / 256), un), dim3(256), 0, sp, P);
     }
+}
+
+int sp_debug_chain(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host) {
+    if (lists <= 0) return MSL_OK;
+    if (!x_host || !n_host || !out_host) return MSL_ERR_INVALID;
+    for (int q = 0; q < lists; q++) if (n_host[q] < 0 || n_host[q] > 256) return MSL_ERR_INVALID;
+    float *dx = nullptr, *dout = nullptr; int *dn = nullptr;
+    MSL_HIP_TRY(hipMalloc(&dx, sizeof(float) * 256 * (size_t)lists)); MSL_HIP_TRY(hipMalloc(&dn, sizeof(int) * (size_t)lists)); MSL_HIP_TRY(hipMalloc(&dout, sizeof(float) * (size_t)lists));
+    MSL_HIP_TRY(hipMemcpy(dx, x_host, sizeof(float) * 256 * (size_t)lists, hipMemcpyHostToDevice));
+    MSL_HIP_TRY(hipMemcpy(dn, n_host, sizeof(int) * (size_t)lists, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_debug_chain, dim3((unsigned)((lists + 3) / 4)), dim3(64), 0, 0, dx, dn, dout, lists, huber);
+    MSL_HIP_TRY(hipMemcpy(out_host, dout, sizeof(float) * (size_t)lists, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dn); (void)hipFree(dout);
+    return MSL_OK;
 }
 
 int sp_debug_div100(const float *x_host, double *out_host, size_t n) {

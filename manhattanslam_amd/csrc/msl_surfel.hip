@@ -1023,6 +1023,7 @@ int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) noexcept {
     } MSL_ABI_CATCH_INT
 }
 int msl_debug_div100(const float *x_host, double *out_host, size_t n) noexcept { try { return sp_debug_div100(x_host, out_host, n); } MSL_ABI_CATCH_INT }
+int msl_debug_chain_sum(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host) noexcept { try { return sp_debug_chain(x_host, n_host, lists, huber, out_host); } MSL_ABI_CATCH_INT }
 const char *msl_sf_kernel_name(int k) noexcept { try { return (k >= 0 && k < MSL_SF_NKERNELS) ? kSfNames[k] : ""; } MSL_ABI_CATCH_PTR }
 
 }  // extern "C"

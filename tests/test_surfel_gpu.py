@@ -271,6 +271,45 @@ def test_div100_exact():
     assert np.array_equal(out, ref), np.flatnonzero(out != ref)[:5]
 
 
+def test_rotating_chain_is_the_left_to_right_float_sum():
+    """kb_update_seeds evaluates the reference's sequential float sums (depth mean and Huber / Newton numerator, src/SurfelFusion.cpp:486-503) as a
+    chain that rotates over 16 lanes (round 5).  On adversarial lists -- every length 0..256, values spread over 20 binades with heavy cancellation,
+    so that any other summation order changes the bits -- the chain returns the left-to-right float32 sum bit for bit; with +-inf markers it adds the
+    DOUBLE constant +-0.4 the way the reference's promotion does."""
+    from manhattanslam_amd import lib
+    from manhattanslam_amd._lib import check, ptr
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([np.arange(257), rng.integers(0, 257, 767)]).astype(np.int32)
+    L = len(lens)
+    x = (rng.uniform(-1, 1, (L, 256)) * np.float32(2.0) ** rng.integers(-10, 10, (L, 256))).astype(np.float32)
+    x[5] = 0.0; x[6, ::2] = -0.0                                   # zeros of both signs
+    x[7, :200] = np.tile(np.array([1e8, 1.0, -1e8, 1.0], np.float32), 50)   # order-sensitive cancellation
+    out = np.zeros(L, np.float32)
+    check(lib.msl_debug_chain_sum(ptr(x), ptr(lens), L, 0, ptr(out)))
+    ref = np.zeros(L, np.float32)
+    for q in range(L):
+        s = np.float32(0.0)
+        for e in range(lens[q]):
+            s = np.float32(s + x[q, e])
+        ref[q] = s
+    assert np.array_equal(out.view(np.int32), ref.view(np.int32)), np.flatnonzero(out.view(np.int32) != ref.view(np.int32))[:5]
+    # order sensitivity of the inputs: a pairwise (tree) sum differs on most lists, so the equality above does discriminate
+    tree = np.array([np.sum(x[q, :lens[q]], dtype=np.float32) for q in range(L)])
+    assert (tree.view(np.int32) != ref.view(np.int32)).mean() > 0.3
+    # Huber tails: +-inf marks an element whose contribution is (float)((double)s +- 0.4)
+    xh = x.copy()
+    mark = rng.random((L, 256)) < 0.15
+    xh[mark] = np.where(rng.random(int(mark.sum())) < 0.5, np.float32(np.inf), np.float32(-np.inf))
+    check(lib.msl_debug_chain_sum(ptr(xh), ptr(lens), L, 1, ptr(out)))
+    for q in range(L):
+        s = np.float32(0.0)
+        for e in range(lens[q]):
+            t = xh[q, e]
+            s = np.float32(np.float64(s) + (0.4 if t > 0 else -0.4)) if np.isinf(t) else np.float32(s + t)
+        ref[q] = s
+    assert np.array_equal(out.view(np.int32), ref.view(np.int32)), np.flatnonzero(out.view(np.int32) != ref.view(np.int32))[:5]
+
+
 def test_map_maintenance_matches_literal_loops(oracle):
     """moveAddSurfels detach / re-attach and the Stop() export filter on the resident map."""
     import ctypes as C
