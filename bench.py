@@ -629,6 +629,9 @@ def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F,
         sf.map_upload(smap)
         sf.map_snapshot()
         d_np = torch.from_numpy(np.tile(depths, (reps, 1, 1))).pin_memory().numpy()
+        # the same depth as the sensor / the data set delivers it: raw 16-bit values, 5000 per metre (TUM / ICL), converted on the device
+        d16_np = torch.from_numpy(np.tile(np.clip(np.rint(depths * 5000.0), 0, 65535).astype(np.uint16), (reps, 1, 1))).pin_memory().numpy()
+        d16_factor = float(np.float32(1.0) / np.float32(5000.0))
         m_np = torch.from_numpy(member).pin_memory().numpy()
         kf_poses = [[poses[(sb * B + j * kfe) % D] for j in range(nkf)] for sb in range(nsub)]
 
@@ -638,18 +641,18 @@ def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F,
             for sb in range(which, nsub, 2):
                 ex.extract_batch_host(g_np[sb * B:(sb + 1) * B], h_kps[sb * B * cap * 28:], h_desc[sb * B * cap * 32:], h_n[sb * B:], B, W, H)
 
-    def sf_worker(npass):
+    def sf_worker(npass, raw16):
         for _ in range(npass):
             sf.map_restore()
             for sb in range(nsub):
-                sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], d_np[sb * B:], m_np, kf_poses[sb], device=False,
-                                       member_shared=True, frame_step=kfe)
+                sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], (d16_np if raw16 else d_np)[sb * B:], m_np, kf_poses[sb],
+                                       device=False, member_shared=True, frame_step=kfe, depth_factor=d16_factor if raw16 else None)
         sf.sync()
 
-    def run(npass):
+    def run(npass, raw16=False):
         th = [threading.Thread(target=orb_worker, args=(i, npass)) for i in range(len(orbs))]
         if do_sf:
-            th.append(threading.Thread(target=sf_worker, args=(npass,)))
+            th.append(threading.Thread(target=sf_worker, args=(npass, raw16)))
         for t in th:
             t.start()
         for t in th:
@@ -670,6 +673,16 @@ def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F,
            "note": "pinned host buffers in (gray for ORB and again for SurfelFusion, f32 depth; the shared membership image once per call) and out "
                    "(keypoints, descriptors, counts); msl_orb_extract_batch / msl_sf_fuse_resident_batch with MSL_MEM_HOST; 2 ORB handles on 2 host "
                    "threads + 1 thread for the surfel handle"}
+    if do_sf:
+        run(2, True)
+        t0 = time.perf_counter()
+        run(npass, True)
+        fps16 = npass * F / (time.perf_counter() - t0)
+        h2d16 = (W * H if do_orb else 0) + (W * H + 2 * W * H) / kfe
+        res["raw_depth16"] = {"value_streaming": round(fps16, 1), "fraction_of_resident": round(fps16 / resident_value, 3), "h2d_bytes_per_frame": int(h2d16),
+                              "h2d_gbs": round(h2d16 * fps16 / 1e9, 2),
+                              "note": "the same passes with the depth images as raw uint16 (5000 per metre) through msl_sf_fuse_resident_batch_d16: converted on "
+                                      "the device as float(raw) * factor (src/Frame.cc:96-97), 2 instead of 4 depth bytes per pixel over PCIe"}
     for ex in orbs:
         ex.close()
     if do_sf:

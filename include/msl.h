@@ -397,6 +397,16 @@ MSL_API int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *r
                                        size_t depth_stride, size_t depth_frame_stride, const int32_t *member,
                                        size_t member_stride, size_t member_frame_stride, msl_mem img_mem,
                                        const float *poses_colmajor) MSL_NOEXCEPT;
+/* The same call for RAW 16-bit depth images (the sensor's / the data set's format): keyframe f's depth is depth16 + f * depth16_frame_stride bytes,
+ * rows depth16_stride bytes apart, and becomes metres on the device as (float)raw * depth_factor -- what Frame::Frame does on the host with
+ * imDepth.convertTo(imDepthScaled, CV_32F, depthMapFactor) (src/Frame.cc:96-97, depthMapFactor = 1 / DepthMapFactor of the settings file,
+ * src/Tracking.cc:133-137; OpenCV evaluates that conversion in float).  Half the depth bytes cross PCIe and the host loop disappears; the results
+ * are bit-identical to msl_sf_fuse_resident_batch on the converted images.  img_mem applies to gray, depth16 and member alike. */
+MSL_API int msl_sf_fuse_resident_batch_d16(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray,
+                                           size_t gray_stride, size_t gray_frame_stride, const uint16_t *depth16,
+                                           size_t depth16_stride, size_t depth16_frame_stride, float depth_factor,
+                                           const int32_t *member, size_t member_stride, size_t member_frame_stride,
+                                           msl_mem img_mem, const float *poses_colmajor) MSL_NOEXCEPT;
 MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) MSL_NOEXCEPT;
 MSL_API int msl_sf_sync(msl_sf *h) MSL_NOEXCEPT;
 MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream) MSL_NOEXCEPT;

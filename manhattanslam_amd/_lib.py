@@ -92,6 +92,7 @@ SIGNATURES = {
     "msl_sf_fuse_resident": (_i, [_vp, _i, _vp, _sz, _vp, _sz, _vp, _sz, _i, _vp]),
     "msl_sf_set_batch_capacity": (_i, [_vp, _i]),
     "msl_sf_fuse_resident_batch": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _i, _vp]),
+    "msl_sf_fuse_resident_batch_d16": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp, _sz, _sz, _f, _vp, _sz, _sz, _i, _vp]),
     "msl_sf_last_counters": (_i, [_vp, _vp]),
     "msl_sf_sync": (_i, [_vp]),
     "msl_sf_set_stream": (_i, [_vp, _vp]),

@@ -265,6 +265,10 @@ enum { SK_SEED_INIT = 0, SK_ASSIGN, SK_PROP, SK_COMMIT_PX, SK_UPDATE_SEEDS, SK_C
 // msl_sf_superpixel.hip
 bool sp_init_attributes(int nseeds);   // true: one keyframe's t(s) fits the LDS (single-launch relaxation)
 void sp_launch_stage(KernelProfiler &prof, hipStream_t st, const SfDev &P, int nFrames, bool propLds);
+// raw 16-bit depth -> float metres (src/Frame.cc:96-97) for nFrames images: src rows srcStride bytes apart, frames srcFrameStride bytes apart; dst tightly
+// packed rows of W floats, frames dstFrameStride floats apart
+void sp_launch_depth_u16(hipStream_t st, const void *src, size_t srcStride, size_t srcFrameStride, float *dst, size_t dstFrameStride, int W, int H, int nFrames,
+                         float factor);
 // msl_sf_map.hip
 void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred);
 void map_launch_compact(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, bool resident);

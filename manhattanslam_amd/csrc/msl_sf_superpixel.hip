@@ -1039,6 +1039,22 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     }
 }
 
+// Raw 16-bit depth (what the sensor / the data set's PNG holds) -> metres, on the device: imDepth.convertTo(imDepthScaled, CV_32F, depthMapFactor) of
+// src/Frame.cc:96-97.  OpenCV's 16U -> 32F conversion with a scale works in float: dst = (float)src * (float)alpha + 0.0f (one rounding: the float
+// product), which is what this kernel evaluates; a third of the bytes cross PCIe (2 instead of 4 per pixel) and the host loop disappears.
+__global__ __launch_bounds__(256) void kb_depth_u16(const uint8_t *src, size_t srcStride, size_t srcFrameStride, float *dst, size_t dstFrameStride, int W, int H,
+                                                    float factor) {
+    const int frame = blockIdx.y;
+    const int npx = W * H;
+    const uint8_t *sf = src + (size_t)frame * srcFrameStride;
+    float *df = dst + (size_t)frame * dstFrameStride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < npx; i += gridDim.x * 256) {
+        const int row = i / W, col = i - row * W;
+        const unsigned raw = *reinterpret_cast<const uint16_t *>(sf + (size_t)row * srcStride + 2 * (size_t)col);
+        df[i] = (float)raw * factor;
+    }
+}
+
 // Image sizes that are not multiples of 8: the strips right of / below the last whole 8x8 cell belong to no cell, so kb_seed_plane does not
 // write their texels; this (tiny, rarely launched) kernel does.
 __global__ __launch_bounds__(256) void kb_tex_strips(SfDev P) {
@@ -1082,6 +1098,12 @@ __global__ void k_debug_div100(const float *x, double *out, long long n) {
 
 namespace msl {
 namespace sf {
+
+void sp_launch_depth_u16(hipStream_t st, const void *src, size_t srcStride, size_t srcFrameStride, float *dst, size_t dstFrameStride, int W, int H, int nFrames,
+                         float factor) {
+    const unsigned bx = (unsigned)std::min(((long long)W * H + 1023) / 1024, 1024ll);   // four pixels per thread
+    hipLaunchKernelGGL(kb_depth_u16, dim3(bx, (unsigned)nFrames), dim3(256), 0, st, (const uint8_t *)src, srcStride, srcFrameStride, dst, dstFrameStride, W, H, factor);
+}
 
 bool sp_init_attributes(int nseeds) {
     // the attribute belongs to the function, not to a handle: always ask for the largest size any handle may use

@@ -47,6 +47,7 @@ struct msl_sf {
     // staged images (host input mode), per slot
     uint8_t *d_gray = nullptr; float *d_depth = nullptr; int32_t *d_member = nullptr;
     size_t grayCap = 0, depthCap = 0, memberCap = 0;  // bytes per slot
+    uint8_t *d_depth16 = nullptr; size_t depth16Cap = 0;   // raw 16-bit depth of host-image calls (msl_sf_fuse_resident_batch_d16), bytes per slot
     long long *d_ctr = nullptr; long long *h_ctr = nullptr;
     unsigned *d_tickets = nullptr, *d_delU = nullptr;
     DeferCtl *d_dc = nullptr;
@@ -185,9 +186,9 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
 void free_slots(msl_sf *h) {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->d_frames); F(h->d_seeds); F(h->d_seedsTmp); F(h->d_cand); F(h->d_candOk); F(h->d_fused); F(h->d_tex); F(h->d_fuseRec); F(h->d_index); F(h->d_amap); F(h->d_tmin);
-    F(h->d_chunkAbort); F(h->d_changed); F(h->d_arec); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member);
+    F(h->d_chunkAbort); F(h->d_changed); F(h->d_arec); F(h->d_pxInv); F(h->d_wl); F(h->d_wlCount); F(h->d_gray); F(h->d_depth); F(h->d_member); F(h->d_depth16);
     if (h->h_frames) { (void)hipHostFree(h->h_frames); h->h_frames = nullptr; }
-    h->grayCap = h->depthCap = h->memberCap = 0;
+    h->grayCap = h->depthCap = h->memberCap = 0; h->depth16Cap = 0;
 }
 
 int alloc_slots(msl_sf *h, int maxBatch) {
@@ -254,12 +255,20 @@ int check_err(msl_sf *h) {
     return MSL_OK;
 }
 // Superpixel stage for slots [slot0, slot0+n) on the pre stream, then the map stage per keyframe on the map stream.
+// depth16 != nullptr: the depth images are raw 16-bit values (rows d16s bytes apart, frames d16fs bytes apart) that become metres on the device,
+// (float)raw * depthFactor (src/Frame.cc:96-97); `depth` / ds / dfs are ignored then.
 int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t gs, size_t gfs, const float *depth, size_t ds, size_t dfs,
-              const int32_t *member, size_t ms, size_t mfs, msl_mem mem, const float *poses, bool compact) {
+              const int32_t *member, size_t ms, size_t mfs, msl_mem mem, const float *poses, bool compact, const uint16_t *depth16 = nullptr,
+              size_t d16s = 0, size_t d16fs = 0, float depthFactor = 1.0f) {
     SfDev &D = h->dev;
     const int W = D.W, H = D.H;
     if (n < 1 || n > h->maxBatch) { set_error("msl_sf: batch of %d keyframes exceeds the batch capacity %d", n, h->maxBatch); return MSL_ERR_INVALID; }
-    if (!gray || !depth || !member || !poses || !refs || gs < (size_t)W || ds < (size_t)W * 4 || ms < (size_t)((W + 1) / 2) * 4 || (ds & 3) || (ms & 3)) {
+    const bool d16 = depth16 != nullptr;
+    if (d16) {
+        if (d16s < (size_t)W * 2 || (d16s & 1) || (d16fs & 1) || ((uintptr_t)depth16 & 1)) { set_error("msl_sf: bad 16-bit depth pointer or strides"); return MSL_ERR_INVALID; }
+        ds = (size_t)W * 4; dfs = ds * (size_t)H;   // the converted images are tightly packed
+    }
+    if (!gray || (!depth && !d16) || !member || !poses || !refs || gs < (size_t)W || ds < (size_t)W * 4 || ms < (size_t)((W + 1) / 2) * 4 || (ds & 3) || (ms & 3)) {
         set_error("msl_sf: bad image pointers or strides");
         return MSL_ERR_INVALID;
     }
@@ -301,6 +310,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     if (h->evMapValid[set] && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evMap[set], 0));   // the set's previous user is done
     D.gstride = gs; D.gbytes = gs * (size_t)(H - 1) + W; D.dstride = ds / 4; D.mstride = ms / 4;
     // bytes actually present in the caller's buffers: the last row carries no stride padding
+    const size_t d16b = d16 ? d16s * (size_t)(H - 1) + (size_t)W * 2 : 0;
     const size_t gb = gs * (size_t)(H - 1) + W, db = ds * (size_t)(H - 1) + (size_t)W * 4, mb = ms * (size_t)((H + 1) / 2 - 1) + (size_t)((W + 1) / 2) * 4;   // the membership image is ceil(H / 2) x ceil(W / 2) (PlaneDetection's cloud size)
     if (mem == MSL_MEM_HOST) {
         const size_t slots = 2 * (size_t)h->maxBatch;
@@ -311,8 +321,17 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             if (h->d_depth) (void)hipFree(h->d_depth);
             if (h->d_member) (void)hipFree(h->d_member);
             h->d_gray = nullptr; h->d_depth = nullptr; h->d_member = nullptr;
+            h->grayCap = h->depthCap = h->memberCap = 0;
             MSL_HIP_TRY(hipMalloc(&h->d_gray, gb * slots)); MSL_HIP_TRY(hipMalloc(&h->d_depth, db * slots)); MSL_HIP_TRY(hipMalloc(&h->d_member, mb * slots));
             h->grayCap = gb; h->depthCap = db; h->memberCap = mb;
+        }
+        if (d16 && d16b > h->depth16Cap) {
+            int rc = sync_all(h);
+            if (rc != MSL_OK) return rc;
+            if (h->d_depth16) (void)hipFree(h->d_depth16);
+            h->d_depth16 = nullptr; h->depth16Cap = 0;
+            MSL_HIP_TRY(hipMalloc(&h->d_depth16, d16b * slots));
+            h->depth16Cap = d16b;
         }
         // The images travel on their own stream so that they overlap the superpixel kernels of the previous call (the other slot set);
         // with caller-provided streams (msl_sf_set_stream) everything stays on that one stream.
@@ -321,23 +340,44 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         h->prof.begin(SK_COPY, sc);
         // Tightly packed frame arrays (the streaming case) travel as ONE copy per image kind instead of one per frame; a membership image
         // shared by all keyframes of the call (member_frame_stride == 0) is staged once.
-        const bool packedG = n > 1 && gfs == gb && h->grayCap == gb, packedD = n > 1 && dfs == db && h->depthCap == db;
+        const bool packedG = n > 1 && gfs == gb && h->grayCap == gb, packedD = !d16 && n > 1 && dfs == db && h->depthCap == db;
+        const bool packed16 = d16 && n > 1 && d16fs == d16b && h->depth16Cap == d16b;
         const bool packedM = n > 1 && mfs == mb && h->memberCap == mb;
         if (packedG) MSL_HIP_TRY(hipMemcpyAsync(h->d_gray + (size_t)slot0 * h->grayCap, gray, gb * (size_t)n, hipMemcpyHostToDevice, sc));
         if (packedD) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + (size_t)slot0 * h->depthCap, depth, db * (size_t)n, hipMemcpyHostToDevice, sc));
+        if (packed16) MSL_HIP_TRY(hipMemcpyAsync(h->d_depth16 + (size_t)slot0 * h->depth16Cap, depth16, d16b * (size_t)n, hipMemcpyHostToDevice, sc));
         if (packedM) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + (size_t)slot0 * h->memberCap, member, mb * (size_t)n, hipMemcpyHostToDevice, sc));
         if (mfs == 0) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + (size_t)slot0 * h->memberCap, member, mb, hipMemcpyHostToDevice, sc));
         for (int f = 0; f < n; f++) {
             const size_t s = slot0 + f;
             if (!packedG) MSL_HIP_TRY(hipMemcpyAsync(h->d_gray + s * h->grayCap, gray + f * gfs, gb, hipMemcpyHostToDevice, sc));
-            if (!packedD) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + s * h->depthCap, (const uint8_t *)depth + f * dfs, db, hipMemcpyHostToDevice, sc));
+            if (!d16 && !packedD) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_depth + s * h->depthCap, (const uint8_t *)depth + f * dfs, db, hipMemcpyHostToDevice, sc));
+            if (d16 && !packed16) MSL_HIP_TRY(hipMemcpyAsync(h->d_depth16 + s * h->depth16Cap, (const uint8_t *)depth16 + f * d16fs, d16b, hipMemcpyHostToDevice, sc));
             if (!packedM && mfs != 0) MSL_HIP_TRY(hipMemcpyAsync((uint8_t *)h->d_member + s * h->memberCap, (const uint8_t *)member + f * mfs, mb, hipMemcpyHostToDevice, sc));
         }
+        if (d16)   // raw -> metres behind the copies, on their stream (same rows of stride d16s in the staging slots; frames depth16Cap bytes apart)
+            sp_launch_depth_u16(sc, h->d_depth16 + (size_t)slot0 * h->depth16Cap, d16s, h->depth16Cap, (float *)((uint8_t *)h->d_depth + (size_t)slot0 * h->depthCap),
+                                h->depthCap / 4, W, H, n, depthFactor);
         h->prof.end(sc);
         if (sc != sp) {
             MSL_HIP_TRY(hipEventRecord(h->evH2D[set], sc));
             MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evH2D[set], 0));
         }
+    }
+    if (d16 && mem != MSL_MEM_HOST) {   // device-resident raw depth: converted into the handle's float slots on the superpixel stream
+        const size_t slots = 2 * (size_t)h->maxBatch;
+        if (db > h->depthCap || !h->d_depth) {
+            int rc = sync_all(h);
+            if (rc != MSL_OK) return rc;
+            if (h->d_gray) (void)hipFree(h->d_gray);
+            if (h->d_depth) (void)hipFree(h->d_depth);
+            if (h->d_member) (void)hipFree(h->d_member);
+            h->d_gray = nullptr; h->d_depth = nullptr; h->d_member = nullptr;
+            h->grayCap = h->depthCap = h->memberCap = 0;     // (a later host-image call allocates all three anew)
+            MSL_HIP_TRY(hipMalloc(&h->d_depth, db * slots));
+            h->depthCap = db;
+        }
+        sp_launch_depth_u16(sp, depth16, d16s, d16fs, (float *)((uint8_t *)h->d_depth + (size_t)slot0 * h->depthCap), h->depthCap / 4, W, H, n, depthFactor);
     }
     if (h->evCopyValid[set]) MSL_HIP_TRY(hipEventSynchronize(h->evCopy[set]));   // pinned staging of this set is free again
     for (int f = 0; f < n; f++) {
@@ -347,7 +387,8 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             F.gray = h->d_gray + s * h->grayCap; F.depth = (const float *)((uint8_t *)h->d_depth + s * h->depthCap);
             F.member = (const int32_t *)((uint8_t *)h->d_member + (mfs == 0 ? (size_t)slot0 : s) * h->memberCap);
         } else {
-            F.gray = gray + f * gfs; F.depth = (const float *)((const uint8_t *)depth + f * dfs); F.member = (const int32_t *)((const uint8_t *)member + f * mfs);
+            F.gray = gray + f * gfs; F.member = (const int32_t *)((const uint8_t *)member + f * mfs);
+            F.depth = d16 ? (const float *)((uint8_t *)h->d_depth + (size_t)(slot0 + f) * h->depthCap) : (const float *)((const uint8_t *)depth + f * dfs);
         }
         memcpy(F.pose, poses + 16 * f, sizeof(float) * 16);
         inverse4<float>(F.pose, F.invPose);   // pose.inverse() (:59), adjugate/determinant in float
@@ -784,6 +825,19 @@ int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, con
     MSL_HIP_TRY(hipSetDevice(h->device));
     return run_batch(h, n_frames, refs, gray, gray_stride, gray_frame_stride, depth, depth_stride, depth_frame_stride, member, member_stride,
                      member_frame_stride, img_mem, poses_colmajor, true);
+    } MSL_ABI_CATCH_INT
+}
+
+int msl_sf_fuse_resident_batch_d16(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray, size_t gray_stride, size_t gray_frame_stride,
+                                   const uint16_t *depth16, size_t depth16_stride, size_t depth16_frame_stride, float depth_factor,
+                                   const int32_t *member, size_t member_stride, size_t member_frame_stride, msl_mem img_mem,
+                                   const float *poses_colmajor) noexcept {
+    try {
+    if (!h) { set_error("msl_sf_fuse_resident_batch_d16: NULL handle"); return MSL_ERR_INVALID; }
+    if (!depth16) { set_error("msl_sf_fuse_resident_batch_d16: NULL depth"); return MSL_ERR_INVALID; }
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    return run_batch(h, n_frames, refs, gray, gray_stride, gray_frame_stride, nullptr, 0, 0, member, member_stride, member_frame_stride, img_mem, poses_colmajor,
+                     true, depth16, depth16_stride, depth16_frame_stride, depth_factor);
     } MSL_ABI_CATCH_INT
 }
 

@@ -120,10 +120,12 @@ class SurfelFusion:
     def set_batch_capacity(self, max_frames):
         check(lib.msl_sf_set_batch_capacity(self._h, int(max_frames)), "msl_sf_set_batch_capacity")
 
-    def fuse_resident_batch(self, refs, grays, depths, members, poses, device=False, member_shared=False, frame_step=1, member_frame_step=None):
+    def fuse_resident_batch(self, refs, grays, depths, members, poses, device=False, member_shared=False, frame_step=1, member_frame_step=None,
+                            depth_factor=None):
         """Keyframes in order.  grays (n,H,W) u8, depths (n,H,W) f32, members (n,H/2,W/2) i32 (or (H/2,W/2) with
         member_shared=True), poses (n,16) column-major; host numpy arrays or, with device=True, torch tensors.
-        frame_step = k: keyframe j is frame j * k of the image arrays (SurfelFusion on every k-th frame of a sequence)."""
+        frame_step = k: keyframe j is frame j * k of the image arrays (SurfelFusion on every k-th frame of a sequence).
+        depth_factor = a: depths are RAW uint16 images, converted on the device as float(raw) * a (src/Frame.cc:96-97)."""
         n = len(refs)
         k = int(frame_step)
         km = k if member_frame_step is None else int(member_frame_step)   # membership images may come one per keyframe (PEAC output)
@@ -131,6 +133,11 @@ class SurfelFusion:
         poses = np.ascontiguousarray(np.stack([_pose16(p) for p in poses]), np.float32)
         w, h = self.width, self.height
         mw, mh = (w + 1) // 2, (h + 1) // 2      # the membership image is ceil(h / 2) x ceil(w / 2) (PlaneDetection's cloud size)
+        if depth_factor is not None:
+            check(lib.msl_sf_fuse_resident_batch_d16(self._h, n, ptr(refs), ptr(grays), w, k * w * h, ptr(depths), 2 * w, 2 * k * w * h, float(depth_factor),
+                                                     ptr(members), 4 * mw, 0 if member_shared else 4 * km * mw * mh,
+                                                     MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch_d16")
+            return
         check(lib.msl_sf_fuse_resident_batch(self._h, n, ptr(refs), ptr(grays), w, k * w * h, ptr(depths), 4 * w, 4 * k * w * h, ptr(members),
                                              4 * mw, 0 if member_shared else 4 * km * mw * mh,
                                              MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch")

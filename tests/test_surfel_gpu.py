@@ -271,6 +271,45 @@ def test_div100_exact():
     assert np.array_equal(out, ref), np.flatnonzero(out != ref)[:5]
 
 
+def test_raw_depth16_batches_match_the_float_path(oracle):
+    """msl_sf_fuse_resident_batch_d16 (round 5): raw 16-bit depth converted on the device as float(raw) * factor -- Frame::Frame's
+    imDepth.convertTo(imDepthScaled, CV_32F, depthMapFactor) (src/Frame.cc:96-97; OpenCV evaluates it in float) -- gives bit for bit the maps, seeds
+    and index maps of the float entry point fed with the host-converted images, from host memory and from device memory, and both are the oracle's."""
+    import torch
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    a = np.float32(1.0) / np.float32(5000.0)                     # mDepthMapFactor = 1.0f / DepthMapFactor (src/Tracking.cc:133-137)
+    frames = [synth.clutter_frame(4 * j) for j in range(4)]
+    raw = np.stack([synth.depth_u16(f[1]) for f in frames])      # what the sensor delivers
+    d32 = raw.astype(np.float32) * a                             # what the reference's host code makes of it
+    grays = np.stack([f[0] for f in frames]); member = np.stack([f[2] for f in frames]); poses = [f[3] for f in frames]
+    m = synth.surfel_map_dense(120000, ref=0, scene=synth.clutter_scene(), k_lo=-40, k_hi=60, min_update_times=1).astype(SURFEL_DTYPE)
+    maps, seeds, idx = [], [], []
+    for mode in ("float", "raw-host", "raw-device"):
+        g, o = _mk(synth.TUM1)
+        g.set_batch_capacity(2); g.map_reserve(300000); g.map_upload(m)
+        for b in range(2):
+            sl = slice(2 * b, 2 * b + 2)
+            if mode == "float":
+                g.fuse_resident_batch([2 * b, 2 * b + 1], grays[sl], d32[sl], member[sl], poses[sl])
+            elif mode == "raw-host":
+                g.fuse_resident_batch([2 * b, 2 * b + 1], grays[sl], raw[sl], member[sl], poses[sl], depth_factor=float(a))
+            else:
+                tg, tr, tm = torch.from_numpy(grays[sl]).cuda(), torch.from_numpy(raw[sl].view(np.int16)).cuda(), torch.from_numpy(member[sl]).cuda()
+                g.fuse_resident_batch([2 * b, 2 * b + 1], tg, tr, tm, poses[sl], device=True, depth_factor=float(a))
+                g.sync()
+        maps.append(g.map_download()); seeds.append(g.debug_seeds()); idx.append(g.debug_index())
+        if mode == "float":
+            o.map_set(m)
+            for j in range(4):
+                o.fuse_map(j, grays[j], d32[j], member[j], poses[j])
+            assert_surfels_close(maps[0], o.map_get(), "float path against the oracle")
+        g.close()
+    for k in (1, 2):
+        assert maps[k].tobytes() == maps[0].tobytes(), k
+        assert seeds[k].tobytes() == seeds[0].tobytes(), k
+        assert np.array_equal(idx[k], idx[0]), k
+
+
 def test_rotating_chain_is_the_left_to_right_float_sum():
     """kb_update_seeds evaluates the reference's sequential float sums (depth mean and Huber / Newton numerator, src/SurfelFusion.cpp:486-503) as a
     chain that rotates over 16 lanes (round 5).  On adversarial lists -- every length 0..256, values spread over 20 binades with heavy cancellation,
