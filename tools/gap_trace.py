@@ -1,4 +1,5 @@
-"""Device-idle gaps and longest kernels of a rocprofv3 --kernel-trace run (CSV output).  Usage: python tools/gap_trace.py <rocprofv3 output directory>\nUsed for profiles/r05_idle_gap_trace.txt."""
+"""Device-idle gaps and longest kernels of a rocprofv3 --kernel-trace run (CSV output), used for profiles/r05_idle_gap_trace.txt.
+Usage: python tools/gap_trace.py <rocprofv3 output directory>"""
 import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
