@@ -262,9 +262,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a line whose n_gpus differs from --gpus")
     if args.dry_run:
         return dry_run(args, world, rank, local_rank)
-    if args.sequences_per_gpu > 1:
-        # every sequence brings six streams of three priorities; the runtime maps them onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams
-        # that share a queue serialise: two sequences 15.8 k frames/s with 4 queues, 19.9 k with 8 (16: the same).  Read when the runtime starts.
+    if args.sequences_per_gpu > 1 or args.io == "host":
+        # every sequence brings six streams of three priorities (the streaming passes: a second ORB handle and three host threads); the runtime maps
+        # them onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and streams that share a queue serialise: two sequences 15.8 k frames/s with 4
+        # queues, 19.9 k with 8 (16: the same); --io host 16.1 k -> 17.6 k.  One resident sequence -- `value` -- is the same with 4, 8 or 16
+        # (23.32 / 23.26 / 23.32 k).  Read when the runtime starts.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
