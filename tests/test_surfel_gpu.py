@@ -284,7 +284,13 @@ def test_raw_depth16_batches_match_the_float_path(oracle):
     grays = np.stack([f[0] for f in frames]); member = np.stack([f[2] for f in frames]); poses = [f[3] for f in frames]
     m = synth.surfel_map_dense(120000, ref=0, scene=synth.clutter_scene(), k_lo=-40, k_hi=60, min_update_times=1).astype(SURFEL_DTYPE)
     maps, seeds, idx = [], [], []
-    for mode in ("float", "raw-host", "raw-device"):
+    from manhattanslam_amd import lib
+    from manhattanslam_amd._lib import check, ptr
+    from manhattanslam_amd.surfel import _pose16
+    W, H = 640, 480
+    rawp = np.full((4, H + 3, W + 24), 0xFFFF, np.uint16)          # rows 2 * (W + 24) bytes apart, frames (H + 3) rows apart, garbage in the padding
+    rawp[:, :H, :W] = raw
+    for mode in ("float", "raw-host", "raw-host-padded", "raw-device"):
         g, o = _mk(synth.TUM1)
         g.set_batch_capacity(2); g.map_reserve(300000); g.map_upload(m)
         for b in range(2):
@@ -293,6 +299,13 @@ def test_raw_depth16_batches_match_the_float_path(oracle):
                 g.fuse_resident_batch([2 * b, 2 * b + 1], grays[sl], d32[sl], member[sl], poses[sl])
             elif mode == "raw-host":
                 g.fuse_resident_batch([2 * b, 2 * b + 1], grays[sl], raw[sl], member[sl], poses[sl], depth_factor=float(a))
+            elif mode == "raw-host-padded":   # straight through the C ABI with row / frame strides that are not tight
+                refs = np.array([2 * b, 2 * b + 1], np.int32)
+                pz = np.ascontiguousarray(np.stack([_pose16(p) for p in poses[sl]]), np.float32)
+                gb, mb, rp = np.ascontiguousarray(grays[sl]), np.ascontiguousarray(member[sl]), np.ascontiguousarray(rawp[sl])
+                check(lib.msl_sf_fuse_resident_batch_d16(g._h, 2, ptr(refs), ptr(gb), W, W * H, ptr(rp), 2 * (W + 24), 2 * (W + 24) * (H + 3), float(a),
+                                                         ptr(mb), 4 * (W // 2), 4 * (W // 2) * (H // 2), 0, ptr(pz)), "d16 padded")
+                g.sync()
             else:
                 tg, tr, tm = torch.from_numpy(grays[sl]).cuda(), torch.from_numpy(raw[sl].view(np.int16)).cuda(), torch.from_numpy(member[sl]).cuda()
                 g.fuse_resident_batch([2 * b, 2 * b + 1], tg, tr, tm, poses[sl], device=True, depth_factor=float(a))
@@ -304,7 +317,7 @@ def test_raw_depth16_batches_match_the_float_path(oracle):
                 o.fuse_map(j, grays[j], d32[j], member[j], poses[j])
             assert_surfels_close(maps[0], o.map_get(), "float path against the oracle")
         g.close()
-    for k in (1, 2):
+    for k in (1, 2, 3):
         assert maps[k].tobytes() == maps[0].tobytes(), k
         assert seeds[k].tobytes() == seeds[0].tobytes(), k
         assert np.array_equal(idx[k], idx[0]), k
