@@ -43,8 +43,9 @@ MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/) MSL_NOEXCEPT;
  * 5: deferred error code; 8-12: running totals over all keyframes since creation -- new, deleted, updated surfels, keyframes, live
  * surfels before each keyframe; 13: some record keeps wide r, g, b; 14-15: spare). */
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) MSL_NOEXCEPT;
-/* n_words 32-bit words from offset_words of one of the compaction's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list;
- * host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
+/* n_words 32-bit words from offset_words of one of the map stage's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list, 2: the screen
+ * keys the last k_fuse launch left per sub-block, 3: the wave -> sub-block dealing table, XCD-major; 4: out[0] = the grid that table is a permutation
+ * for, 0 if none; host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
  * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
 /* Mean time (us) an event pair carried by a dispatch reports for an EMPTY kernel of `grid` single-wave workgroups on the map stream (n launches):
  * the measurement overhead contained in msl_sf_profile_read's per-kernel times (rocprofv3's kernel durations do not contain it). */
@@ -59,6 +60,10 @@ MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint
  * = host / device overrides).  Frames whose node data does not fit the LDS take the host path regardless. */
 MSL_API int msl_debug_peac_cluster_on_device(int n_frames) MSL_NOEXCEPT;
 MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) MSL_NOEXCEPT;
+/* Test hook: the dealing of n_subblocks (a multiple of 8) k_fuse sub-blocks to the eight XCDs by screen key (0 .. 254: mean image row of the
+ * sub-block's in-view surfels, >= 255: nothing in view), as k_compact / k_deal build it (msl_sf_map.hip, deal_subblocks): deal[x * n / 8 + j] = the
+ * sub-block wave 8 j + x takes.  Host arrays; synchronous. */
+MSL_API int msl_debug_deal(const uint32_t *keys_host, int n_subblocks, uint32_t *deal_host) MSL_NOEXCEPT;
 /* Test hook: out[i] = the kernels' division-free evaluation of (double)(x[i]*x[i]) / 100.0 (host arrays). */
 MSL_API int msl_debug_div100(const float *x_host, double *out_host, size_t n) MSL_NOEXCEPT;
 /* Test hook: out[q] = the strictly sequential (left-to-right) float sum of the first n[q] <= 256 entries of list q (256 floats each) as the superpixel

@@ -103,6 +103,7 @@ SIGNATURES = {
     "msl_sf_debug_scratch": (_i, [_vp, _i, _sz, _vp, _sz]),
     "msl_sf_debug_event_overhead": (_i, [_vp, _i, _i, _vp]),
     "msl_debug_div100": (_i, [_vp, _vp, _sz]),
+    "msl_debug_deal": (_i, [_vp, _i, _vp]),
     "msl_debug_chain_sum": (_i, [_vp, _vp, _i, _i, _vp]),
     "msl_debug_peac_mse": (_i, [_vp, _sz, _i, _vp]),
     "msl_debug_peac_cluster_on_device": (_i, [_i]),

@@ -145,6 +145,13 @@ struct SfDev {
     long long *ctr;
     msl_surfel *newSurfels;
     unsigned *blockSums, *blockUpd, *delList, *srcOf;
+    // Dealing of the sub-blocks to the XCDs by SCREEN position (round 6; msl_sf_map.hip, deal_subblocks): every k_fuse wave leaves the screen key of
+    // its sub-block (mean image row of its in-view surfels, 0 .. 254; 255 = nothing in view) in sbKeys[]; the launch that follows k_fuse on the map
+    // stream (k_compact's second workgroup; k_deal behind a deferred window) turns them into deal[]: wave w of the next k_fuse launch takes the
+    // sub-block deal[(w & 7) * (G / 8) + (w >> 3)], so that XCD x works on the sub-blocks that project into the x-th band of image rows and its L2
+    // fetches that band of the texel map and of the seed records instead of all of them.  Hints only: any permutation of 0 .. G - 1 is correct.
+    unsigned *sbKeys, *deal;     // [blkStride] each
+    int dealG;                   // k_compact / k_deal: the grid (sub-blocks, a multiple of 8) to build deal[] for; 0 = leave it alone
     unsigned *tickets;           // [0..1] hand-off counters, [3] change-list length, [4] delUCount
     unsigned *delU;              // [LIST_D] unordered list of the slots k_fuse found deleted (fast path of k_compact)
     unsigned *delUCount;         // number of slots appended (may exceed LIST_D: then the list is incomplete and unused)
@@ -270,9 +277,10 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t st, const SfDev &P, int n
 void sp_launch_depth_u16(hipStream_t st, const void *src, size_t srcStride, size_t srcFrameStride, float *dst, size_t dstFrameStride, int W, int H, int nFrames,
                          float factor);
 // msl_sf_map.hip
-void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred);
+void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred, bool dealt);
 void map_launch_compact(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, bool resident);
 void map_launch_replay(KernelProfiler &prof, hipStream_t st, const SfDev &P, int nFrames, unsigned blkStride);   // closes a deferred window of nFrames keyframes
+void map_launch_deal(hipStream_t st, const SfDev &P);   // builds P.deal for a grid of P.dealG sub-blocks from the screen keys the last k_fuse launch left
 void map_launch_empty_pair(KernelProfiler &prof, hipStream_t st);                   // the profiler's empty-kernel event pair (SK_NEW)
 void map_launch_set_ctr(hipStream_t st, const SfDev &P, long long n, int wide);
 void map_launch_add_ctr(hipStream_t st, const SfDev &P, long long add);
@@ -283,6 +291,7 @@ void map_launch_select_write(hipStream_t st, const SfDev &P, int mode, int arg, 
 void map_launch_collect_changed(hipStream_t st, const SfDev &P, int ref, long long n, unsigned *count, unsigned *idxOut, msl_surfel *recOut, unsigned capOut);
 void map_launch_empty(hipStream_t st, int grid, hipEvent_t a, hipEvent_t b);
 int sp_debug_div100(const float *x_host, double *out_host, size_t n);
+int map_debug_deal(const uint32_t *keys_host, int G, uint32_t *deal_host);
 int sp_debug_chain(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host);
 
 }  // namespace sf

@@ -135,21 +135,10 @@ __device__ __forceinline__ unsigned lane_rank(unsigned long long m) {   // numbe
     return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
-// 16-byte stores of the records phase B rewrites.  MSL_FUSE_ST: 0 = plain (the lines stay dirty in the XCD's L2 until the kernel ends),
-// 1 = sc1 (write-through: nothing left to write back at the kernel boundary, the line leaves the L2), 2 = nt.  A/B in DESIGN.md section 6.
-#ifndef MSL_FUSE_ST
-#define MSL_FUSE_ST 0
-#endif
+// 16-byte stores of the records phase B rewrites: plain stores (the lines stay dirty in the XCD's L2 until the kernel ends).  Measured and dropped in
+// round 5 (A/B on one box): sc1 = write-through (+2.5 us per launch), nt (+0.3 us).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st16(void *p, u32x4 v) {
-#if MSL_FUSE_ST == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#elif MSL_FUSE_ST == 2
-    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-#else
-    *reinterpret_cast<u32x4 *>(p) = v;
-#endif
-}
+__device__ __forceinline__ void st16(void *p, u32x4 v) { *reinterpret_cast<u32x4 *>(p) = v; }
 
 // What k_fuse reads of the handle and of the keyframe: slim copies of SfDev / FrameDev with the slot offsets folded in on the host.  The
 // whole structs are ~150 dwords of kernel arguments = scalar registers the compiler loads up front and then spills around the hot loop;
@@ -162,21 +151,25 @@ struct FuseFrame {
 };
 struct FuseArgs {
     int W, H, nseeds, kf;          // kf: keyframe number inside a deferred window (its launch materialises the new surfels of kf - 1 first)
-    int prevSlot, _pad;            // superpixel slot of keyframe kf - 1, counted from the first slot of the handle (DeferCtl holds the array bases)
+    int prevSlot;                  // superpixel slot of keyframe kf - 1, counted from the first slot of the handle (DeferCtl holds the array bases)
+    int rowScale;                  // (254 << 16) / H: image row -> screen key 0 .. 253 of the dealing (SfDev::sbKeys)
     float fx, fy, cx, cy, fuseFar, fuseNear;
     const uint2 *tex; const float4 *fuseRec; uint8_t *fused;   // this keyframe's slot
     HotPk *hot; ColdRec *cold;
     long long *ctr;
     unsigned *blockSums, *blockUpd;   // per-sub-block deleted (classic) / updated counts (deferred: the keyframe's slice)
+    unsigned *sbKeys;              // per-sub-block screen key this launch leaves for the next dealing
+    const unsigned *deal;          // wave -> sub-block table of THIS launch (XCD-major: [w & 7][w >> 3]); nullptr: array order in runs of FUSE_CHUNK per XCD
     unsigned *delOut;              // where deleted slots go: classic delU[LIST_D] (k_compact's hand-over list), deferred the window's deletion log
     unsigned *delCount;            // ... and their count: classic delUCount, deferred DeferCtl::delCnt[kf]
     DeferCtl *dc;                  // extents and deletion counts of a deferred window; and what only a few waves per launch need (DeferCtl::aux):
                                    // side arrays of wide records, deletion lists, capacity -- loaded where they are used instead of living in scalar
                                    // registers through the whole kernel
 };
-__host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred) {
+__host__ inline FuseArgs fuse_args(const SfDev &P, int slot, bool deferred, bool dealt = false) {
     FuseArgs A;
-    A.W = P.W; A.H = P.H; A.nseeds = P.nseeds; A.kf = P.kf; A.prevSlot = P.prevSlotAbs; A._pad = 0;
+    A.W = P.W; A.H = P.H; A.nseeds = P.nseeds; A.kf = P.kf; A.prevSlot = P.prevSlotAbs; A.rowScale = (254 << 16) / P.H;
+    A.sbKeys = P.sbKeys; A.deal = dealt ? P.deal : nullptr;
     A.fx = P.fx; A.fy = P.fy; A.cx = P.cx; A.cy = P.cy; A.fuseFar = P.fuseFar; A.fuseNear = P.fuseNear;
     A.tex = P.tex + (size_t)slot * P.pxStride; A.fuseRec = P.fuseRec + (size_t)slot * P.nseeds * 3; A.fused = P.fused + (size_t)slot * P.flagStride;
     A.hot = P.map.hot; A.cold = P.map.cold; A.ctr = P.ctr;
@@ -337,11 +330,25 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
 #define MSL_FUSE_CHUNK 16
 #endif
     constexpr unsigned FUSE_CHUNK = MSL_FUSE_CHUNK;
-    long long lin = waveIdx;
-    {
+    // Round 6: when the launch before left screen keys, the sub-blocks are DEALT by screen position instead (P.deal, built by deal_subblocks below):
+    // XCD x gets the sub-blocks whose in-view surfels project into the x-th band of image rows, top to bottom, then its share of the sub-blocks
+    // with nothing in view -- its L2 then fetches one band of the texel map and of the seed records, not the whole screen (every XCD fetching the
+    // whole 2.46 MB texel map was a third of the kernel's fabric traffic).  One scalar load on the head of the wave's chain.
+    long long sb0;
+    if (!spawnWave && P.deal != nullptr) {
+        const unsigned gs = (unsigned)G >> 3;   // (G is a multiple of 8 whenever a table is handed over)
+        // (a scalar load by hand: the compiler cannot prove that no store of the kernel aliases the table and would fetch the wave-uniform word
+        // through the vector cache; the launch before wrote it, and the scalar cache is invalidated at every kernel start)
+        const unsigned *dp = P.deal + ((waveIdx & 7u) * gs + (waveIdx >> 3));
+        unsigned dv;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dv) : "s"(dp) : "memory");
+        sb0 = (long long)dv;
+    } else {
+        long long lin = waveIdx;
         constexpr unsigned T = 8u * FUSE_CHUNK;
         const unsigned full = ((unsigned)G / T) * T;
         if (waveIdx < full) { const unsigned grp = waveIdx / T, r = waveIdx % T; lin = (long long)grp * T + (r & 7u) * FUSE_CHUNK + (r >> 3); }
+        sb0 = (long long)G - 1 - lin;
     }
     for (long long it = 0;; it++) {
         // (the lane number is re-materialised per iteration: values derived from it are then not hoisted out of this -- normally single-trip --
@@ -349,7 +356,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
         unsigned lane = lane0;
         asm volatile("" : "+v"(lane));
 #define REC_LOCAL(k) (64u * (unsigned)(k) + lane)
-        const long long sb = (long long)G - 1 - lin + it * G;   // regular waves: the sub-block; grid-stride should the map have outgrown the grid
+        const long long sb = sb0 + it * G;   // regular waves: the sub-block; grid-stride should the map have outgrown the grid
         long long c0, n = 0, cntIdx;
         if (DEFER && spawnWave) {
             c0 = E0 + it * WSPAN;
@@ -382,6 +389,7 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             n = E0;
         }
         unsigned stp = 0;  // two bits per record: 0: nothing to do, 1: stale -> delete, 2: already deleted, 3: in view
+        unsigned keyAcc = 0;   // bits 0..15: sum of the screen keys (image row scaled to 0 .. 253) of the lane's in-view records, bits 16..: their number
         float pzv[KPL];
         unsigned offT[KPL];
         // rare: a record with exact ints in the side array, or a slot the window has logged already -- ONE test for the lane's four records
@@ -417,15 +425,11 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
                 const float projectU = pc[0] * P.fx / zq + P.cx, projectV = pc[1] * P.fy / zq + P.cy;  // :75-78
                 const int pUInt = round_half_up_pixel(projectU), pVInt = round_half_up_pixel(projectV);   // int(projectU + 0.5) wherever it matters
                 const bool inImage = !(pUInt < 1 || pUInt > P.W - 2 || pVInt < 1 || pVInt > P.H - 2);
-                if (cand && inImage) st = 3;
-#ifdef MSL_FUSE_TEXCLAMP   // (round 4 / early round 5: every record gathers a texel, records outside the view the border texel nearest to their projection)
-                const int pUc = min(max(pUInt, 0), P.W - 1), pVc = min(max(pVInt, 0), P.H - 1);   // always a valid address
-                off = (unsigned)(pVc * P.W + pUc);
-#else
+                if (cand && inImage) { st = 3; keyAcc += (((unsigned)pVInt * (unsigned)P.rowScale) >> 16) | 0x10000u; }
                 // a record that is not in view needs no texel: all such lanes read texel 0 (ONE line for the whole wave) instead of up to 64 scattered
-                // border texels -- two thirds of the dense map's records, each a separate request to the vector cache
+                // border texels -- two thirds of the dense map's records, each a separate request to the vector cache (round 4 clamped the address
+                // to the border texel nearest to the projection)
                 off = st == 3 ? (unsigned)(pVInt * P.W + pUInt) : 0u;
-#endif
             }
             stp |= (unsigned)st << (2 * k); pzv[k] = pc[2];
             offT[k] = off;
@@ -438,6 +442,14 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
             // round trip back into up to four dependent ones
             if constexpr (KPL == 4) asm volatile("" ::"v"(tx[0].x), "v"(tx[1].x), "v"(tx[2].x), "v"(tx[3].x), "v"(tx[0].y), "v"(tx[1].y), "v"(tx[2].y), "v"(tx[3].y));
             else asm volatile("" ::"v"(tx[0].x), "v"(tx[KPL - 1].x), "v"(tx[0].y), "v"(tx[KPL - 1].y));
+        }
+        // the sub-block's screen key for the next dealing: mean row of its in-view records (255: nothing in view) -- stored here, before phase B,
+        // so that nothing of it stays live through the gathers (a hint: the approximate reciprocal is good enough)
+        if (!(DEFER && spawnWave)) {
+            const unsigned ks = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan(keyAcc), 63);
+            const unsigned kc = ks >> 16;
+            const unsigned key = kc ? min((unsigned)((float)(ks & 0xFFFFu) * __builtin_amdgcn_rcpf((float)kc)), 254u) : 255u;
+            if (lane == 0) P.sbKeys[cntIdx] = key;
         }
         // ---- classification: deletions of phase A, survivors ----
         // (one bit field per lane instead of eight lane masks: the masks would live in scalar registers, which this kernel is short of)
@@ -611,7 +623,139 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (DEFER) {
         if (blockIdx.x == 0) fuse_body<DEFER, true>(P, F, nSubHint, 0u, (int)gridDim.x - 1);   // workgroup 0: the spawn wave (its own instantiation: what it
         else fuse_body<DEFER, false>(P, F, nSubHint, blockIdx.x - 1u, (int)gridDim.x - 1);     // carries through the loop costs the other waves no register)
-    } else fuse_body<false, false>(P, F, nSubHint, blockIdx.x, (int)gridDim.x);
+    } else {
+        fuse_body<false, false>(P, F, nSubHint, blockIdx.x, (int)gridDim.x);
+    }
+}
+
+// ---- dealing the sub-blocks to the XCDs by screen position (round 6) ----------------------------------------------------------------------
+// Workgroup g of a launch runs on XCD g % 8, and every XCD has its own L2.  With the sub-blocks handed out in ARRAY order every XCD's waves
+// project all over the screen: each of the eight L2s fetched the whole texel map (2.46 MB) and all seed records of the keyframe -- about 17 of
+// the 52 MB k_fuse read per launch (round 5 counters).  Array neighbours do project to neighbouring pixels (creation order = superpixel
+// raster order of the source keyframe), so a sub-block's in-view surfels cover a narrow band of image rows; k_fuse leaves that band's mean row
+// as the sub-block's screen key, and this pass -- one workgroup beside the compaction, one launch behind the fusion that measured the keys --
+// sorts the sub-blocks by key and cuts the list into eight equal runs: XCD x gets the x-th run (adaptive bands: equal numbers of in-view
+// sub-blocks whatever the distribution of the rows), in row order, followed by its share of the sub-blocks with nothing in view, so that
+// every XCD runs exactly G / 8 waves and the heavy ones are dispatched first.  Counting sort on the 255 key values in the LDS.
+// The table is a hint: whatever the keys are, deal[] is a permutation of 0 .. G - 1 (G a multiple of 8).
+template <int NT>
+__device__ __forceinline__ void deal_subblocks(const unsigned *keys, int G, unsigned *deal, unsigned *s_hist, unsigned *s_off, unsigned *s_wave, unsigned *s_aux) {
+    static_assert(NT == 256, "one histogram bin per thread");
+    // Thread t owns the 32 consecutive sub-blocks [base + 32 t, base + 32 t + 32) of a chunk of 8192 (a map of 1 M surfels is one chunk): their keys
+    // arrive as eight 16-byte loads issued together and are packed to one byte each.  The two passes walk the eight registers in ROLLED loops (the
+    // group is rotated by one register per step and is itself again after eight) -- four waves that run alone on their SIMDs pay every dependent LDS
+    // round trip and every instruction (4 cycles each) in full, so: no returning atomic in pass 1, four in flight per step in pass 2 together with
+    // the per-key table word that says where the key's ranks go, and the sub-blocks with nothing in view (a third to two thirds of the map, all
+    // in bin 255) are ranked by prefix sums instead of atomics.  (Round 6 history: straight-line code for 32 keys per thread was 40 KB of
+    // instructions executed once -- 15 us beside the compaction's 8; one key per loop trip with two dependent LDS round trips each -- 18 us; a
+    // seven-compare search for the XCD of every rank -- 12 us.)
+    const unsigned t = threadIdx.x;
+    constexpr int CH = 32 * NT;
+    auto load_pack = [&](int base, unsigned (&kp)[8]) {
+        uint4 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) v[q] = *reinterpret_cast<const uint4 *>(keys + base + 32 * (int)t + 4 * q);   // (the key plane is padded by > 8192 entries)
+#pragma unroll
+        for (int q = 0; q < 8; q++) kp[q] = min(v[q].x, 255u) | (min(v[q].y, 255u) << 8) | (min(v[q].z, 255u) << 16) | (min(v[q].w, 255u) << 24);
+    };
+    auto next_word = [&](unsigned (&kp)[8]) -> unsigned {   // the group's first register; the group rotated by one
+        const unsigned w = kp[0];
+#pragma unroll
+        for (int q = 0; q < 7; q++) kp[q] = kp[q + 1];
+        kp[7] = w;
+        return w;
+    };
+    // pass 1 over a chunk: histogram of the in-view keys; returns the thread's number of sub-blocks with nothing in view
+    auto count_chunk = [&](int base, unsigned (&kp)[8], bool hist) -> unsigned {
+        unsigned fc = 0;
+#pragma unroll 1
+        for (int d = 0; d < 8; d++) {
+            const unsigned w = next_word(kp);
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned key = (w >> (8 * b)) & 255u;
+                const bool in = base + 32 * (int)t + 4 * d + b < G;
+                if (hist && in && key != 255u) atomicAdd(&s_hist[key], 1u);
+                fc += in && key == 255u ? 1u : 0u;
+            }
+        }
+        return fc;
+    };
+    unsigned k0[8];
+    load_pack(0, k0);
+    s_hist[t] = 0;
+    __syncthreads();
+    const unsigned fc0 = count_chunk(0, k0, true);
+    for (int base = CH; base < G; base += CH) { unsigned kc[8]; load_pack(base, kc); (void)count_chunk(base, kc, true); }
+    __syncthreads();
+    // in-view rank r -> XCD x = floor(8 r / NI): the ranks [inS(x), inS(x + 1)); the fillers take what is left of each XCD's G / 8 waves: XCD x the
+    // filler ranks [outS(x), outS(x + 1)), outS(x) = x G / 8 - inS(x)
+    unsigned NI, fTot0, ex, fb0;   // NI: sub-blocks with something in view
+    block_excl_scan_pair(t < 255u ? s_hist[t] : 0u, fc0, s_wave, &NI, &fTot0, ex, fb0);
+    const unsigned gs = (unsigned)G >> 3;
+    auto inS = [&](unsigned x) { return (x * NI + 7u) >> 3; };
+    auto outS = [&](unsigned x) { return x * gs - inS(x); };
+    {   // per key: the XCD its first rank falls into and how many more ranks fit there (nearly always all of the bin's); the running rank of the
+        // bin counts from that XCD's start, so an atomic's return value IS the place in the XCD's run
+        unsigned x0 = 0;
+#pragma unroll
+        for (unsigned y = 1; y < 8; y++) x0 += ex >= inS(y) ? 1u : 0u;
+        s_off[t] = ex - inS(x0);
+        s_hist[t] = x0 | ((inS(x0 + 1) - inS(x0)) << 3);
+        if (t < 9) s_aux[t] = inS(t);   // (a rank that crosses into the next XCD's run looks its bounds up here)
+    }
+    __syncthreads();
+    unsigned fillBase = 0;
+    auto place_chunk = [&](int base, unsigned (&kp)[8], unsigned fb, unsigned ftot) {   // fb: the rank of the thread's first filler inside the chunk (array order)
+        fb += fillBase;
+        fillBase += ftot;
+        unsigned xf = 0;
+#pragma unroll
+        for (unsigned y = 1; y < 8; y++) xf += fb >= outS(y) ? 1u : 0u;
+        unsigned jf = (inS(xf + 1) - inS(xf)) + (fb - outS(xf));
+#pragma unroll 1
+        for (int d = 0; d < 8; d++) {
+            const unsigned w = next_word(kp);
+            unsigned rr[4], tb[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const unsigned key = (w >> (8 * b)) & 255u;
+                rr[b] = 0; tb[b] = 0;
+                if (base + 32 * (int)t + 4 * d + b < G && key != 255u) { rr[b] = atomicAdd(&s_off[key], 1u); tb[b] = s_hist[key]; }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                // branch-free: the place of an in-view sub-block (its rank inside the XCD the key's table word names) or of a filler (the thread's
+                // running filler place) selected per lane; only a rank that crosses into the next XCD's run -- rare -- takes a (wave-level) slow path.
+                // (With a divergent branch per kind every step ran both sides one after the other: 6 us for this pass.)
+                const unsigned key = (w >> (8 * b)) & 255u;
+                const int sb = base + 32 * (int)t + 4 * d + b;
+                const bool in = sb < G, iv = in && key != 255u, fl = in && key == 255u;
+                unsigned x = tb[b] & 7u, room = tb[b] >> 3, j = rr[b];
+                if (__builtin_expect(__ballot((iv && j >= room) || (fl && jf >= gs)) != 0ull, 0)) {
+                    if (iv) while (j >= room) { j -= room; x++; room = s_aux[x + 1] - s_aux[x]; }      // the bin straddles two XCDs' runs
+                    if (fl) while (jf >= gs) { xf++; jf = s_aux[xf + 1] - s_aux[xf]; }                  // this XCD's run is full: on to the next one with room for fillers
+                }
+                const unsigned at = (iv ? x : xf) * gs + (iv ? j : jf);
+                if (in) deal[at] = (unsigned)sb;
+                jf += fl ? 1u : 0u;
+            }
+        }
+    };
+    place_chunk(0, k0, fb0, fTot0);
+    for (int base = CH; base < G; base += CH) {
+        unsigned kc[8];
+        load_pack(base, kc);
+        const unsigned fc = count_chunk(base, kc, false);
+        unsigned ftot;
+        const unsigned fb = block_excl_scan(fc, s_wave, &ftot);
+        place_chunk(base, kc, fb, ftot);
+    }
+    __syncthreads();   // (the caller reuses the LDS arrays)
+}
+__global__ __launch_bounds__(256) void k_deal(const unsigned *keys, int G, unsigned *deal) {
+    __shared__ unsigned s_hist[256], s_off[256], s_wave[33], s_aux[16];
+    deal_subblocks<256>(keys, G, deal, s_hist, s_off, s_wave, s_aux);
 }
 
 constexpr int TAIL_MAX_HOPS = 64;   // relay hops resolved per hole before the literal loop takes over (k_compact)
@@ -646,6 +790,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     __builtin_amdgcn_s_setprio(3);   // latency-critical serial chain next to the throughput-oriented batched kernels
     // Steady state (k_fuse handed over <= LIST_D deleted slots): workgroup 0 does everything alone; the others leave after one load
     // instead of fetching the partials and flags as well.
+    // (round 6) the second workgroup first deals the sub-blocks for the next fuse launch from the screen keys this keyframe's launch left
+    // (deal_subblocks above) -- beside workgroup 0's compaction, not behind it
+    if (mode == 0 && blockIdx.x == 1 && P.dealG > 0) deal_subblocks<NT>(P.sbKeys, P.dealG, P.deal, s_raw, s_dl, s_wave, s_nzIdx);
     if (mode == 0 && blockIdx.x != 0 && *P.delUCount <= LIST_D) return;
     // Loads that do not depend on anything are issued first; in particular every workgroup already fetches the seed flags
     // the continuation needs, so the continuing workgroup does not start its dependent chain with a cold memory round trip.
@@ -1377,8 +1524,35 @@ __global__ void k_empty(int grid_dummy) { (void)grid_dummy; }
 namespace msl {
 namespace sf {
 
-void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred) {
-    const FuseArgs A = fuse_args(P, slot, deferred);
+void map_launch_deal(hipStream_t st, const SfDev &P) { hipLaunchKernelGGL(k_deal, dim3(1), dim3(256), 0, st, P.sbKeys, P.dealG, P.deal); }
+// Test hook: the dealing of G sub-blocks (a multiple of 8) with the given screen keys, host arrays, synchronous.
+int map_debug_deal(const uint32_t *keys_host, int G, uint32_t *deal_host) {
+    if (!keys_host || !deal_host || G < 8 || (G & 7)) return MSL_ERR_INVALID;
+    unsigned *dk = nullptr, *dd = nullptr;
+    const size_t pad = (size_t)G + 8192;   // the key plane of a handle is padded the same way (whole chunks are loaded)
+    MSL_HIP_TRY(hipMalloc(&dk, sizeof(unsigned) * pad)); MSL_HIP_TRY(hipMalloc(&dd, sizeof(unsigned) * (G + 64)));
+    MSL_HIP_TRY(hipMemset(dk, 0xFF, sizeof(unsigned) * pad)); MSL_HIP_TRY(hipMemset(dd, 0xFF, sizeof(unsigned) * G));
+    MSL_HIP_TRY(hipMemcpy(dk, keys_host, sizeof(unsigned) * G, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_deal, dim3(1), dim3(256), 0, 0, dk, G, dd);
+    MSL_HIP_TRY(hipMemcpy(deal_host, dd, sizeof(unsigned) * G, hipMemcpyDeviceToHost));
+    if (const char *reps = getenv("MSL_DEAL_REPS")) {   // experiment: mean time of the dealing kernel alone (HIP events around back-to-back launches)
+        const int n = atoi(reps);
+        hipEvent_t a, b;
+        MSL_HIP_TRY(hipEventCreate(&a)); MSL_HIP_TRY(hipEventCreate(&b));
+        for (int w = 0; w < 20; w++) hipLaunchKernelGGL(k_deal, dim3(1), dim3(256), 0, 0, dk, G, dd);
+        MSL_HIP_TRY(hipEventRecord(a, 0));
+        for (int i = 0; i < n; i++) hipLaunchKernelGGL(k_deal, dim3(1), dim3(256), 0, 0, dk, G, dd);
+        MSL_HIP_TRY(hipEventRecord(b, 0));
+        MSL_HIP_TRY(hipEventSynchronize(b));
+        float ms = 0; MSL_HIP_TRY(hipEventElapsedTime(&ms, a, b));
+        fprintf(stderr, "k_deal G=%d: %.2f us per launch (back to back, %d launches)\n", G, ms * 1e3f / n, n);
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+    (void)hipFree(dk); (void)hipFree(dd);
+    return MSL_OK;
+}
+void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, const FrameDev &F, int nSubGrid, int nSubHint, bool deferred, bool dealt) {
+    const FuseArgs A = fuse_args(P, slot, deferred, dealt);
     const FuseFrame FF = fuse_frame(F, P.frames + slot);
     if (deferred) MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<true>, dim3((unsigned)nSubGrid + 1u), dim3(64), A, FF, nSubHint);
     else MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<false>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);

@@ -32,6 +32,7 @@ struct msl_sf {
     int maxBatch = 1;              // keyframes per batch; slots = 2 * maxBatch (double-buffered sets)
     hipStream_t preStream = nullptr, mapStream = nullptr; bool ownStreams = true;
     size_t blkStride = 0;          // entries per per-sub-block count slice (blockSums: one slice; blockUpd: DEFER_WIN slices, one per keyframe of a window)
+    int dealG = 0;                 // the k_fuse grid SfDev::deal currently is a permutation for (0: none yet) -- screen-position dealing, msl_sf_map.hip
     hipStream_t copyStream = nullptr;   // host-image mode: the H2D copies of slot set i + 1 run beside the superpixel kernels of set i
     hipEvent_t evH2D[2] = {nullptr, nullptr};
     hipEvent_t evPre[2] = {nullptr, nullptr}, evMap[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
@@ -100,6 +101,7 @@ void set_map_ptrs(msl_sf *h) {
     SfDev &D = h->dev;
     D.cap = c;
     D.blockSums = h->d_blockSums; D.blockUpd = h->d_blockUpd; D.delList = h->d_delList; D.srcOf = h->d_srcOf;
+    D.sbKeys = h->d_blockSums + h->blkStride; D.deal = h->d_blockSums + 2 * h->blkStride; D.dealG = 0;   // (three planes of one allocation: counts, screen keys, dealing table)
     unsigned *r = h->d_rpStore;
     D.loc64 = reinterpret_cast<unsigned long long *>(r);            // (first: 8-byte aligned)
     D.stageCold = reinterpret_cast<ColdRec *>(r + 2 * c);
@@ -142,9 +144,10 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     const size_t bst = cap / SUB_ITEMS + 8200;   // per slice; >= 1024 / 8192 padding entries: the compaction reads its first tiles unconditionally
     auto attempt = [&]() -> int {
         MSL_HIP_TRY(hipMalloc(&nstore, sizeof(float) * MAP_WORDS * cap));
-        MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * bst));
+        MSL_HIP_TRY(hipMalloc(&nbs, sizeof(unsigned) * 3 * bst));           // deleted counts | screen keys | dealing table (SfDev::sbKeys, ::deal)
         MSL_HIP_TRY(hipMalloc(&nbu, sizeof(unsigned) * DEFER_WIN * bst));   // one slice per keyframe of a deferred window (classic: the first)
         MSL_HIP_TRY(hipMemset(nbs, 0, sizeof(unsigned) * bst));
+        MSL_HIP_TRY(hipMemset(nbs + bst, 0xFF, sizeof(unsigned) * bst));    // no key yet: "nothing in view"
         MSL_HIP_TRY(hipMemset(nbu, 0, sizeof(unsigned) * DEFER_WIN * bst));
         MSL_HIP_TRY(hipMalloc(&ndl, sizeof(unsigned) * cap));
         MSL_HIP_TRY(hipMalloc(&nso, sizeof(unsigned) * cap));
@@ -179,6 +182,7 @@ int map_realloc(msl_sf *h, size_t cap, size_t keep) {
     }
     h->d_mapStore = nstore; h->d_blockSums = nbs; h->d_blockUpd = nbu; h->d_delList = ndl; h->d_srcOf = nso; h->d_rpStore = nrp; h->mapCap = cap;
     h->blkStride = bst;
+    h->dealG = 0;              // (the dealing table went with the old allocation)
     set_map_ptrs(h);
     return write_ctl(h);
 }
@@ -415,8 +419,14 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     // grid: the last known live count plus a margin (k_fuse is grid-stride, so a map that outgrew it is still covered), never beyond the upper
     // bound; hint: the sub-blocks that were full at the last known count load without waiting for the live count
     const size_t known = std::min(h->liveKnown, boundLive);
-    const int nSubGrid = (int)std::max<size_t>(1, (std::min(known + 2 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS);
+    // (round 6) ... rounded up to a multiple of 64 sub-blocks inside the capacity (a multiple of 32 sub-blocks): the dealing table of the launch before is
+    // a permutation for ONE grid size, so the grid should change rarely -- a wave beyond the live count costs one load
+    const size_t subWant = (std::min(known + 2 * (size_t)D.nseeds, boundLive) + SUB_ITEMS - 1) / SUB_ITEMS;
+    const int nSubGrid = (int)std::max<size_t>(8, std::min((subWant + 63) & ~(size_t)63, (size_t)D.cap / SUB_ITEMS));
     const int nSubHint = (int)(known / SUB_ITEMS);
+    static const int DEAL_EVERY = getenv("MSL_SF_DEAL_EVERY") ? std::max(1, atoi(getenv("MSL_SF_DEAL_EVERY"))) : 4;
+    static const char *dealEnv = getenv("MSL_SF_DEAL");   // "0": sub-blocks in array order (rounds 1-5), for A/B measurements
+    const bool dealOn = !(dealEnv && !strcmp(dealEnv, "0")) && (nSubGrid & 7) == 0 && (size_t)nSubGrid <= h->blkStride;
     // Map stage.  Deferred compaction (the default for resident batches; MSL_SF_DEFER=0 turns it off): windows of <= DEFER_WIN keyframes, ONE
     // launch per keyframe, the window's compactions replayed at its end (msl_sf_map.hip).  Classic (k_fuse + k_compact per keyframe): single
     // keyframes, the host-vector drop-in, the first keyframe after the map was replaced from outside, and batches enqueued while the recent
@@ -433,8 +443,14 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     const bool churny = !deferForce && (h->churn > CHURN_MAX || sp != sm);
     auto classic = [&](int f) {
         P.kf = 0;
-        map_launch_fuse(h->prof, sm, P, f, h->h_frames[slot0 + f], nSubGrid, nSubHint, false);
+        map_launch_fuse(h->prof, sm, P, f, h->h_frames[slot0 + f], nSubGrid, nSubHint, false, dealOn && h->dealG == nSubGrid);
+        // k_compact's second workgroup deals the sub-blocks for the launches that follow (resident mode: 128 workgroups) -- on every DEAL_EVERY-th
+        // keyframe of a call and whenever the table does not fit the grid: the pass takes one workgroup ~10 us against the compaction's ~6 beside it
+        // (32 keys per thread through LDS atomics and scattered stores), and a table a few keyframes old still has nearly every sub-block in the
+        // right band (the view moves a fraction of a band per keyframe; a misplaced sub-block only costs its XCD some extra lines)
+        P.dealG = dealOn && compact && (f % DEAL_EVERY == 0 || h->dealG != nSubGrid) ? nSubGrid : 0;
         map_launch_compact(h->prof, sm, P, f, compact);
+        if (P.dealG) h->dealG = nSubGrid;
     };
     int f = 0;
     const int fProbe = n / 2;   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
@@ -446,11 +462,12 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             const int w = std::min(DEFER_WIN, n - f);
             for (int q = 0; q < w; q++) {
                 P.kf = q; P.prevSlotAbs = slot0 + f + q - 1;
-                map_launch_fuse(h->prof, sm, P, f + q, h->h_frames[slot0 + f + q], nSubGrid, nSubHint, true);
+                map_launch_fuse(h->prof, sm, P, f + q, h->h_frames[slot0 + f + q], nSubGrid, nSubHint, true, dealOn && h->dealG == nSubGrid);
                 if (f + q == fProbe) map_launch_empty_pair(h->prof, sm);
             }
             P.kf = w; P.prevSlotAbs = slot0 + f + w - 1;
             map_launch_replay(h->prof, sm, P, w, (unsigned)h->blkStride);
+            if (dealOn) { P.dealG = nSubGrid; map_launch_deal(sm, P); h->dealG = nSubGrid; }   // one dealing per window, from the keys of its last keyframe
             f += w;
         }
     }
@@ -1005,11 +1022,18 @@ int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) noexcept {
 }
 int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words) noexcept {
     try {
-    if (!h || !out || which < 0 || which > 1 || offset_words + n_words > h->mapCap) return MSL_ERR_INVALID;
+    if (!h || !out || which < 0 || which > 4) return MSL_ERR_INVALID;
+    if (which == 4) {   // the grid the dealing table currently is a permutation for (host state; 0: none)
+        if (n_words < 1) return MSL_ERR_INVALID;
+        out[0] = (uint32_t)h->dealG;
+        return MSL_OK;
+    }
+    if (offset_words + n_words > (which < 2 ? h->mapCap : h->blkStride)) return MSL_ERR_INVALID;
     MSL_HIP_TRY(hipSetDevice(h->device));
     int rc = sync_all(h);
     if (rc != MSL_OK) return rc;
-    MSL_HIP_TRY(hipMemcpy(out, (which == 0 ? h->d_srcOf : h->d_delList) + offset_words, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
+    const uint32_t *src = which == 0 ? h->d_srcOf : which == 1 ? h->d_delList : which == 2 ? h->dev.sbKeys : h->dev.deal;
+    MSL_HIP_TRY(hipMemcpy(out, src + offset_words, sizeof(uint32_t) * n_words, hipMemcpyDeviceToHost));
     return MSL_OK;
     } MSL_ABI_CATCH_INT
 }
@@ -1076,6 +1100,7 @@ int msl_sf_profile_read(msl_sf *h, float *ms, int32_t *launches) noexcept {
     return MSL_OK;
     } MSL_ABI_CATCH_INT
 }
+int msl_debug_deal(const uint32_t *keys_host, int n_subblocks, uint32_t *deal_host) noexcept { try { return map_debug_deal(keys_host, n_subblocks, deal_host); } MSL_ABI_CATCH_INT }
 int msl_debug_div100(const float *x_host, double *out_host, size_t n) noexcept { try { return sp_debug_div100(x_host, out_host, n); } MSL_ABI_CATCH_INT }
 int msl_debug_chain_sum(const float *x_host, const int32_t *n_host, int lists, int huber, float *out_host) noexcept { try { return sp_debug_chain(x_host, n_host, lists, huber, out_host); } MSL_ABI_CATCH_INT }
 const char *msl_sf_kernel_name(int k) noexcept { try { return (k >= 0 && k < MSL_SF_NKERNELS) ? kSfNames[k] : ""; } MSL_ABI_CATCH_PTR }
