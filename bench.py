@@ -97,6 +97,8 @@ def parse(argv=None):
     ap.add_argument("--scene", default=None, choices=["room", "clutter"], help="depth / membership content: the bare box room or the furnished room (config 4's default)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the single-thread CPU-baseline sample (0 = no CPU baseline)")
     ap.add_argument("--no-breakdown", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true", help="skip the parity gate behind the timed region (profiler passes: its few launches would enter the per-kernel "
+                    "averages); the default line carries it and bench.py exits non-zero when it fails")
     ap.add_argument("--dry-run", action="store_true", help="launcher / aggregation / device-binding check on CPU (gloo), no GPU work, fabricated timings")
     return ap.parse_args(argv)
 
@@ -199,6 +201,63 @@ def cpu_baseline(args, cfg, W, H, kfe):
         if k in res:
             out[k] = res[k]
     return out
+
+
+GATE_FRAMES = 4       # ORB frames / keyframes the parity gate checks against the oracle after the timed region
+
+
+def parity_gate(args, q, cfg, W, H, intr, kfe, B, nkf, local_rank):
+    """SURVEY.md 8(d), last row ("parity gates in the same run"): after the timed region, GATE_FRAMES frames of this sequence's own workload go
+    through the same handles once more -- ORB of its first frames; the pre-seeded map put back and its first keyframes fused (same call shape as
+    the timed passes: device-resident inputs, batched call) -- and the results are checked against the CPU oracle in the cpu_baseline interpreter
+    (tools/cpu_baseline.py --parity-gate; the only place bench.py meets oracle/).  Returns the checker's verdict; main() exits non-zero if it is not ok."""
+    import tempfile
+    import torch
+    do_orb, do_sf = cfg["orb"], cfg["sf"]
+    data = {"size": np.array([W, H], np.int32), "intr": np.array([intr["fx"], intr["fy"], intr["cx"], intr["cy"]], np.float64)}
+    n = min(GATE_FRAMES, len(q.grays))
+    if do_orb:
+        cap = q.orb.capacity
+        q.orb.extract_batch_device(q.d_gray, q.d_kps, q.d_desc, q.d_n, n, W, H)
+        q.orb.sync()
+        data["orb_gray"] = q.grays[:n]
+        data["orb_n"] = q.d_n[:n].cpu().numpy()
+        data["orb_kps"] = q.d_kps[:n * cap * 28].cpu().numpy().reshape(n, cap * 28)
+        data["orb_desc"] = q.d_desc[:n * cap * 32].cpu().numpy().reshape(n, cap * 32)
+    if do_sf:
+        nk = min(GATE_FRAMES, nkf)
+        q.sf.sync()
+        q.sf.map_restore()
+        refs = np.arange(nk)
+        use_peac = bool(cfg.get("peac"))
+        if use_peac:
+            if q.peac_dev[0] is None:
+                q.sub_sf(0); q.sf.sync(); q.sf.map_restore()          # (a dry call that fetches the plane membership of this pass's keyframes)
+            member_d, member_h, shared = q.peac_dev[0][:nk], q.peac_dev[0][:nk].cpu().numpy(), False
+        else:
+            member_d, member_h, shared = q.d_member, q.member[None], True
+        q.sf.fuse_resident_batch(refs, q.d_gray, q.d_depth, member_d, q.kf_poses[0][:nk], device=True, member_shared=shared, frame_step=kfe,
+                                 **({"member_frame_step": 1} if use_peac else {}))
+        q.sf.sync()
+        D = len(q.grays)
+        fr = [(j * kfe) % D for j in range(nk)]
+        data.update(sf_map0=q.smap.view(np.uint8).reshape(len(q.smap), -1), sf_map_gpu=q.sf.map_download().view(np.uint8).reshape(-1, q.smap.dtype.itemsize),
+                    sf_refs=refs, sf_gray=q.grays[fr], sf_depth=q.depths[fr], sf_member=member_h, sf_poses=np.stack([np.asarray(p, np.float32).reshape(16) for p in q.kf_poses[0][:nk]]))
+        q.sf.map_restore()
+        q.kf_no[0] = 0
+    fd, path = tempfile.mkstemp(prefix=f"msl_gate_{local_rank}_", suffix=".npz", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    os.close(fd)
+    try:
+        np.savez(path, **data)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--parity-gate", path], capture_output=True, text=True, timeout=600)
+        try:
+            res = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001
+            res = {"ok": False, "failures": [f"parity checker failed to run: rc {r.returncode}, {r.stderr[-400:]!r}"]}
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+    return res
 
 
 def geometry(args):
@@ -467,10 +526,20 @@ def main():
     frames_rank = args.steps * P * F * S
     counters = [frames_rank, n_kp_pass * args.steps * P, ctr["n_live_after"], ctr["n_new"], ctr["n_updated"], ctr["n_deleted"], int(local_ms * 1e6), n_live_start]
     total_ms, gathered = aggregate(local_ms, counters, world, dev)
+    # parity gate (outside the timed region): every rank checks its own sequence; the verdicts travel like the counters
+    gate = None
+    if not args.no_parity_gate:
+        gate = parity_gate(args, q0, cfg, W, H, intr, kfe, B, nkf, local_rank)
+        _, gate_all = aggregate(0.0, [1 if gate.get("ok") else 0, int(gate.get("orb_frames", 0)), int(gate.get("keyframes", 0)), int(1e12 * float(gate.get("max_abs", 0.0)))], world, dev)
+        gate["ok_all_ranks"] = all(g[0] == 1 for g in gate_all)
+        gate["per_rank_ok"] = [bool(g[0]) for g in gate_all]
+        gate["max_abs_all_ranks"] = max(g[3] for g in gate_all) * 1e-12
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
+        if gate is not None and not gate.get("ok"):
+            raise SystemExit(3)
         return
 
     frames_total = frames_rank * world
@@ -542,6 +611,7 @@ def main():
                               "read_write": {"achieved": round((r_frame + w_frame) * fps_gpu / 1e9, 1),
                                              "frac": round((r_frame + w_frame) * fps_gpu / 1e9 / HBM_PEAK_GBS, 4)}},
         "counters_per_rank": gathered,
+        "parity_gate": gate,
     }
 
     if args.io == "host" and world == 1:
@@ -604,6 +674,8 @@ def main():
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if gate is not None and not gate.get("ok_all_ranks", gate.get("ok")):
+        raise SystemExit(3)   # results differ from the oracle's: the line above says where (parity_gate.failures); no headline without parity
 
 
 def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F, P, B, D, device, resident_value):

@@ -7,7 +7,7 @@ i=0
 while read -r GROUP; do
   [ -z "$GROUP" ] && continue
   i=$((i+1))
-  timeout 70 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT/g$i -o p -- python $R/bench.py --config 3 --cpu-frames 0 --no-breakdown --steps 1 --warmup 1 --passes-per-step 1 > $OUT/g$i.log 2>&1
+  timeout 70 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT/g$i -o p -- python $R/bench.py --config 3 --cpu-frames 0 --no-breakdown --no-parity-gate --steps 1 --warmup 1 --passes-per-step 1 > $OUT/g$i.log 2>&1
   echo "group $i rc=$?"
 done <<'EOG'
 TCC_REQ TCC_HIT TCC_MISS TCC_READ

@@ -62,6 +62,65 @@ def run_sequence(inp, W, H, n_frames, do_orb=True, do_sf=True, threads10=False, 
     return t_begin, time.perf_counter(), t_orb, t_sf, n_kf
 
 
+def parity_gate(path):
+    """SURVEY.md 8(d), last row: the checker half of bench.py's parity gate.  `path` is an .npz bench.py wrote after its timed region: the inputs of
+    a few frames / keyframes of the run's OWN workload and what the HIP library made of them (keypoints + descriptors per frame; the resident map
+    after the keyframes, starting from the pre-seeded map).  The oracle processes the same inputs; ORB must agree byte for byte (count, every
+    cv::KeyPoint field, order, 32 descriptor bytes), the map in length, order and integer fields exactly and in every float field within 1e-4
+    (NaNs in the same places).  Prints one JSON object; bench.py exits non-zero when "ok" is false."""
+    from tests import oracle_lib
+    z = np.load(path, allow_pickle=False)
+    W, H = int(z["size"][0]), int(z["size"][1])
+    out = {"orb_frames": 0, "keyframes": 0, "ok": True, "max_abs": 0.0, "tolerance": 1e-4, "checker": "oracle/libmsl_oracle.so (parity unpinned: DESIGN.md 3)"}
+    fail = []
+    o = oracle_lib.load()
+    if "orb_gray" in z:
+        ex = o.orb_create(1000, 1.2, 8, 20, 7)
+        n_kp = 0
+        for f, img in enumerate(z["orb_gray"]):
+            ko, do = ex.extract(img)
+            n = int(z["orb_n"][f])
+            kg = z["orb_kps"][f][:n * 28].tobytes()
+            dg = z["orb_desc"][f][:n * 32].tobytes()
+            if n != len(ko) or kg != ko.tobytes() or dg != do.tobytes():
+                fail.append(f"ORB frame {f}: {n} keypoints on the GPU, {len(ko)} in the oracle" + ("" if n != len(ko) else ", bytes differ"))
+            n_kp += len(ko)
+        out["orb_frames"] = int(len(z["orb_gray"])); out["orb_keypoints"] = n_kp
+    if "sf_map_gpu" in z:
+        I = z["intr"]
+        sf = oracle_lib.OracleSurfel(W, H, float(I[0]), float(I[1]), float(I[2]), float(I[3]), 30.0, 0.5)
+        sf.map_set(z["sf_map0"].view(oracle_lib.SURFEL_DTYPE).reshape(-1))
+        nk = len(z["sf_refs"])
+        for k in range(nk):
+            mem = z["sf_member"][k if z["sf_member"].shape[0] > 1 else 0]
+            sf.fuse_map(int(z["sf_refs"][k]), np.ascontiguousarray(z["sf_gray"][k]), np.ascontiguousarray(z["sf_depth"][k]), np.ascontiguousarray(mem),
+                        np.ascontiguousarray(z["sf_poses"][k], np.float32))
+        mo = sf.map_get()
+        mg = z["sf_map_gpu"].view(oracle_lib.SURFEL_DTYPE).reshape(-1)
+        out["keyframes"] = int(nk); out["surfels"] = int(len(mo)); out["surfels_updated"] = int((mo["lastUpdate"] >= int(z["sf_refs"][0])).sum())
+        if len(mg) != len(mo):
+            fail.append(f"map: {len(mg)} surfels on the GPU, {len(mo)} in the oracle")
+        else:
+            for f in ("r", "g", "b", "updateTimes", "lastUpdate"):
+                if not np.array_equal(mg[f], mo[f]):
+                    fail.append(f"map field {f}: {int((mg[f] != mo[f]).sum())} surfels differ (first at {int(np.flatnonzero(mg[f] != mo[f])[0])})")
+            for f in ("px", "py", "pz", "nx", "ny", "nz", "size", "color", "weight"):
+                a, b = mg[f].astype(np.float64), mo[f].astype(np.float64)
+                if not np.array_equal(np.isnan(a), np.isnan(b)):
+                    fail.append(f"map field {f}: NaNs in different places")
+                    continue
+                d = np.abs(a - b); d = d[~np.isnan(d)]
+                m = float(d.max()) if d.size else 0.0
+                out["max_abs"] = max(out["max_abs"], m)
+                if m > 1e-4:
+                    fail.append(f"map field {f}: max |GPU - oracle| = {m:.3g}")
+            out["bit_identical"] = bool(mg.tobytes() == mo.tobytes())
+    out["ok"] = not fail
+    if fail:
+        out["failures"] = fail[:8]
+    print(json.dumps(out), flush=True)
+
+
 def _worker(inp, W, H, n_frames, do_orb, do_sf, kfe, barrier, q):
     try:
         barrier.wait()
@@ -117,7 +176,10 @@ def main():
     ap.add_argument("--map", default="dense", choices=["dense", "sparse", "moving"])
     ap.add_argument("--map-order", default="creation", choices=["creation", "random"])
     ap.add_argument("--scene", default="room", choices=["room", "clutter"])
+    ap.add_argument("--parity-gate", default=None, help="checker half of bench.py's parity gate: the .npz of inputs and HIP results to check against the oracle")
     args = ap.parse_args()
+    if args.parity_gate:
+        return parity_gate(args.parity_gate)
     W, H = (int(v) for v in args.size.lower().split("x"))
     do_orb, do_sf, kfe = not args.no_orb, not args.no_surfel, args.keyframe_every
     inp = build_inputs(args.distinct_frames, args.surfels if do_sf else 16, W, H, args.intrinsics, map_kind=args.map, map_order=args.map_order, scene=args.scene)

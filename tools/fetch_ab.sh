@@ -10,7 +10,7 @@ for v in $A $B; do
   while read -r GROUP; do
     [ -z "$GROUP" ] && continue
     i=$((i+1))
-    env $VAR=$v timeout 100 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT/v$v/g$i -o p -- python $R/bench.py --config 3 --cpu-frames 0 --no-breakdown --steps 1 --warmup 1 --passes-per-step 1 > $OUT/v${v}_g$i.log 2>&1
+    env $VAR=$v timeout 100 rocprofv3 --pmc $GROUP --kernel-trace --output-format csv -d $OUT/v$v/g$i -o p -- python $R/bench.py --config 3 --cpu-frames 0 --no-breakdown --no-parity-gate --steps 1 --warmup 1 --passes-per-step 1 > $OUT/v${v}_g$i.log 2>&1
   done <<'EOG'
 FETCH_SIZE
 WRITE_SIZE

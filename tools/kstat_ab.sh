@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/kstat_ab; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in $A $B; do
   rm -rf $OUT/v$v
-  env $VAR=$v timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/v$v -o p -- python $R/bench.py $ARGS --cpu-frames 0 --no-breakdown --steps 2 --warmup 1 --passes-per-step 2 > $OUT/v$v.log 2>&1
+  env $VAR=$v timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/v$v -o p -- python $R/bench.py $ARGS --cpu-frames 0 --no-breakdown --no-parity-gate --steps 2 --warmup 1 --passes-per-step 2 > $OUT/v$v.log 2>&1
   rm -f $OUT/v$v/*kernel_trace.csv $OUT/v$v/*/*kernel_trace.csv
   python3 - <<P
 import csv, glob, re

@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes for bench.py (run on the GPU box through gpurun).  Usage: tools/profile.sh <tag> [bench args]
-#   trace : --kernel-trace --stats of `bench.py --cpu-frames 0 --no-breakdown --steps 3 --warmup 1 [args]` (the stationary workload of the default
+#   trace : --kernel-trace --stats of `bench.py --cpu-frames 0 --no-breakdown --no-parity-gate --steps 3 --warmup 1 [args]` (the stationary workload of the default
 #           command: every pass starts from the same map, so 3 steps show the same kernels as 20)
 #   pmc   : FETCH_SIZE and WRITE_SIZE in separate passes (never combined with sys / hip trace domains) on --steps 1 --warmup 1 --passes-per-step 2
 TAG=${1:-r03}; shift
@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--cpu-frames 0 --no-breakdown $@"
+ARGS="--cpu-frames 0 --no-breakdown --no-parity-gate $@"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python $R/bench.py $ARGS --steps 3 --warmup 1 > $OUT/trace.log 2>&1
 rm -f $OUT/trace/*kernel_trace.csv      # hundreds of MB of per-dispatch rows; the statistics are what is kept
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- python $R/bench.py $ARGS --steps 1 --warmup 1 --passes-per-step 2 > $OUT/pmc_fetch.log 2>&1

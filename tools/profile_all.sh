@@ -10,9 +10,9 @@ cd $R
 tools/profile.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
 for c in 3; do
   O=$R/gpurun_out/prof_${TAG}_config$c; mkdir -p $O
-  (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --config $c --cpu-frames 0 --no-breakdown --steps 2 --warmup 1 > $O/trace.log 2>&1; rm -f $O/trace/*kernel_trace.csv)
+  (cd /tmp && TMPDIR=/tmp timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python $R/bench.py --config $c --cpu-frames 0 --no-breakdown --no-parity-gate --steps 2 --warmup 1 > $O/trace.log 2>&1; rm -f $O/trace/*kernel_trace.csv)
 done
-tools/pmc.sh $TAG bench.py --steps 1 --warmup 1 --passes-per-step 2 --cpu-frames 0 --no-breakdown > gpurun_out/pmc_$TAG.log 2>&1
+tools/pmc.sh $TAG bench.py --steps 1 --warmup 1 --passes-per-step 2 --cpu-frames 0 --no-breakdown --no-parity-gate > gpurun_out/pmc_$TAG.log 2>&1
 python tools/summarize_pmc.py $TAG > gpurun_out/pmc_$TAG/sq_counters.txt 2>&1
 find gpurun_out/pmc_$TAG -name "*.csv" -delete
 python bench.py --io host > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
