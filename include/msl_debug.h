@@ -45,7 +45,8 @@ MSL_API int msl_sf_debug_index(msl_sf *h, int32_t *out /*w*h*/) MSL_NOEXCEPT;
 MSL_API int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) MSL_NOEXCEPT;
 /* n_words 32-bit words from offset_words of one of the map stage's scratch arrays (which = 0: tail-move sources, 1: deleted-slot list, 2: the screen
  * keys the last k_fuse launch left per sub-block, 3: the wave -> sub-block dealing table, XCD-major; 4: out[0] = the grid that table is a permutation
- * for, 0 if none; host output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
+ * for, 0 if none; 5: out[0], out[1] = keyframes this handle has sent through the classic chain (k_fuse + k_compact) and through deferred windows; host
+ * output, synchronous).  Instrumented experiment builds (-DMSL_FUSE_STAMPS=<keyframe>, tools/fuse_stamps.py) park device-clock stamps of
  * k_fuse / k_compact / kb_seed_plane there; otherwise the content is meaningless. */
 /* Mean time (us) an event pair carried by a dispatch reports for an EMPTY kernel of `grid` single-wave workgroups on the map stream (n launches):
  * the measurement overhead contained in msl_sf_profile_read's per-kernel times (rocprofv3's kernel durations do not contain it). */
@@ -59,6 +60,9 @@ MSL_API int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint
  * (the automatic rule: more than eight frames per worker this process may use, the worker count being divided by LOCAL_WORLD_SIZE; MSL_PEAC_CLUSTER
  * = host / device overrides).  Frames whose node data does not fit the LDS take the host path regardless. */
 MSL_API int msl_debug_peac_cluster_on_device(int n_frames) MSL_NOEXCEPT;
+/* Worker threads of the plane extractor's host pool that could NOT be started since the process began (std::system_error from thread creation: the
+ * calls went on with fewer workers; the first occurrence also leaves a line in msl_last_error() and on stderr).  0 in a healthy process. */
+MSL_API long long msl_debug_peac_thread_shortfall(void) MSL_NOEXCEPT;
 MSL_API int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) MSL_NOEXCEPT;
 /* Test hook: the dealing of n_subblocks (a multiple of 8) k_fuse sub-blocks to the eight XCDs by screen key (0 .. 254: mean image row of the
  * sub-block's in-view surfels, >= 255: nothing in view), as k_compact / k_deal build it (msl_sf_map.hip, deal_subblocks): deal[x * n / 8 + j] = the

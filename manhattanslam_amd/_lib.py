@@ -107,6 +107,7 @@ SIGNATURES = {
     "msl_debug_chain_sum": (_i, [_vp, _vp, _i, _i, _vp]),
     "msl_debug_peac_mse": (_i, [_vp, _sz, _i, _vp]),
     "msl_debug_peac_cluster_on_device": (_i, [_i]),
+    "msl_debug_peac_thread_shortfall": (C.c_longlong, []),
     "msl_sf_profile_enable": (_i, [_vp, _i]),
     "msl_sf_profile_stride": (_i, [_vp, _i]),
     "msl_sf_profile_read": (_i, [_vp, _vp, _vp]),

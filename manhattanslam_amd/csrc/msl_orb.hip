@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <memory>
 #include <vector>
 
 using namespace msl;
@@ -1412,7 +1413,10 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
         return nullptr;
     }
     if (bind_device(device) != MSL_OK) return nullptr;
-    msl_orb *h = new msl_orb;
+    // (owned by a guard until the handle is complete: an exception from the containers below -- std::bad_alloc -- lands in the catch barrier, and the
+    // streams, events and device buffers created so far must go with it)
+    std::unique_ptr<msl_orb, void (*)(msl_orb *)> guard(new msl_orb, [](msl_orb *p) { msl_orb_destroy(p); });
+    msl_orb *h = guard.get();
     h->device = device; h->nfeatures = nfeatures; h->nlevels = nlevels; h->iniTh = iniThFAST; h->minTh = minThFAST;
     h->maxW = max_width; h->maxH = max_height; h->maxBatch = max_batch;
     h->scaleFactor = scaleFactorF;  // include/ORBextractor.h:97 keeps it as double
@@ -1454,12 +1458,11 @@ msl_orb *msl_orb_create(int nfeatures, float scaleFactorF, int nlevels, int iniT
         hipStreamCreateWithPriority(&h->sideStream, hipStreamNonBlocking, prLo) != hipSuccess ||
         hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess) {
         set_error("msl_orb_create: HIP resource allocation failed");
-        msl_orb_destroy(h);
         return nullptr;
     }
     h->prof.nk = MSL_ORB_NKERNELS;
-    if (build_geometry(h, max_width, max_height) != MSL_OK) { msl_orb_destroy(h); return nullptr; }
-    return h;
+    if (build_geometry(h, max_width, max_height) != MSL_OK) return nullptr;
+    return guard.release();
     } MSL_ABI_CATCH_PTR
 }
 

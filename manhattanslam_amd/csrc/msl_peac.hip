@@ -1129,6 +1129,7 @@ class SegPool {
 public:
     static SegPool &get() { static SegPool p; return p; }
     int workers() const { return maxWorkers_ + 1; }   // the caller takes part
+    long long thread_shortfall() const { return threadShortfall_.load(); }   // worker threads that could not be started since the process began
     // fn(frame, workspace) for frame = 0 .. nFrames-1, each exactly once; returns when all are done
     void run(int nFrames, const std::function<void(int, FrameSegmenter &)> &fn) {
         std::lock_guard<std::mutex> one(callMutex_);   // one batch at a time
@@ -1159,7 +1160,15 @@ public:
             for (int t = 0; t < nWorkers; t++) threads.emplace_back([&, t]() { work(*ws_[t + 1]); });
         } catch (...) {   // thread creation failed (std::system_error): the threads that did start finish the work together with the caller
             std::lock_guard<std::mutex> g(failMutex);
-            if (getenv("MSL_PEAC_STRICT_THREADS") && !failure) failure = std::current_exception();
+            static const bool strict = getenv("MSL_PEAC_STRICT_THREADS") != nullptr;
+            if (strict && !failure) failure = std::current_exception();
+            // the degradation is recorded, not silent: a counter the debug hook reads, and -- once per process -- a line in msl_last_error()'s
+            // buffer (the call still succeeds) and on stderr
+            const int miss = nWorkers - (int)threads.size();
+            if (threadShortfall_.fetch_add(miss) == 0) {
+                set_error("msl_peac: only %d of %d worker threads could be started (resource limit?); the call continues with fewer", (int)threads.size(), nWorkers);
+                fprintf(stderr, "[msl_peac] warning: only %d of %d worker threads could be started; continuing with fewer\n", (int)threads.size(), nWorkers);
+            }
         }
         work(*ws_[0]);
         for (auto &th : threads) th.join();
@@ -1180,6 +1189,7 @@ private:
         if (getenv("MSL_PEAC_POOL_REPORT")) fprintf(stderr, "[msl_peac] pool workers = %d (usable CPUs %d)\n", maxWorkers_ + 1, usable_cpus());
     }
     const int maxWorkers_;
+    std::atomic<long long> threadShortfall_{0};
     std::mutex callMutex_;
     std::vector<std::unique_ptr<FrameSegmenter>> ws_;
 };
@@ -1574,6 +1584,8 @@ int msl_debug_peac_cluster_on_device(int n_frames) noexcept {
     return n_frames > 8 * SegPool::get().workers() ? 1 : 0;
     } MSL_ABI_CATCH_INT
 }
+
+long long msl_debug_peac_thread_shortfall(void) noexcept { try { return SegPool::get().thread_shortfall(); } MSL_ABI_CATCH_(return -1) }
 
 int msl_debug_peac_mse(const msl_peac_stats *stats, size_t n, int lanes, double *mse_out) noexcept {
     try {

@@ -53,7 +53,7 @@ __host__ __device__ inline size_t fuserec_index(int nseeds, unsigned seed, int w
 struct alignas(16) HotPk { float px, py, pz; unsigned tl; };
 struct HotRec { float px, py, pz; int updateTimes, lastUpdate; };   // the unpacked form kernels compute with
 constexpr unsigned HOT_WIDE = 0x80000000u, HOT_HOLE = 0xFFFFFFFFu;
-__host__ __device__ inline bool tl_fits(int ut, int lu) { return (unsigned)ut < 2048u && (unsigned)(lu + (1 << 19)) < (1u << 20); }
+__host__ __device__ inline bool tl_fits(int ut, int lu) { return (unsigned)ut < 2048u && ((unsigned)lu + (1u << 19)) < (1u << 20); }   // (unsigned sum: no signed overflow for lu near INT_MAX)
 __host__ __device__ inline unsigned tl_pack(int ut, int lu) { return ((unsigned)ut << 20) | ((unsigned)lu & 0xFFFFFu); }
 __host__ __device__ inline int tl_ut(unsigned tl) { return (int)(tl >> 20); }                 // (of a record with bit 31 clear)
 __host__ __device__ inline int tl_lu(unsigned tl) { return (int)(tl << 12) >> 12; }

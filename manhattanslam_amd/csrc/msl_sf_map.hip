@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(64) void k_defer_tail(SfDev P, FuseArgs A, int F, u
     const unsigned lane = threadIdx.x;
     if ((int)blockIdx.x < F) {
         const int f = (int)blockIdx.x;
-        // keyframe f's counts: one per sub-block below the extent its regular waves worked on, and behind them (from index (E0 >> 8) + 1 on) one per
+        // keyframe f's counts: one per sub-block below the extent its regular waves worked on, and behind them (from index E0 / SUB_ITEMS + 1 on) one per
         // 256 new surfels of keyframe f - 1 that its spawn wave wrote and fused
         const long long E0 = f > 0 ? P.dc->ext[f - 1] : P.dc->ext[0], Kp = f > 0 ? P.dc->ext[f] - E0 : 0;
         const long long nblk = (E0 + SUB_ITEMS - 1) / SUB_ITEMS, x0 = E0 / SUB_ITEMS + 1, x1 = x0 + (Kp + SUB_ITEMS - 1) / SUB_ITEMS;

@@ -6,7 +6,8 @@
 //                           FRAME-BATCHED on the "pre" stream (kb_* kernels, one launch sequence per batch of F keyframes);
 //   msl_sf_map.hip          the map stage (fusion -> new surfels -> compaction) is sequential per keyframe, on the "map" stream:
 //                           k_fuse + k_compact per keyframe (classic), or ONE k_fuse launch per keyframe with the compactions of a
-//                           window of <= 32 keyframes replayed at its end (deferred, the default for batches);
+//                           window of <= 32 keyframes replayed at its end (deferred); run_batch picks per batch: deferred for a handle on ONE
+//                           caller-provided stream under low churn, classic otherwise (a handle with its own two streams: always classic);
 // the two stages overlap across batches (double-buffered slot sets).
 
 #include "msl_sf.h"
@@ -15,6 +16,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -32,6 +34,7 @@ struct msl_sf {
     int maxBatch = 1;              // keyframes per batch; slots = 2 * maxBatch (double-buffered sets)
     hipStream_t preStream = nullptr, mapStream = nullptr; bool ownStreams = true;
     size_t blkStride = 0;          // entries per per-sub-block count slice (blockSums: one slice; blockUpd: DEFER_WIN slices, one per keyframe of a window)
+    unsigned long long kfClassic = 0, kfDeferred = 0;   // keyframes that went through the classic pair of launches / through deferred windows (msl_sf_debug_scratch, which = 5)
     int dealG = 0;                 // the k_fuse grid SfDev::deal currently is a permutation for (0: none yet) -- screen-position dealing, msl_sf_map.hip
     hipStream_t copyStream = nullptr;   // host-image mode: the H2D copies of slot set i + 1 run beside the superpixel kernels of set i
     hipEvent_t evH2D[2] = {nullptr, nullptr};
@@ -236,12 +239,32 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     return MSL_OK;
 }
 
+// Counter snapshots that have arrived (their event has fired): a tighter bound / a fresher value of the live count, and the churn estimate -- spawned +
+// deleted surfels per keyframe between two snapshots, from the running totals.
+void consume_snapshots(msl_sf *h, size_t nseeds) {
+    for (int i = 0; i < msl_sf::NSNAP; i++)
+        if (h->snapBusy[i] && hipEventQuery(h->snapEv[i]) == hipSuccess) {
+            h->snapBusy[i] = false;
+            const long long *sn = h->h_snap + (size_t)i * msl_sf::SNAPW;
+            if (h->snapLive[i]) {
+                const size_t cand = (size_t)sn[0] + (size_t)(h->kfEnq - h->snapKf[i]) * nseeds;   // count then + what was enqueued since
+                if (cand < h->liveBound) h->liveBound = cand;
+                if (h->snapKf[i] >= h->liveKnownKf) { h->liveKnown = (size_t)sn[0]; h->liveKnownKf = h->snapKf[i]; }   // completed snapshots are visited in array order, not age order
+            }
+            if (h->snapKf[i] > h->churnAt) {   // running totals: new ctr[8], deleted ctr[9], keyframes ctr[11]
+                if (h->churnNew >= 0 && sn[11] > h->churnKf) h->churn = (double)((sn[8] - h->churnNew) + (sn[9] - h->churnDel)) / (double)(sn[11] - h->churnKf);
+                h->churnNew = sn[8]; h->churnDel = sn[9]; h->churnKf = sn[11]; h->churnAt = h->snapKf[i];
+            }
+        }
+}
+
 int read_ctr(msl_sf *h) {
     if (h->ownStreams && h->copyStream) MSL_HIP_TRY(hipStreamSynchronize(h->copyStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->preStream));
     MSL_HIP_TRY(hipMemcpyAsync(h->h_ctr, h->d_ctr, sizeof(long long) * 16, hipMemcpyDeviceToHost, h->mapStream));
     MSL_HIP_TRY(hipStreamSynchronize(h->mapStream));
     h->prof.drain();
+    consume_snapshots(h, (size_t)h->dev.nseeds);   // (all pending snapshots have arrived: their churn information is kept, the live count below is newer)
     h->liveBound = (size_t)h->h_ctr[0];   // both streams are idle: the count is exact
     h->liveKnown = h->liveBound; h->liveKnownKf = h->kfEnq;
     for (int i = 0; i < msl_sf::NSNAP; i++) h->snapBusy[i] = false;   // (their events have fired: the stream is idle)
@@ -282,20 +305,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         // overflow it.  Every keyframe adds at most nseeds surfels, so the host only needs an upper bound of the live count; the
         // exact count is read back (one sync) only when that bound reaches the capacity.
         const size_t need = (size_t)n * (size_t)D.nseeds;
-        for (int i = 0; i < msl_sf::NSNAP; i++)
-            if (h->snapBusy[i] && hipEventQuery(h->snapEv[i]) == hipSuccess) {
-                h->snapBusy[i] = false;
-                const long long *sn = h->h_snap + (size_t)i * msl_sf::SNAPW;
-                if (h->snapLive[i]) {
-                    const size_t cand = (size_t)sn[0] + (size_t)(h->kfEnq - h->snapKf[i]) * (size_t)D.nseeds;   // count then + what was enqueued since
-                    if (cand < h->liveBound) h->liveBound = cand;
-                    if (h->snapKf[i] >= h->liveKnownKf) { h->liveKnown = (size_t)sn[0]; h->liveKnownKf = h->snapKf[i]; }   // completed snapshots are visited in array order, not age order
-                }
-                if (h->snapKf[i] > h->churnAt) {   // running totals: new ctr[8], deleted ctr[9], keyframes ctr[11]
-                    if (h->churnNew >= 0 && sn[11] > h->churnKf) h->churn = (double)((sn[8] - h->churnNew) + (sn[9] - h->churnDel)) / (double)(sn[11] - h->churnKf);
-                    h->churnNew = sn[8]; h->churnDel = sn[9]; h->churnKf = sn[11]; h->churnAt = h->snapKf[i];
-                }
-            }
+        consume_snapshots(h, (size_t)D.nseeds);
         if (h->liveBound + need > h->mapCap) {
             int rc = read_ctr(h);
             if (rc != MSL_OK) return rc;
@@ -427,7 +437,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     static const int DEAL_EVERY = getenv("MSL_SF_DEAL_EVERY") ? std::max(1, atoi(getenv("MSL_SF_DEAL_EVERY"))) : 4;
     static const char *dealEnv = getenv("MSL_SF_DEAL");   // "0": sub-blocks in array order (rounds 1-5), for A/B measurements
     const bool dealOn = !(dealEnv && !strcmp(dealEnv, "0")) && (nSubGrid & 7) == 0 && (size_t)nSubGrid <= h->blkStride;
-    // Map stage.  Deferred compaction (the default for resident batches; MSL_SF_DEFER=0 turns it off): windows of <= DEFER_WIN keyframes, ONE
+    // Map stage.  Deferred compaction (MSL_SF_DEFER=0 turns it off, =1 forces it; unset: the policy below): windows of <= DEFER_WIN keyframes, ONE
     // launch per keyframe, the window's compactions replayed at its end (msl_sf_map.hip).  Classic (k_fuse + k_compact per keyframe): single
     // keyframes, the host-vector drop-in, the first keyframe after the map was replaced from outside, and batches enqueued while the recent
     // churn (spawned + deleted surfels per keyframe, from the asynchronous counter snapshots) is high -- k_compact takes any number of stale or
@@ -451,6 +461,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         P.dealG = dealOn && compact && (f % DEAL_EVERY == 0 || h->dealG != nSubGrid) ? nSubGrid : 0;
         map_launch_compact(h->prof, sm, P, f, compact);
         if (P.dealG) h->dealG = nSubGrid;
+        h->kfClassic++;
     };
     int f = 0;
     const int fProbe = n / 2;   // only when its profiler slot is enabled: what an event pair reports for an EMPTY dispatch at this place of the chain
@@ -467,6 +478,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             }
             P.kf = w; P.prevSlotAbs = slot0 + f + w - 1;
             map_launch_replay(h->prof, sm, P, w, (unsigned)h->blkStride);
+            h->kfDeferred += (unsigned long long)w;
             if (dealOn) { P.dealG = nSubGrid; map_launch_deal(sm, P); h->dealG = nSubGrid; }   // one dealing per window, from the keys of its last keyframe
             f += w;
         }
@@ -498,7 +510,10 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         return nullptr;
     }
     if (bind_device(device) != MSL_OK) return nullptr;
-    msl_sf *h = new msl_sf;
+    // (owned by a guard until the handle is complete: an exception below -- std::bad_alloc from the table vector -- lands in the catch barrier, and
+    // the streams, events and device buffers created so far must go with it)
+    std::unique_ptr<msl_sf, void (*)(msl_sf *)> guard(new msl_sf, [](msl_sf *p) { msl_sf_destroy(p); });
+    msl_sf *h = guard.get();
     h->device = device;
     SfDev &D = h->dev;
     D.W = width; D.H = height; D.spW = width / SP; D.spH = height / SP; D.nseeds = D.spW * D.spH; D.npx = width * height;   // spWidth = width / SP_SIZE: truncation (:29-38)
@@ -537,13 +552,13 @@ msl_sf *msl_sf_create(int width, int height, float fx, float fy, float cx, float
         D.colX = h->d_projTab; D.rowY = h->d_projTab + width + 1;
     }
     if (ok) h->propLds = sp_init_attributes(D.nseeds);
-    if (!ok) { set_error("msl_sf_create: HIP allocation failed"); msl_sf_destroy(h); return nullptr; }
+    if (!ok) { set_error("msl_sf_create: HIP allocation failed"); return nullptr; }
     memset(h->h_ctr, 0, sizeof(long long) * 16);
     D.ctr = h->d_ctr; D.newSurfels = h->d_new; D.tickets = h->d_tickets; D.delU = h->d_delU; D.delUCount = h->d_tickets + 4;
     D.dc = h->d_dc; D.kf = 0; D.prevSlotAbs = 0;
     h->prof.nk = MSL_SF_NKERNELS;
-    if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) { msl_sf_destroy(h); return nullptr; }
-    return h;
+    if (alloc_slots(h, 1) != MSL_OK || map_realloc(h, 1 << 16, 0) != MSL_OK) return nullptr;
+    return guard.release();
     } MSL_ABI_CATCH_PTR
 }
 
@@ -883,7 +898,7 @@ int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) noexcept {
 // Host-vector mode.  The caller's vector is the map for this call; what travels is kept to what has to:
 //   in : the whole vector (56 B per surfel) -- unless MSL_SF_LOCAL_UNCHANGED says it still is what the previous call on this handle left there, in
 //        which case the device copy of that call is used as it stands (checked: same length, no other map operation on the handle in between);
-//   out: only the stretches of the vector that hold surfels this keyframe touched.  k_fuse leaves a deleted and an updated count per 256-surfel
+//   out: only the stretches of the vector that hold surfels this keyframe touched.  k_fuse leaves a deleted and an updated count per SUB_ITEMS-surfel
 //        sub-block; sub-blocks with neither are byte-identical to the caller's copy and are not sent back (runs of touched sub-blocks travel as
 //        one copy each, small gaps bridged; more than 64 runs collapse into fewer by bridging larger gaps).
 int msl_sf_fuse_ex(msl_sf *h, int referenceFrameIndex, const uint8_t *gray, size_t gray_stride, const float *depth, size_t depth_stride,
@@ -1022,7 +1037,12 @@ int msl_sf_debug_ctr(msl_sf *h, int64_t out[16]) noexcept {
 }
 int msl_sf_debug_scratch(msl_sf *h, int which, size_t offset_words, uint32_t *out, size_t n_words) noexcept {
     try {
-    if (!h || !out || which < 0 || which > 4) return MSL_ERR_INVALID;
+    if (!h || !out || which < 0 || which > 5) return MSL_ERR_INVALID;
+    if (which == 5) {   // keyframes this handle sent through the classic chain / through deferred windows (host state)
+        if (n_words < 2) return MSL_ERR_INVALID;
+        out[0] = (uint32_t)h->kfClassic; out[1] = (uint32_t)h->kfDeferred;
+        return MSL_OK;
+    }
     if (which == 4) {   // the grid the dealing table currently is a permutation for (host state; 0: none)
         if (n_words < 1) return MSL_ERR_INVALID;
         out[0] = (uint32_t)h->dealG;

@@ -3,9 +3,10 @@ import sys
 
 import pytest
 
-# Resident batches take the deferred compaction unless the recent churn (spawned + deleted surfels per keyframe) is high, in which case the library
-# switches to the classic two-launch chain (msl_surfel.hip, run_batch).  The parity tests are exactly the heavy-churn cases, so they pin the deferred
-# path (read once per process); tests/test_surfel_gpu.py::test_classic_chain_gives_identical_maps runs them again with MSL_SF_DEFER=0.
+# Which map chain a resident batch takes is the library's choice (msl_surfel.hip, run_batch: deferred windows for a handle on one caller stream under low
+# churn, the classic k_fuse + k_compact pair otherwise -- a handle with its own two streams always).  The parity tests pin the deferred chain (read once
+# per process) because it is the more intricate one; tests/test_surfel_gpu.py::test_classic_chain_gives_identical_maps runs them again with MSL_SF_DEFER=0,
+# and ::test_default_policy_picks_the_chain_and_keeps_parity runs the unset-environment policy itself in a child process.
 os.environ.setdefault("MSL_SF_DEFER", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -823,8 +823,8 @@ def test_host_vector_sparse_change_list(oracle):
 
 
 def test_classic_chain_gives_identical_maps():
-    """Resident batches take the DEFERRED compaction by default (round 5: one k_fuse launch per keyframe, new surfels appended physically, the
-    window's placements and tail moves replayed at its end, msl_sf_map.hip).  MSL_SF_DEFER=0 sends every keyframe through the classic pair
+    """The parity suite pins the DEFERRED compaction (tests/conftest.py: MSL_SF_DEFER=1; round 5: one k_fuse launch per keyframe, new surfels appended
+    physically, the window's placements and tail moves replayed at its end, msl_sf_map.hip).  MSL_SF_DEFER=0 sends every keyframe through the classic pair
     k_fuse + k_compact instead.  The flag is read once per process, so the batched / resident parity tests run again in a child process with
     it set: both chains leave the oracle's maps, counters and new-surfel lists."""
     import os
@@ -839,6 +839,20 @@ def test_classic_chain_gives_identical_maps():
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_default_policy_picks_the_chain_and_keeps_parity():
+    """tests/conftest.py pins MSL_SF_DEFER=1 and test_classic_chain_gives_identical_maps pins 0; bench.py -- and any caller -- runs with NEITHER: the library
+    then chooses per batch (msl_surfel.hip, run_batch).  tests/policy_child.py runs that unset-environment path in a child process: a handle with its own
+    two streams (bench.py's shape) takes the classic chain for every keyframe, a handle on one caller stream takes deferred windows, and falls back to
+    the classic chain once the churn estimate flips -- all three against the oracle, batch by batch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "MSL_SF_DEFER"}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "policy_child.py")], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "policy ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_wide_update_counters_survive_the_packed_hot_record(oracle):
