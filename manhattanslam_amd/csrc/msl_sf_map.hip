@@ -778,8 +778,36 @@ constexpr int TAIL_MAX_HOPS = 64;   // relay hops resolved per hole before the l
 // mode 1 (host-vector drop-in, one workgroup): emission and counters only; the caller compacts (SurfelMapping.cpp:366-391).
 constexpr int SMALL_D = 512, SMALL_CHUNKS = 48;   // single-workgroup path: few deletions in few chunks
 
+// What k_compact reads of the handle: a slim copy of SfDev with the keyframe's slot folded in (round 6; 36 instead of ~150 dwords of kernel
+// arguments).  Unlike k_fuse in round 5 the kernel's register count did not follow (182 VGPRs in the 8-word form: the prefetched counts, flag
+// words and candidate records of the steady-state path are live together by design -- every load of the chain leaves before the first use; a
+// 128-register cap spills 78 of them to scratch), so what the slim arguments buy is the shorter scalar prologue only.
+struct CompactArgs {
+    int nseeds, flagStride, dealG, _pad;
+    unsigned long long cap;
+    MapSoA map;
+    long long *ctr;
+    const uint8_t *candOk, *fused;     // this keyframe's slot
+    const msl_surfel *cand;            // ...
+    msl_surfel *newSurfels;
+    unsigned *blockSums, *blockUpd, *delList, *srcOf, *tickets, *delU, *delUCount;
+    const unsigned *sbKeys; unsigned *deal;
+};
+__host__ inline CompactArgs compact_args(const SfDev &P, int slot) {
+    CompactArgs A;
+    A.nseeds = P.nseeds; A.flagStride = P.flagStride; A.dealG = P.dealG; A._pad = 0; A.cap = P.cap; A.map = P.map; A.ctr = P.ctr;
+    A.candOk = P.candOk + (size_t)slot * P.flagStride; A.fused = P.fused + (size_t)slot * P.flagStride; A.cand = P.cand + (size_t)slot * P.nseeds;
+    A.newSurfels = P.newSurfels; A.blockSums = P.blockSums; A.blockUpd = P.blockUpd; A.delList = P.delList; A.srcOf = P.srcOf; A.tickets = P.tickets;
+    A.delU = P.delU; A.delUCount = P.delUCount; A.sbKeys = P.sbKeys; A.deal = P.deal;
+    return A;
+}
+
 // LDS is kept to ~3.5 KB: on a GPU saturated by the LDS-heavy batched kernels a larger workgroup waits for a CU to drain.
-__global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
+// NQW: the seed flags of a thread arrive in ONE round trip as NQW 32-bit words per array (8: <= 32 seeds per thread, 640 x 480 has 19; 24: <= 96,
+// 1280 x 960 has 76); 0: the generic loop (any size or alignment).  Separate instantiations: the 24-word form costs 45 registers more (227
+// against 182), which the common geometry need not carry.
+template <int NQW>
+__global__ __launch_bounds__(256) void k_compact(CompactArgs P, int mode) {
     constexpr int NT = 256, TILE = 4 * NT;
     __shared__ unsigned s_wave[33];
     __shared__ unsigned s_dl[SMALL_D];          // single-workgroup paths: the ascending deleted-slot list stays in LDS
@@ -806,12 +834,12 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
     const unsigned dHand = *P.delUCount;   // k_fuse's running total of deleted slots = D of this keyframe
     const long long n = P.ctr[0];
     const bool bad = P.ctr[5] == 20;
-    const uint8_t *candOk = P.candOk + (size_t)slot * P.flagStride, *fused = P.fused + (size_t)slot * P.flagStride;
+    const uint8_t *candOk = P.candOk, *fused = P.fused;
     const int per = (((P.nseeds + NT - 1) / NT) + 3) & ~3;      // seeds per thread, multiple of 4: aligned 32-bit flag loads
     const int s0 = threadIdx.x * per, s1 = min(s0 + per, P.nseeds);
     unsigned cnt = 0;
     unsigned long long emit = 0, emitHi = 0;   // bit j: seed s0 + j spawns a surfel (emit: j < 64; emitHi: 64 <= j < 128)
-    const msl_surfel *cand = P.cand + (size_t)slot * P.nseeds;
+    const msl_surfel *cand = P.cand;
     const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
     const bool aligned4 = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
     // all flag words of the thread in ONE round trip: 8 words each for <= 32 seeds per thread (640 x 480: 19), 24 words for <= 96 (1280 x 960: 76 --
@@ -840,10 +868,9 @@ __global__ __launch_bounds__(256) void k_compact(SfDev P, int slot, int mode) {
                 else emitHi |= (unsigned long long)e << ((4 * q + j - 64) & 63);
             }
     };
-    if (per <= 32 && aligned4) {
-        flags_in_one_trip(std::integral_constant<int, 8>{});
-    } else if (per <= 96 && aligned4) {
-        flags_in_one_trip(std::integral_constant<int, 24>{});
+    if constexpr (NQW > 0) {
+        (void)aligned4;   // (the host picked this instantiation: per <= 4 NQW and aligned flag arrays)
+        flags_in_one_trip(std::integral_constant<int, NQW>{});
     } else {
         for (int i = s0; i < s1; i += 4) {
             unsigned c4, f4;
@@ -1558,7 +1585,13 @@ void map_launch_fuse(KernelProfiler &prof, hipStream_t st, const SfDev &P, int s
     else MSL_SF_LAUNCH(prof, SK_FUSE, st, k_fuse<false>, dim3((unsigned)nSubGrid), dim3(64), A, FF, nSubHint);
 }
 void map_launch_compact(KernelProfiler &prof, hipStream_t st, const SfDev &P, int slot, bool resident) {
-    MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_compact, dim3(resident ? 128 : 1), dim3(256), P, slot, resident ? 0 : 1);   // scan + new surfels + refill + tail compaction
+    const CompactArgs A = compact_args(P, slot);
+    const int per = (((P.nseeds + 255) / 256) + 3) & ~3;   // seeds per thread (k_compact)
+    const bool aligned4 = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(A.candOk) | reinterpret_cast<size_t>(A.fused)) & 3) == 0;
+    const dim3 grid(resident ? 128 : 1);
+    if (per <= 32 && aligned4) MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_compact<8>, grid, dim3(256), A, resident ? 0 : 1);
+    else if (per <= 96 && aligned4) MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_compact<24>, grid, dim3(256), A, resident ? 0 : 1);
+    else MSL_SF_LAUNCH(prof, SK_COMPACT, st, k_compact<0>, grid, dim3(256), A, resident ? 0 : 1);   // scan + new surfels + refill + tail compaction
 }
 // Closes a deferred window of F keyframes (P.prevSlotAbs = the slot of its last keyframe, P.blockUpd = the window's first per-sub-block slice).
 void map_launch_replay(KernelProfiler &prof, hipStream_t st, const SfDev &P, int F, unsigned blkStride) {

@@ -39,7 +39,7 @@ struct msl_sf {
     hipStream_t copyStream = nullptr;   // host-image mode: the H2D copies of slot set i + 1 run beside the superpixel kernels of set i
     hipEvent_t evH2D[2] = {nullptr, nullptr};
     hipEvent_t evPre[2] = {nullptr, nullptr}, evMap[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
-    bool evMapValid[2] = {false, false}, evCopyValid[2] = {false, false};
+    bool evMapValid[2] = {false, false}, evCopyValid[2] = {false, false}, evPreValid[2] = {false, false};
     unsigned long long batchNo = 0;
     int lastSlot = 0;
     // per-slot device buffers
@@ -235,6 +235,7 @@ int alloc_slots(msl_sf *h, int maxBatch) {
     h->maxBatch = maxBatch;
     h->lastSlot = 0;            // the debug accessors must never index beyond the reallocated slot buffers
     h->evMapValid[0] = h->evMapValid[1] = false;
+    h->evPreValid[0] = h->evPreValid[1] = false;
     h->evCopyValid[0] = h->evCopyValid[1] = false;
     return MSL_OK;
 }
@@ -350,7 +351,11 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         // The images travel on their own stream so that they overlap the superpixel kernels of the previous call (the other slot set);
         // with caller-provided streams (msl_sf_set_stream) everything stays on that one stream.
         hipStream_t sc = (h->ownStreams && h->copyStream) ? h->copyStream : sp;
-        if (sc != sp && h->evMapValid[set]) MSL_HIP_TRY(hipStreamWaitEvent(sc, h->evMap[set], 0));   // the set's previous user is done
+        // (round 6) the staged images of a set are read by the SUPERPIXEL stage only -- the map stage works on the slot arrays (texels, seed records,
+        // candidates) -- so the copies of call k wait for the superpixel stage of call k - 2 (evPre), not for its map stage (evMap, which the
+        // superpixel stage of call k still waits for): the link runs up to two calls ahead of the map chain instead of in step with it
+        // (A/B on one box, bench.py --io host: 17.6 k -> 19.0 k frames/s with f32 depth, 18.8 k -> 20.1 k with raw 16-bit depth)
+        if (sc != sp && h->evPreValid[set]) MSL_HIP_TRY(hipStreamWaitEvent(sc, h->evPre[set], 0));
         h->prof.begin(SK_COPY, sc);
         // Tightly packed frame arrays (the streaming case) travel as ONE copy per image kind instead of one per frame; a membership image
         // shared by all keyframes of the call (member_frame_stride == 0) is staged once.
@@ -423,6 +428,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     sp_launch_stage(h->prof, sp, P, n, h->propLds);
     if (sp != sm) {
         MSL_HIP_TRY(hipEventRecord(h->evPre[set], sp));
+        h->evPreValid[set] = true;
         MSL_HIP_TRY(hipStreamWaitEvent(sm, h->evPre[set], 0));
     }
     const size_t boundLive = compact ? h->liveBound : h->mapCap;

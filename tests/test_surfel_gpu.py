@@ -718,6 +718,34 @@ def test_host_image_batches_with_shared_membership_and_strided_frames(oracle):
     g.close()
 
 
+@pytest.mark.parametrize("raw16", [False, True])
+def test_six_host_image_calls_in_flight(oracle, raw16):
+    """Streaming from host memory (bench.py --io host): six calls enqueued back to back without a sync, every call with its own frames.  The H2D copies of
+    call k run on the copy stream and (round 6) wait only for the SUPERPIXEL stage of call k - 2 -- the last reader of the set's staged images --, not
+    for its map stage, so the link runs ahead of the map chain; a copy that overtook a reader, or a superpixel stage that overtook the map stage of the
+    slot arrays it rewrites, would show as a map that differs from the oracle's."""
+    from manhattanslam_amd import synth, SURFEL_DTYPE
+    g, o = _mk(synth.TUM1)
+    m = synth.surfel_map_dense(150_000, ref=0).astype(SURFEL_DTYPE)
+    g.set_batch_capacity(4)
+    g.map_reserve(len(m) + 100_000)
+    g.map_upload(m); o.map_set(m)
+    nk = 24
+    frames = [synth.surfel_frame(k, variant="B" if k % 5 == 3 else "A") for k in range(nk)]
+    factor = float(np.float32(1.0) / np.float32(5000.0))
+    d16 = [np.clip(np.rint(f[1] * 5000.0), 0, 65535).astype(np.uint16) for f in frames]
+    depth_f = [(d.astype(np.float32) * np.float32(factor)) if raw16 else f[1] for d, f in zip(d16, frames)]      # what the device conversion yields
+    member = frames[0][2]
+    for c in range(nk // 4):
+        sl = slice(4 * c, 4 * c + 4)
+        g.fuse_resident_batch(np.arange(4 * c, 4 * c + 4), np.stack([f[0] for f in frames[sl]]), np.stack(d16[sl]) if raw16 else np.stack([f[1] for f in frames[sl]]),
+                              member, [f[3] for f in frames[sl]], member_shared=True, depth_factor=factor if raw16 else None)
+    for k in range(nk):
+        o.fuse_map(k, frames[k][0], depth_f[k], member, frames[k][3])
+    assert_surfels_close(g.map_download(), o.map_get(), "six host-image calls in flight")
+    g.close()
+
+
 def test_map_outgrows_the_fuse_grid_inside_one_call(oracle):
     """k_fuse's grid covers the host's last KNOWN live count plus 2 keyframes' worth of seeds; a call whose keyframes add more than that (an
     empty map and 16 fresh views) is still covered because the kernel is grid-stride over the device's live count."""
