@@ -442,7 +442,10 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     const int nSubHint = (int)(known / SUB_ITEMS);
     static const int DEAL_EVERY = getenv("MSL_SF_DEAL_EVERY") ? std::max(1, atoi(getenv("MSL_SF_DEAL_EVERY"))) : 4;
     static const char *dealEnv = getenv("MSL_SF_DEAL");   // "0": sub-blocks in array order (rounds 1-5), for A/B measurements
-    const bool dealOn = !(dealEnv && !strcmp(dealEnv, "0")) && (nSubGrid & 7) == 0 && (size_t)nSubGrid <= h->blkStride;
+    // ... and only while the map (48 bytes per surfel) fits the 256 MB Infinity Cache: a larger map is streamed from HBM, where waves that walk the array in
+    // order keep DRAM pages open -- 8 M surfels: k_fuse 76.9 us in array order, 80.5 us dealt (bench.py --surfels 8000000, A/B on one box)
+    constexpr int DEAL_MAX_GRID = (4 << 20) / SUB_ITEMS;
+    const bool dealOn = !(dealEnv && !strcmp(dealEnv, "0")) && (nSubGrid & 7) == 0 && (size_t)nSubGrid <= h->blkStride && nSubGrid <= DEAL_MAX_GRID;
     // Map stage.  Deferred compaction (MSL_SF_DEFER=0 turns it off, =1 forces it; unset: the policy below): windows of <= DEFER_WIN keyframes, ONE
     // launch per keyframe, the window's compactions replayed at its end (msl_sf_map.hip).  Classic (k_fuse + k_compact per keyframe): single
     // keyframes, the host-vector drop-in, the first keyframe after the map was replaced from outside, and batches enqueued while the recent
