@@ -1,7 +1,8 @@
 # L2 (TCC) / vector-cache (TCP) request counters of the surfel kernels on bench.py --config 3: three rocprofv3 --pmc passes (kernel trace only), per-launch
 # averages on stdout (profiles/r05_cache_counters.txt).  Run on the GPU box through gpurun.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/tcc_r05; mkdir -p $OUT
+TAG=${1:-r06}
+OUT=$R/gpurun_out/tcc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r GROUP; do

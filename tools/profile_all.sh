@@ -4,7 +4,7 @@
 # CPU baseline, configurations 2-5 with theirs, the 8 M-surfel run whose map exceeds the 256 MB Infinity Cache, the moving-camera regime, the
 # deferred compaction against the classic chain).
 # Usage: tools/profile_all.sh <tag>
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 tools/profile.sh $TAG > gpurun_out/profile_$TAG.log 2>&1
@@ -24,5 +24,15 @@ timeout 300 python bench.py --map moving --cpu-frames 0 --steps 8 > gpurun_out/b
 MSL_SF_DEFER=1 timeout 300 python bench.py --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_deferred.json 2> gpurun_out/bench_${TAG}_deferred.err
 MSL_SF_DEFER=1 timeout 300 python bench.py --config 3 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_config3_deferred.json 2> gpurun_out/bench_${TAG}_config3_deferred.err
 for d in 0 1; do MSL_SF_DEFER=$d timeout 200 python tools/fuse_iso.py 3 2>/dev/null | tail -1 > gpurun_out/fuse_iso_${TAG}_defer$d.json; done
+# round 6: the screen-position dealing of k_fuse's sub-blocks against array order (fabric traffic and L2 counters, A/B on this box), the L2 / vector-cache
+# request counters of the surfel kernels, two sequences per GPU (bench line + SQ counters of that shape), the random-order map
+bash tools/fetch_ab.sh MSL_SF_DEAL 1 0 > gpurun_out/fetch_ab_$TAG.txt 2>&1
+bash tools/cache_counters.sh $TAG > gpurun_out/cache_counters_$TAG.txt 2>&1
+timeout 300 python bench.py --sequences-per-gpu 2 --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_two_sequences.json 2> gpurun_out/bench_${TAG}_two_sequences.err
+tools/pmc.sh ${TAG}_2seq bench.py --sequences-per-gpu 2 --steps 1 --warmup 1 --passes-per-step 2 --cpu-frames 0 --no-breakdown --no-parity-gate > gpurun_out/pmc_${TAG}_2seq.log 2>&1
+python tools/summarize_pmc.py ${TAG}_2seq > gpurun_out/pmc_${TAG}_2seq/sq_counters.txt 2>&1
+find gpurun_out/pmc_${TAG}_2seq -name "*.csv" -delete
+timeout 300 python bench.py --map-order random --cpu-frames 0 --steps 8 --no-breakdown > gpurun_out/bench_${TAG}_random_order.json 2> gpurun_out/bench_${TAG}_random_order.err
+bash tools/kstat_ab.sh MSL_SF_DEAL 1 0 > gpurun_out/kstat_deal_$TAG.txt 2>&1
 ls gpurun_out/prof_$TAG gpurun_out/pmc_$TAG | head -20
 for f in gpurun_out/bench_$TAG*.json; do echo $f; tail -c 300 $f; echo; done
