@@ -165,6 +165,26 @@ def pmc_traffic(kernel, config):
     return None, f"{os.path.basename(f)} has no counters for {kernel}"
 
 
+def rocprof_clock(kernel, config, alg_bytes):
+    """The roofline fraction on rocprofv3's own clock: the kernel's average duration in the committed --kernel-trace --stats summary of THIS command
+    on THESE kernel sources (profiles/<tag>_summary.json, hash-tied like pmc_traffic).  This is the figure to quote; the event-pair figure of the
+    live run stands beside it.  None when no matching summary is committed."""
+    cur = os.path.join(ROOT, "profiles", "current.txt")
+    if not os.path.exists(cur):
+        return None
+    tag = open(cur).read().strip()
+    f = os.path.join(ROOT, "profiles", f"{tag}_summary.json" if config == "frontend" else f"{tag}_config{config}_summary.json")
+    try:
+        doc = json.load(open(f))
+    except Exception:  # noqa: BLE001
+        return None
+    e = doc.get(kernel)
+    if doc.get("_meta", {}).get("kernel_source_hash") != kernel_source_hash() or not e or not e.get("avg_us"):
+        return None
+    return {"avg_launch_us": e["avg_us"], "calls": e.get("calls"), "frac": round(alg_bytes / (e["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+            "source": os.path.basename(f), "note": "rocprofv3 --kernel-trace --stats of this command on these kernel sources (committed, hash-tied): the clock the roofline claim is made on"}
+
+
 def aggregate(local_ms, counters, world, device=None):
     """max-over-ranks of the timed region + all_gather of the per-sequence counters (RCCL on GPU, gloo on CPU)."""
     import torch
@@ -596,6 +616,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_us": round(launch_s * 1e6, 2),
                      "avg_launch_us_event_pair_raw": round(raw_launch_s * 1e6, 2), "event_pair_empty_kernel_us": round(empty_us, 2) if empty_us else None,
                      "frac_on_raw_event_time": round(alg_bytes / raw_launch_s / 1e9 / HBM_PEAK_GBS, 4) if roof_launches else 0.0,
+                     "rocprofv3": rocprof_clock(roof_kernel, args.config, alg_bytes),
                      "read_write": {"algorithmic_bytes_per_launch": int(alg_bytes + alg_write), "achieved": round(achieved_rw, 1),
                                     "frac": round(achieved_rw / HBM_PEAK_GBS, 4)},
                      "timer": f"HIP events carried by the {roof_kernel} dispatch (hipExtLaunchKernelGGL) on its own stream, "
