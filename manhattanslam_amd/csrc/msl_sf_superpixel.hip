@@ -33,6 +33,20 @@ __device__ __forceinline__ double div100_exact(double x) {
     return fma(fma(-q1, 100.0, x), y, q1);
 }
 
+// Comparisons of a FLOAT x with one of the reference's DOUBLE constants c (HUBER_RANGE 0.4, MAX_ANGLE_COS 0.1, the 0.05 / 0.1 depth limits), which
+// C++ evaluates as (double)x OP c: none of these constants is a float, and for each of them the float nearest to it, cf = (float)c, is the float
+// next ABOVE it (asserted below), so there is no float in [c, cf) and the sets of floats on either side of c and of cf are the same:
+//   (double)x <  c  <=>  x <  cf        (double)x >  -c  <=>  x >  -cf
+//   (double)x >= c  <=>  x >= cf        (double)x <= -c  <=>  x <= -cf        (double)x > c  <=>  x >= cf
+// (NaN: false on both sides.)  One v_cmp_f32 instead of v_cvt_f64_f32 + v_cmp_f64 per test.
+constexpr float float_below(float f) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, f) - 1u); }   // (positive finite f)
+constexpr float HUBER_RANGE_F = (float)HUBER_RANGE, MAX_ANGLE_COS_F = (float)MAX_ANGLE_COS, DEPTH_005_F = 0.05f, DEPTH_01_F = 0.1f;
+static_assert((double)HUBER_RANGE_F > HUBER_RANGE && (double)float_below(HUBER_RANGE_F) < HUBER_RANGE, "0.4f is the float next above 0.4");
+static_assert((double)MAX_ANGLE_COS_F > MAX_ANGLE_COS && (double)float_below(MAX_ANGLE_COS_F) < MAX_ANGLE_COS, "0.1f is the float next above 0.1");
+static_assert((double)DEPTH_005_F > 0.05 && (double)float_below(DEPTH_005_F) < 0.05, "0.05f is the float next above 0.05");
+static_assert((double)DEPTH_01_F > 0.1 && (double)float_below(DEPTH_01_F) < 0.1, "0.1f is the float next above 0.1");
+__device__ __forceinline__ bool in_huber_band(float r) { return r < HUBER_RANGE_F && r > -HUBER_RANGE_F; }   // residual < HUBER_RANGE && residual > -HUBER_RANGE
+
 // Strictly sequential (left-to-right) float sums over 16-byte aligned LDS arrays; wide LDS reads are issued
 // ahead of the dependent add chain so the chain runs at VALU latency instead of LDS latency.  (kb_seed_plane; kb_update_seeds uses the chains below.)
 __device__ __forceinline__ float seq_sum_f32(const float *a, int n, float s) {
@@ -626,7 +640,7 @@ __device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, f
     // back_project of the right / down neighbours with the tabulated quotients: (col+1, row) and (col, row+1)
     float rightX = cx1 * rightDepth, rightY = ryr * rightDepth, rightZ = rightDepth;
     float downX = cxr * downDepth, downY = ry1 * downDepth, downZ = downDepth;
-    if (myZ < 0.1 || rightZ < 0.1 || downZ < 0.1) return;
+    if (myZ < DEPTH_01_F || rightZ < DEPTH_01_F || downZ < DEPTH_01_F) return;   // `< 0.1` (:628): float form, see float_below
     rightX = rightX - myX; rightY = rightY - myY; rightZ = rightZ - myZ;
     downX = downX - myX; downY = downY - myY; downZ = downZ - myZ;
     float normX = rightY * downZ - rightZ * downY;
@@ -635,7 +649,7 @@ __device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, f
     const float normLength = sqrtf(normX * normX + normY * normY + normZ * normZ);
     normX /= normLength; normY /= normLength; normZ /= normLength;
     const float viewAngle = (normX * myX + normY * myY + normZ * myZ) / sqrtf(myX * myX + myY * myY + myZ * myZ);
-    if (viewAngle > -MAX_ANGLE_COS && viewAngle < MAX_ANGLE_COS) return;
+    if (viewAngle > -MAX_ANGLE_COS_F && viewAngle < MAX_ANGLE_COS_F) return;
     nX = normX; nY = normY; nZ = normZ;
 }
 
@@ -644,8 +658,10 @@ __device__ __forceinline__ void pixel_normal(const SfDev &P, int row, int col, f
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov_d(double v) {
     const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
-    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, false);
+    // (bound_ctrl: the row rotations and quad permutes used here give every lane a source lane, so the `old` operand is never read -- without it the
+    // compiler materialises a zero for it in front of every move: 2 of 5 instructions per value and step of group_sum_d)
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xF, 0xF, true);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ double group_sum_d(double v) {
@@ -761,7 +777,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                     const float xDiff = i - S.x, yDiff = jrow - S.y;
                     const float dist = xDiff * xDiff + yDiff * yDiff;
                     if (dist > maxDist) maxDist = dist;
-                    if (dq[m].v[e] > 0.05) vm |= 1u << (4 * m + e);
+                    if (dq[m].v[e] >= DEPTH_005_F) vm |= 1u << (4 * m + e);   // `> 0.05` (:686)
                 }
             }
         nvalid = __popc(vm);
@@ -839,7 +855,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         if (active)
             for (int o = l; o < nvalid; o += 16) {
                 const float residual = meanDepth - pZ[o];
-                c += (residual < HUBER_RANGE && residual > -HUBER_RANGE) ? 1 : 0;
+                c += in_huber_band(residual) ? 1 : 0;
             }
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 16);
@@ -854,7 +870,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             float a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
             if (needCompact && o < nvalid) {
                 const float residual = meanDepth - pZ[o];
-                inl = residual < HUBER_RANGE && residual > -HUBER_RANGE;
+                inl = in_huber_band(residual);
                 a0 = pX[o]; a1 = pY[o]; a2 = pZ[o];
                 b0 = qX[o]; b1 = qY[o]; b2 = qZ[o];
             }
@@ -907,16 +923,25 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         if (active) {
 #pragma unroll 1   // (not unrolled: 128 instead of 130 VGPRs = 3 x 128 per SIMD, which leaves room for two 64-register k_fuse waves instead of one)
             for (int t = 0; t < tRounds; t++) {   // (a wave-uniform bound: the longest inlier list of the four seeds, typically 4-6 of the 16 rounds)
+                // Branch-free for the common case (every point inside the Huber band): a lane without a point in this round, or whose point is outside
+                // the band, adds +0.0 to its four sums -- exact: a sum that starts at +0.0 never becomes -0.0 -- with the coordinates replaced by zeros
+                // BEFORE the products (a NaN / infinite coordinate of a point outside the band must not reach them).  The nested per-lane branches
+                // of the literal form cost four taken branches per round, which one or two waves per SIMD cannot hide.  Points outside the band take the
+                // reference's two tail cases behind ONE wave-uniform test.
                 const int o = l + 16 * t;
-                if (o < ninl) {
-                    const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
-                    const float residual = px * nx + py * ny + pz * nz + nb;
-                    if (residual < HUBER_RANGE && residual > -1 * HUBER_RANGE) {
-                        mask |= 1u << t;
-                        J0 += 2 * residual * px; J1 += 2 * residual * py; J2 += 2 * residual * pz; J3 += 2 * residual;
-                    } else if (residual >= HUBER_RANGE) {
+                const bool has = o < ninl;
+                const int oc = has ? o : 0;
+                const float px = pX[oc] - sumX, py = pY[oc] - sumY, pz = pZ[oc] - sumZ;
+                const float residual = px * nx + py * ny + pz * nz + nb;
+                const bool inb = has && in_huber_band(residual);
+                mask |= (inb ? 1u : 0u) << t;
+                const float r2 = inb ? 2 * residual : 0.0f;
+                const float qx = inb ? px : 0.0f, qy = inb ? py : 0.0f, qz = inb ? pz : 0.0f;
+                J0 += r2 * qx; J1 += r2 * qy; J2 += r2 * qz; J3 += r2;
+                if (__builtin_expect(__ballot(has && !inb) != 0ull, 0)) {
+                    if (has && residual >= HUBER_RANGE_F) {
                         J0 += HUBER_RANGE * px; J1 += HUBER_RANGE * py; J2 += HUBER_RANGE * pz; J3 += HUBER_RANGE;
-                    } else if (residual <= -1 * HUBER_RANGE) {
+                    } else if (has && residual <= -HUBER_RANGE_F) {
                         J0 += -1 * HUBER_RANGE * px; J1 += -1 * HUBER_RANGE * py; J2 += -1 * HUBER_RANGE * pz; J3 += -1 * HUBER_RANGE;
                     }
                 }
@@ -930,14 +955,15 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             double H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
             if (active && diffGroups) {
 #pragma unroll 1
-                for (int t = 0; t < tRounds; t++)
-                    if (mask & (1u << t)) {
-                        const int o = l + 16 * t;
-                        const float px = pX[o] - sumX, py = pY[o] - sumY, pz = pZ[o] - sumZ;
-                        H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
-                        H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
-                        H22 += 2 * pz * pz; H23 += 2 * pz; H33 += 2;
-                    }
+                for (int t = 0; t < tRounds; t++) {   // (branch-free like the Jacobian loop: a lane without an in-band point in this round adds zeros)
+                    const bool inb = (mask >> t) & 1u;
+                    const int oc = inb ? l + 16 * t : 0;
+                    const float rx = pX[oc] - sumX, ry = pY[oc] - sumY, rz = pZ[oc] - sumZ;
+                    const float px = inb ? rx : 0.0f, py = inb ? ry : 0.0f, pz = inb ? rz : 0.0f;
+                    H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
+                    H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
+                    H22 += 2 * pz * pz; H23 += 2 * pz; H33 += inb ? 2.0 : 0.0;
+                }
             }
             H00 = group_sum_d(H00); H01 = group_sum_d(H01); H02 = group_sum_d(H02); H03 = group_sum_d(H03);
             H11 = group_sum_d(H11); H12 = group_sum_d(H12); H13 = group_sum_d(H13);
