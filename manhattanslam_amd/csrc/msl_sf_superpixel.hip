@@ -394,6 +394,26 @@ __device__ __forceinline__ int row_incl_scan(int v) {
     return v;
 }
 
+// 16-lane (DPP row = seed group) exchanges in the VALU instead of __shfl / __shfl_xor, which compile to ds_bpermute: a trip through the LDS crossbar per
+// value (plus the address arithmetic in front of it and a dependent wait behind it) where a DPP move or operand costs one VALU slot and a few cycles.
+// Only controls that give EVERY lane a source lane (row rotations, quad permutes, row_newbcast), so `old` is never read (bound_ctrl).
+template <int CTRL> __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dpp_f32(float v) { return __int_as_float(dpp_i32<CTRL>(__float_as_int(v))); }
+template <int N> __device__ __forceinline__ int row_lane_i32(int v) { return dpp_i32<0x150 + N>(v); }      // lane N of the row, to all its lanes (row_newbcast)
+template <int N> __device__ __forceinline__ float row_lane_f32(float v) { return dpp_f32<0x150 + N>(v); }
+// sum / maximum over the 16 lanes of a row, every lane receives it: row_ror:8, row_ror:4, quad_perm [2,3,0,1], quad_perm [1,0,3,2].  For integers, and for
+// floats whose partial sums are all exact (integer-valued sums below 2^24), any order gives the same result as the xor butterfly this replaces.
+__device__ __forceinline__ int row_sum_i32(int v) { v += dpp_i32<0x128>(v); v += dpp_i32<0x124>(v); v += dpp_i32<0x4E>(v); v += dpp_i32<0xB1>(v); return v; }
+__device__ __forceinline__ float row_sum_exact_f32(float v) { v += dpp_f32<0x128>(v); v += dpp_f32<0x124>(v); v += dpp_f32<0x4E>(v); v += dpp_f32<0xB1>(v); return v; }
+__device__ __forceinline__ float row_max_f32(float v) {
+    v = fmaxf(v, dpp_f32<0x128>(v)); v = fmaxf(v, dpp_f32<0x124>(v)); v = fmaxf(v, dpp_f32<0x4E>(v)); v = fmaxf(v, dpp_f32<0xB1>(v));
+    return v;
+}
+// maximum over the four rows of a wave of a value that is uniform inside each row: a scalar
+__device__ __forceinline__ int rows_max_i32(int v) {
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
 // kb_update_seeds (:428-515): 16 lanes per seed (lane = window row), 16 seeds per workgroup.
 // Integer-valued sums are exact in any order; the float depth sum and the Huber/Newton sums run in window raster order as rotating DPP chains
 // over the seed's 16 lanes (chain_block_f32 above), fed by terms each lane computes from its own elements of the ordered depth list.
@@ -474,7 +494,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             for (int e = 0; e < 4; e++) {
                 const int col = colc + e;
                 const bool own = rowOk && (!STRADDLE || col >= col0) && col >= xb && col < xe && idq[m].v[e] == seedI;
-                hd[e] = own && dq[m].v[e] > 0.1;
+                hd[e] = own && dq[m].v[e] >= DEPTH_01_F;   // `> 0.1` (:452), float form (float_below)
                 if (own) { sumX += col; sumY += j; sumI += gq[m].v[e]; cnt++; }
                 c += hd[e] ? 1 : 0;
             }
@@ -483,15 +503,11 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 #pragma unroll
             for (int e = 0; e < 4; e++)
                 if (hd[e]) s_depth[g][o++] = dq[m].v[e];
-            nd += __shfl(incl, g15, 64);
+            nd += row_lane_i32<15>(incl);
         }
     }
     USTAMP();   // 1: seed record + window gather + ordered depth list
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) {
-        sumX += __shfl_xor(sumX, d, 16); sumY += __shfl_xor(sumY, d, 16);
-        sumI += __shfl_xor(sumI, d, 16); cnt += __shfl_xor(cnt, d, 16);
-    }
+    sumX = row_sum_exact_f32(sumX); sumY = row_sum_exact_f32(sumY); sumI = row_sum_exact_f32(sumI); cnt = row_sum_i32(cnt);   // (integer-valued: exact in any order)
     __builtin_amdgcn_wave_barrier();
     // what this update changes of the seed record (the record itself is read again for the final stores: 12 registers less through the gather above,
     // where the kernel's register count peaks)
@@ -516,11 +532,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     // ---- mean depth and its Huber refinement (:486-512): the sequential sums as rotating chains (above); everything per seed is uniform over its
     // 16 lanes and lives in registers -- no LDS, no atomics, no barriers in the Newton loop ----
     const int ndL = depthLoop ? nd : 0;                 // a seed without a depth loop contributes empty lists
-    int nblk = (ndL + 15) >> 4;
-#pragma unroll
-    for (int d = 32; d >= 16; d >>= 1) nblk = max(nblk, __shfl_xor(nblk, d, 64));
-    nblk = __builtin_amdgcn_readfirstlane(nblk);       // blocks of the longest list of the wave's four seeds
-    const int g15r = (threadIdx.x & 48) | 15;
+    const int nblk = rows_max_i32((ndL + 15) >> 4);    // blocks of the longest list of the wave's four seeds
     float meanDepth = 0.0f;
     {
         float sd = 0.0f;
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             const int e = l + 16 * bq;
             sd = chain_block_f32(sd, e < ndL ? s_depth[g][e] : 0.0f);
         }
-        const float sumDepth = __shfl(sd, g15r, 64);
+        const float sumDepth = row_lane_f32<15>(sd);
         if (depthLoop) meanDepth = sumDepth / (float)nd;
     }
     USTAMP();   // 2: means, colour fetch, sequential depth sum
@@ -542,11 +554,10 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             const int e = l + 16 * bq;
             if (open && e < ndL) {
                 const float residual = meanDepth - s_depth[g][e];
-                if (residual < HUBER_RANGE && residual > -HUBER_RANGE) inr++; else tail = true;
+                if (in_huber_band(residual)) inr++; else tail = true;
             }
         }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) inr += __shfl_xor(inr, d, 16);
+        inr = row_sum_i32(inr);
         const bool anyTail = __ballot(tail) != 0ull;
         // pass 2: the chain over the terms -- in range: 2*residual; a tail element: the +-inf marker huber_term_add() turns into +-HUBER_RANGE
         float sa = 0.0f;
@@ -555,13 +566,13 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             float t = 0.0f;
             if (open && e < ndL) {
                 const float residual = meanDepth - s_depth[g][e];
-                if (residual < HUBER_RANGE && residual > -HUBER_RANGE) t = 2 * residual;
+                if (in_huber_band(residual)) t = 2 * residual;
                 else t = residual > 0 ? __builtin_inff() : -__builtin_inff();
             }
             // no Huber tails anywhere in the wave (the common case): a plain float chain, 1 VALU op per element instead of ~8
             sa = anyTail ? chain_block_huber(sa, t) : chain_block_f32(sa, t);
         }
-        const float sumA = __shfl(sa, g15r, 64);
+        const float sumA = row_lane_f32<15>(sa);
         const float sumB = (float)(2 * inr);
         const float deltaDepth = (float)((double)(-sumA) / ((double)sumB + 10.0));
         if (open) {
@@ -782,14 +793,13 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             }
         nvalid = __popc(vm);
         SECTION_STAMP();   // 1a: window loads arrived, ownership tests
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) nvalid += __shfl_xor(nvalid, d, 16);
+        nvalid = row_sum_i32(nvalid);
         {   // list bases inside the pool: multiples of 4 entries (16-byte reads of the sequential sums), and the second list of each 32-lane half
             // 16 banks away from the first one (mod 32) -- the loops below read entry base + l + 16 t with ds_read_b32, whose lane groups are the two
             // halves of the wave and whose bank is the word address mod 32: with arbitrary bases the two seeds of a half collided on every access
             // (round 4: 27 % of the kernel's LDS cycles were bank conflicts)
             const int pad = (nvalid + 3) & ~3;
-            const int n0 = __shfl(pad, 0, 64), n1 = __shfl(pad, 16, 64), n2 = __shfl(pad, 32, 64), n3 = __shfl(pad, 48, 64);
+            const int n0 = __builtin_amdgcn_readlane(pad, 0), n1 = __builtin_amdgcn_readlane(pad, 16), n2 = __builtin_amdgcn_readlane(pad, 32), n3 = __builtin_amdgcn_readlane(pad, 48);
             const int b1 = n0 + ((16 - n0) & 31), b2 = b1 + n1, b3 = b2 + n2 + ((16 - n2) & 31);   // b1 = 16 (mod 32) relative to b0 = 0; b3 likewise to b2
             base = g == 0 ? 0 : g == 1 ? b1 : g == 2 ? b2 : b3;
             poolUsed = b3 + n3;
@@ -797,7 +807,6 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             const int padEnd = g == 0 ? b1 : g == 1 ? b2 : g == 2 ? b3 : b3 + n3;
             for (int q = base + nvalid + l; q < padEnd; q += 16) { s_pool[2][q] = 0.0f; s_pool[3][q] = 0.0f; s_pool[4][q] = 0.0f; s_pool[5][q] = 0.0f; }
         }
-        const int g15 = (lane & 48) | 15;
         int run = base;
 #pragma unroll
         for (int m = 0; m < 4; m++) {   // ordered compaction in window raster order = (iteration, lane, element)
@@ -820,14 +829,13 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                     s_pool[4][o] = ddq[m].v[e]; s_pool[5][o] = __int_as_float(rce);
                     o++;
                 }
-            run += __shfl(incl, g15, 64);
+            run += row_lane_i32<15>(incl);
         }
     }
     SECTION_STAMP();   // 1: gather + ordered lists
     float *const pX = s_pool[0] + base, *const pY = s_pool[1] + base, *const pZ = s_pool[2] + base;
     float *const qX = s_pool[3] + base, *const qY = s_pool[4] + base, *const qZ = s_pool[5] + base;
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) maxDist = fmaxf(maxDist, __shfl_xor(maxDist, d, 16));
+    maxDist = row_max_f32(maxDist);
     __builtin_amdgcn_wave_barrier();
     // entry e -> position + cross-product normal, written back in place (order preserved).  The work per entry does not depend on the seed, so
     // the 64 lanes walk the whole pool together: ceil(pool / 64) rounds instead of ceil(longest list / 16) -- the four superpixels of a wave
@@ -857,9 +865,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                 const float residual = meanDepth - pZ[o];
                 c += in_huber_band(residual) ? 1 : 0;
             }
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 16);
-        ninl = c;
+        ninl = row_sum_i32(c);
     }
     const bool needCompact = active && ninl != nvalid;
     if (__ballot(needCompact)) {
@@ -893,9 +899,8 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     {
         float acc = 0.0f;
         if (active && l < 6) acc = seq_sum_f32(s_pool[l < 3 ? 3 + l : l - 3] + base, ninl, 0.0f);
-        const int gb = lane & 48;
-        normX = __shfl(acc, gb + 0, 64); normY = __shfl(acc, gb + 1, 64); normZ = __shfl(acc, gb + 2, 64);
-        sumX = __shfl(acc, gb + 3, 64); sumY = __shfl(acc, gb + 4, 64); sumZ = __shfl(acc, gb + 5, 64);
+        normX = row_lane_f32<0>(acc); normY = row_lane_f32<1>(acc); normZ = row_lane_f32<2>(acc);
+        sumX = row_lane_f32<3>(acc); sumY = row_lane_f32<4>(acc); sumZ = row_lane_f32<5>(acc);
         const float normLength = sqrtf(normX * normX + normY * normY + normZ * normZ);
         normX = normX / normLength; normY = normY / normLength; normZ = normZ / normLength;
         sumX /= ninl; sumY /= ninl; sumZ /= ninl;
@@ -913,10 +918,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int r0 = ca == 0 ? 1 : 0, r1 = ca <= 1 ? 2 : 1, r2 = ca <= 2 ? 3 : 2;
     const int c0 = cb == 0 ? 1 : 0, c1 = cb <= 1 ? 2 : 1, c2 = cb <= 2 ? 3 : 2;
     const int gbase = lane & 48;
-    int tRounds = active ? (ninl + 15) >> 4 : 0;
-#pragma unroll
-    for (int d = 32; d >= 16; d >>= 1) tRounds = max(tRounds, __shfl_xor(tRounds, d, 64));   // ninl is uniform inside a group of 16 lanes
-    tRounds = __builtin_amdgcn_readfirstlane(tRounds);
+    const int tRounds = rows_max_i32(active ? (ninl + 15) >> 4 : 0);   // (ninl and active are uniform inside a group of 16 lanes)
     for (int gnI = 0; gnI < 5; gnI++) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
         unsigned mask = 0;
@@ -981,8 +983,7 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
                                   M_(r0, c1) * (M_(r1, c0) * M_(r2, c2) - M_(r1, c2) * M_(r2, c0)) +
                                   M_(r0, c2) * (M_(r1, c0) * M_(r2, c1) - M_(r1, c1) * M_(r2, c0));
                 const double cof = ((ca + cb) & 1) ? -d3 : d3;
-                const double f0 = __shfl(cof, gbase + 0, 64), f1 = __shfl(cof, gbase + 1, 64), f2 = __shfl(cof, gbase + 2, 64),
-                             f3 = __shfl(cof, gbase + 3, 64);
+                const double f0 = dpp_mov_d<0x150>(cof), f1 = dpp_mov_d<0x151>(cof), f2 = dpp_mov_d<0x152>(cof), f3 = dpp_mov_d<0x153>(cof);   // lanes 0..3 of the group
                 const double det = ((M_(0, 0) * f0 + M_(0, 1) * f1) + M_(0, 2) * f2) + M_(0, 3) * f3;
 #undef M_
                 if (diffGroups) invl = cof / det;
@@ -991,11 +992,11 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         }
         // upd[r] = ((inv[0*4+r] J0 + inv[1*4+r] J1) + inv[2*4+r] J2) + inv[3*4+r] J3; lane l holds inv[l], its column is l >> 2
         const double prod = invl * (ca == 0 ? J0 : ca == 1 ? J1 : ca == 2 ? J2 : J3);
-        const double q1 = __shfl(prod, gbase + 4 + cb, 64), q2 = __shfl(prod, gbase + 8 + cb, 64), q3 = __shfl(prod, gbase + 12 + cb, 64);
-        const double q0 = __shfl(prod, gbase + cb, 64);
-        const double updr = ((q0 + q1) + q2) + q3;            // lane with cb == r now holds upd[r]
-        const double u0 = __shfl(updr, gbase + 0, 64), u1 = __shfl(updr, gbase + 1, 64), u2 = __shfl(updr, gbase + 2, 64),
-                     u3 = __shfl(updr, gbase + 3, 64);
+        // lanes r = 0..3 of the group (column 0, row r) collect their row: lane r + 4 a holds the term of column a -- row_ror:n hands lane i the value of
+        // lane i - n (mod 16), so n = 12, 8, 4 fetch the lanes 4, 8, 12 ahead; the other lanes compute sums nobody reads
+        const double q0 = prod, q1 = dpp_mov_d<0x12C>(prod), q2 = dpp_mov_d<0x128>(prod), q3 = dpp_mov_d<0x124>(prod);
+        const double updr = ((q0 + q1) + q2) + q3;            // lane r < 4 of the group now holds upd[r]
+        const double u0 = dpp_mov_d<0x150>(updr), u1 = dpp_mov_d<0x151>(updr), u2 = dpp_mov_d<0x152>(updr), u3 = dpp_mov_d<0x153>(updr);
         nx = (float)((double)nx - u0); ny = (float)((double)ny - u1); nz = (float)((double)nz - u2); nb = (float)((double)nb - u3);
         SECTION_STAMP();   // 5-9: Gauss-Newton steps
     }
