@@ -483,7 +483,6 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
             dq[m] = load_quad(F.depthG() + (size_t)jc * P.dstride + colc);
             gq[m] = load_quad(F.grayG() + (size_t)jc * P.gstride + colc);
         }
-        const int g15 = (threadIdx.x & 48) | 15;
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int j = yb0 + 4 * m + rq;
@@ -693,6 +692,8 @@ __device__ __forceinline__ double group_sum_d(double v) {
 // LDS: one pool per wave.  The four seeds of a wave form a 2x2 block of the seed lattice, so their 16x16 windows cover
 // 24x24 = 576 distinct pixels; every pixel belongs to one seed, hence the four ordered lists hold <= 576 entries in total
 // (+ 3 x 3 for 16-byte alignment of each list) instead of 4 x 256.  14 KB per wave: 11 waves per CU instead of 5.
+struct PlaneFit { int active; float nx, ny, nz, nb, sumX, sumY, sumZ, maxDist; };   // kb_seed_plane -> kb_seed_finish, in the seed's slot of SfDev::cand
+static_assert(sizeof(PlaneFit) <= sizeof(msl_surfel), "the hand-over record fits a candidate slot");
 constexpr int PLANE_POOL = 24 * 24 + 12 + 2 * 28;   // + the bank-phase gaps in front of the second list of each half
 template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} -- a window quad can stick out over the right edge (instantiated separately: the common
                            // geometry carries none of that code)
@@ -719,9 +720,9 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     SECTION_STAMP();   // 0a: kernel arguments + frame record
 #endif
     const unsigned short *index = P.index + (size_t)slot * P.pxStride;
-    msl_seed S;
-    memset(&S, 0, sizeof(S));
-    if (inRange) S = P.seeds[(size_t)slot * P.nseeds + seedI];
+    // (unconditionally: a group outside the lattice reads seed 0 -- seedI = 0 above -- and never uses or stores it; the zero-filled record the
+    // conditional load needed cost 84 select instructions)
+    const msl_seed S = P.seeds[(size_t)slot * P.nseeds + seedI];
 #ifdef MSL_FUSE_STAMPS
     asm volatile("" :: "v"(S.x), "v"(S.meanDepth));
     SECTION_STAMP();   // 0b: seed record
@@ -917,7 +918,6 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int ca = l >> 2, cb = l & 3;
     const int r0 = ca == 0 ? 1 : 0, r1 = ca <= 1 ? 2 : 1, r2 = ca <= 2 ? 3 : 2;
     const int c0 = cb == 0 ? 1 : 0, c1 = cb <= 1 ? 2 : 1, c2 = cb <= 2 ? 3 : 2;
-    const int gbase = lane & 48;
     const int tRounds = rows_max_i32(active ? (ninl + 15) >> 4 : 0);   // (ninl and active are uniform inside a group of 16 lanes)
     for (int gnI = 0; gnI < 5; gnI++) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
@@ -1006,7 +1006,30 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         atomicAdd(&P.delList[64], 1u);
     }
 #endif
+    // The per-seed rest -- the plane's normalisation, the seed record, FuseRec and the candidate surfel: ~310 instructions that only ONE lane of a
+    // seed's sixteen would execute here (4 of 64 lanes busy) -- runs in kb_seed_finish, one thread per seed.  What it needs of this kernel travels in the
+    // seed's slot of the candidate array, which kb_seed_finish itself overwrites afterwards.
     if (!inRange || l != 0) return;
+    PlaneFit T;
+    T.active = active ? 1 : 0; T.nx = nx; T.ny = ny; T.nz = nz; T.nb = nb; T.sumX = sumX; T.sumY = sumY; T.sumZ = sumZ; T.maxDist = maxDist;
+    __builtin_memcpy(reinterpret_cast<char *>(P.cand + ((size_t)slot * P.nseeds + seedI)), &T, sizeof(T));
+}
+
+// kb_seed_finish: the end of calculateNorms for one seed (:744-773: plane normalisation, the seed's position on the plane, viewCos, size), then what the
+// map stage reads of the seed (FuseRec) and the surfel it would spawn (initializeSurfels, :291-329).  One thread per seed; same expressions, same
+// operands as the reference, fed by the fit kb_seed_plane left in the seed's candidate slot.
+__global__ __launch_bounds__(256) void kb_seed_finish(SfDev P) {
+    const int slot = blockIdx.y;
+    const int seedI = blockIdx.x * 256 + threadIdx.x;
+    if (seedI >= P.nseeds) return;
+    const FrameDev &F = P.frames[slot];
+    msl_seed S = P.seeds[(size_t)slot * P.nseeds + seedI];
+    PlaneFit T;
+    __builtin_memcpy(&T, reinterpret_cast<const char *>(P.cand + ((size_t)slot * P.nseeds + seedI)), sizeof(T));
+    const bool active = T.active != 0;
+    float nx = T.nx, ny = T.ny, nz = T.nz, nb = T.nb;
+    const float sumX = T.sumX, sumY = T.sumY, sumZ = T.sumZ, maxDist = T.maxDist;
+    float normX, normY, normZ, meanDepth = S.meanDepth;
     if (active) {
         nb = nb - (nx * sumX + ny * sumY + nz * sumZ);
         {
@@ -1170,9 +1193,12 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
     // beside the slimmer kb_update_seeds: 10 waves 21.9 k, 9 waves 23.1-23.3 k, 8 waves 22.8-23.1 k, 7 waves 23.3-23.5 k, 6 waves 22.8 k, 5 waves
     // 22.5 k.  The kernel alone is no slower with fewer waves (its waves are VALU-latency bound), and the wave slots, registers and LDS it leaves
     // go to the ORB kernels and to the map stage that run beside it.
+    // round 6, after the per-seed epilogue moved to kb_seed_finish (88 VGPRs, 339 us per launch at this cap): 10 waves per CU 281 us / 21.9 k frames/s, 8 waves
+    // 306 us / 23.2-23.4 k, 7 waves 339 us / 24.0-24.2 k, 6 waves 384 us / 23.9 k -- the sweet spot did not move
     constexpr unsigned planePad = 6144;
     if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<true>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     else MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<false>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
+    hipLaunchKernelGGL(kb_seed_finish, seedGrid, dim3(256), 0, sp, P);
     if ((W % SP) || (H % SP)) {   // pixels outside the whole cells (sizes that are not multiples of 8)
         const int nStrip = (W - P.spW * SP) * P.spH * SP + W * (H - P.spH * SP);
         hipLaunchKernelGGL(kb_tex_strips, dim3((unsigned)((nStrip + 255) / 256), un), dim3(256), 0, sp, P);
