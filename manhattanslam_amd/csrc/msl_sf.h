@@ -123,6 +123,7 @@ struct SfDev {
     int W, H, spW, spH, nseeds, npx;   // npx = W * H (the flat pixel index range of the reference); spW = W / 8, spH = H / 8 (truncated, :29-38)
     float fx, fy, cx, cy, fuseFar, fuseNear;
     unsigned long long gstride, gbytes, dstride, mstride;   // gray bytes, depth floats, member ints
+    unsigned gsB, dsB, msB;      // the same row strides in BYTES as 32-bit numbers (run_batch refuses images whose rows span 4 GB or more): byte_off() below
     const FrameDev *frames;      // [slots]
     msl_seed *seeds, *seedsTmp;  // [slots][nseeds]
     msl_surfel *cand;            // [slots][nseeds] world-frame surfel a seed would spawn
@@ -184,8 +185,22 @@ __device__ __forceinline__ int seed_chunk(int seedI, int nseeds) {   // THREAD_N
     const int c = seedI / step;
     return c > NCHUNK - 1 ? NCHUNK - 1 : c;
 }
-__device__ __forceinline__ uint8_t gray_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.grayG()[(size_t)y * P.gstride + x]; }
-__device__ __forceinline__ float depth_at(const SfDev &P, const FrameDev &F, int y, int x) { return F.depthG()[(size_t)y * P.dstride + x]; }
+// The element `off` BYTES behind a global pointer.  With a 32-bit unsigned offset a load takes the scalar-base + vector-offset form: one 32-bit multiply-add per
+// address instead of a 64-bit multiply, add, shift and add (five to sixteen instructions per load in the frame-batched kernels, which issue 8 - 17 loads per lane).
+template <typename T> __device__ __forceinline__ gptr<T> byte_off(gptr<T> p, unsigned off) {
+    return reinterpret_cast<gptr<T>>(reinterpret_cast<const char __attribute__((address_space(1))) *>(p) + off);
+}
+template <typename T> __device__ __forceinline__ gptr<T> byte_off(const T *p, unsigned off) { return byte_off((gptr<T>)p, off); }   // (a pointer into global memory)
+template <typename T> using gptr_w = T __attribute__((address_space(1))) *;
+template <typename T> __device__ __forceinline__ gptr_w<T> byte_off_w(T *p, unsigned off) {   // the same for stores
+    return reinterpret_cast<gptr_w<T>>(reinterpret_cast<char __attribute__((address_space(1))) *>((gptr_w<T>)p) + off);
+}
+// (non-negative in-image coordinates)
+__device__ __forceinline__ uint8_t gray_at(const SfDev &P, const FrameDev &F, int y, int x) { return *byte_off(F.grayG(), (unsigned)y * P.gsB + (unsigned)x); }
+__device__ __forceinline__ float depth_at(const SfDev &P, const FrameDev &F, int y, int x) { return *byte_off(F.depthG(), (unsigned)y * P.dsB + 4u * (unsigned)x); }
+__device__ __forceinline__ int32_t member_at(const SfDev &P, const FrameDev &F, int y, int x) {   // membershipImg(y / 2, x / 2)
+    return *byte_off(F.memberG(), ((unsigned)y >> 1) * P.msB + 4u * ((unsigned)x >> 1));
+}
 __device__ __forceinline__ void vec3b(const SfDev &P, const FrameDev &F, float row, float col, int &r, int &g, int &b) {
     const unsigned long long off = (unsigned long long)(int)row * P.gstride + 3ull * (unsigned long long)(int)col;
     r = off < P.gbytes ? F.grayG()[off] : 0;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void kb_seed_init(SfDev P) {
     msl_seed s;
     memset(&s, 0, sizeof(s));
     P.fused[(size_t)slot * P.flagStride + seedI] = 0;
-    if (F.memberG()[(size_t)(imageY / 2) * P.mstride + imageX / 2] != -1) {
+    if (member_at(P, F, imageY, imageX) != -1) {
         P.seeds[(size_t)slot * P.nseeds + seedI] = s; P.arec[(size_t)slot * P.nseeds + seedI] = assign_rec(s);
         return;
     }
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots, in
         const int rowI = 8 * (by0 + k) + 4 + ly;
         inImg[k] = colIn && rowI >= 0 && rowI < P.H && by0 + k + 1 < nby;
         const int rowC = min(max(rowI, 0), P.H - 1), colC = min(max(colI, 0), P.W - 1), pc = rowC * P.W + colC;   // (a clamped address: loaded, never used)
-        mem[k] = F.memberG()[(size_t)(rowC / 2) * P.mstride + colC / 2];
+        mem[k] = member_at(P, F, rowC, colC);
         gI[k] = gray_at(P, F, rowC, colC);
-        dIn[k] = it == 0 ? depth_at(P, F, rowC, colC) : pxInv[pc];
-        cur[k] = it == 0 ? 0 : (int)index[pc];
+        dIn[k] = it == 0 ? depth_at(P, F, rowC, colC) : *byte_off(pxInv, 4u * (unsigned)pc);
+        cur[k] = it == 0 ? 0 : (int)*byte_off(index, 2u * (unsigned)pc);
     }
 #pragma unroll
     for (int k = 0; k < ASSIGN_NY; k++)
-        tCur[k] = it == 0 ? 0u : tmin[cur[k]];   // (a plain load: 0 stays 0 and non-zero stays non-zero during the pass, so a stale line answers the same)
+        tCur[k] = it == 0 ? 0u : *byte_off(tmin, 4u * (unsigned)cur[k]);   // (a plain load: 0 stays 0 and non-zero stays non-zero during the pass, so a stale line answers the same)
     // ---- per cell: the four cost evaluations ----
 #pragma unroll
     for (int k = 0; k < ASSIGN_NY; k++) {
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots, in
         if (it == 0) {
             myInvDepth = 0.0f;
             if (dIn[k] > 0.01) myInvDepth = (float)(1.0 / (double)dIn[k]);
-            if (inImg[k] && !isPlane) pxInv[p] = myInvDepth;
+            if (inImg[k] && !isPlane) *byte_off_w(pxInv, 4u * (unsigned)p) = myInvDepth;
         }
         const bool pxHasDepth = myInvDepth > 0;
         const double myInvD = (double)myInvDepth;
@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256) void kb_assign(SfDev P, int it, int nSlots, in
         if (okx1 && oky1) consider(cr[k + 1][1], rowIdx[k + 1] + 1, lx != 0 && ly != 0);
         const int pick = allHasDepth ? minSpIndexDepth : minSpIndexNodepth;
         if (!inImg[k]) continue;
-        if (it == 0) { index[p] = isPlane ? (unsigned short)0 : (unsigned short)(pick >= 0 ? pick : 0); continue; }
-        amap[p] = isPlane ? IDX_PLANE : (pick >= 0 ? (unsigned short)pick : IDX_NONE);
+        if (it == 0) { *byte_off_w(index, 2u * (unsigned)p) = isPlane ? (unsigned short)0 : (unsigned short)(pick >= 0 ? pick : 0); continue; }
+        *byte_off_w(amap, 2u * (unsigned)p) = isPlane ? IDX_PLANE : (pick >= 0 ? (unsigned short)pick : IDX_NONE);
         if (!isPlane && pick >= 0) {
             // the current seed is unstable at pass start <=> t(cur) == 0 (kb_update_seeds / kb_commit_seeds left 0 or T_INF, and this pass
             // only ever lowers a t to p + 1 >= 1, so a value read at any time during the pass answers the same)
@@ -479,9 +479,9 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             const int jc = min(max(yb0 + 4 * m + rq, 0), P.H - 1);
-            idq[m] = load_quad(index + (size_t)jc * P.W + colc);
-            dq[m] = load_quad(F.depthG() + (size_t)jc * P.dstride + colc);
-            gq[m] = load_quad(F.grayG() + (size_t)jc * P.gstride + colc);
+            idq[m] = load_quad(byte_off(index, 2u * (unsigned)(jc * P.W + colc)));
+            dq[m] = load_quad(byte_off(F.depthG(), (unsigned)jc * P.dsB + 4u * (unsigned)colc));
+            gq[m] = load_quad(byte_off(F.grayG(), (unsigned)jc * P.gsB + (unsigned)colc));
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -751,10 +751,10 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             const int wr = yb + 4 * m + rq + wrapRow;
             const int row = min(max(wr, 0), P.H - 1);     // rows outside the image fail the flat-index test below
             if (!straddle) {
-                idq[m] = load_quad(index + (size_t)row * P.W + wcol0);
-                dq[m] = load_quad(F.depthG() + (size_t)row * P.dstride + wcol0);
-                ddq[m] = load_quad(F.depthG() + (size_t)min(row + 1, P.H - 1) * P.dstride + wcol0);
-                dr3[m] = F.depthG()[(size_t)row * P.dstride + min(wcol0 + 4, P.W - 1)];
+                idq[m] = load_quad(byte_off(index, 2u * (unsigned)(row * P.W + wcol0)));
+                dq[m] = load_quad(byte_off(F.depthG(), (unsigned)row * P.dsB + 4u * (unsigned)wcol0));
+                ddq[m] = load_quad(byte_off(F.depthG(), (unsigned)min(row + 1, P.H - 1) * P.dsB + 4u * (unsigned)wcol0));
+                dr3[m] = *byte_off(F.depthG(), (unsigned)row * P.dsB + 4u * (unsigned)min(wcol0 + 4, P.W - 1));
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {

@@ -300,6 +300,10 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         set_error("msl_sf: bad image pointers or strides");
         return MSL_ERR_INVALID;
     }
+    if (gs * (size_t)H >= (1ull << 32) || ds * (size_t)H >= (1ull << 32) || ms * (size_t)((H + 1) / 2) >= (1ull << 32)) {   // (the kernels address an image with 32-bit byte offsets)
+        set_error("msl_sf: image rows span 4 GB or more");
+        return MSL_ERR_INVALID;
+    }
     if (compact) {
         h->mirrorValid = false;   // the resident map moves on without the host-vector caller
         // The reference's mvLocalSurfels is an unbounded std::vector (include/Map.h:130): grow the resident map before a batch could
@@ -324,6 +328,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
     hipStream_t sp = h->preStream, sm = h->mapStream;
     if (h->evMapValid[set] && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evMap[set], 0));   // the set's previous user is done
     D.gstride = gs; D.gbytes = gs * (size_t)(H - 1) + W; D.dstride = ds / 4; D.mstride = ms / 4;
+    D.gsB = (unsigned)gs; D.dsB = (unsigned)ds; D.msB = (unsigned)ms;
     // bytes actually present in the caller's buffers: the last row carries no stride padding
     const size_t d16b = d16 ? d16s * (size_t)(H - 1) + (size_t)W * 2 : 0;
     const size_t gb = gs * (size_t)(H - 1) + W, db = ds * (size_t)(H - 1) + (size_t)W * 4, mb = ms * (size_t)((H + 1) / 2 - 1) + (size_t)((W + 1) / 2) * 4;   // the membership image is ceil(H / 2) x ceil(W / 2) (PlaneDetection's cloud size)
