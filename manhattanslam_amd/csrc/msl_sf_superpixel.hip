@@ -419,6 +419,16 @@ __device__ __forceinline__ int rows_max_i32(int v) {
 // over the seed's 16 lanes (chain_block_f32 above), fed by terms each lane computes from its own elements of the ordered depth list.
 // Round 5: 56 VGPRs and 17 KB of LDS (rounds 2-4: 80 and 35 KB -- the term list, the per-seed LDS scalars and their atomics are gone): 8 instead
 // of 4 workgroups per CU for a kernel whose waves mostly wait (13.5 -> 6.9 us per frame beside the other stages, front end +3.7 %).
+// What kb_update_seeds leaves for kb_commit_seeds in the seed's record of seedsTmp[] (round 6): the per-seed scalar rest of updateSeedsKernel -- three
+// divisions, the colour fetch, the stability test, the new seed record and its AssignRec with an FP64 division: ~130 instructions that ONE lane of a
+// seed's sixteen executed -- runs there, one thread per seed.
+struct SeedUpd {
+    int state;            // 0: skipped (unused or stable: kb_update_seeds wrote what changes); 1: no pixel owned, the seed ends its chunk (:473-474); 2: update
+    int cnt, sumI, sumX, sumY;   // the integer-valued sums (:461-464)
+    int depthLoop;        // the seed has valid depths: meanDepth below is the refined mean (:486-512), otherwise 0 goes to the record (:489-490)
+    float meanDepth;
+};
+static_assert(sizeof(SeedUpd) <= sizeof(msl_seed), "the hand-over record fits a seedsTmp record");
 template <bool STRADDLE>   // STRADDLE: W mod 8 in {1, 2, 3} (a window quad can stick out over the right edge)
 __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlots) {
     // rows of 256 + 16 words: the two seeds of a 32-lane half read / write entry l + 16 t of their own row together (ds_*_b32: bank = word address mod
@@ -444,13 +454,13 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     if (active) {
         S = P.seeds[(size_t)slot * P.nseeds + seedI];
         stable = it > 0 ? (P.tmin[(size_t)slot * P.nseeds + seedI] == T_INF) : (S.stable != 0);
-        // Seeds are updated in place.  A processed seed first saves its old record in seedsTmp[] (marked _pad = 2), so the
-        // commit pass can restore it when the chunk turns out to have ended earlier; everyone else clears that mark.
+        // The seed records themselves are written by kb_commit_seeds (from the SeedUpd this kernel leaves in seedsTmp[]), which also knows by then
+        // whether the seed's chunk had ended earlier.
         if (!S.use || stable) {
             if (l == 0) {   // skipped: only the stable flag (as left by the pixel pass) and t(s) change
                 P.seeds[(size_t)slot * P.nseeds + seedI].stable = stable;
                 P.arec[(size_t)slot * P.nseeds + seedI].stable = stable ? 1u : 0u;
-                P.seedsTmp[(size_t)slot * P.nseeds + seedI]._pad = 0;
+                reinterpret_cast<SeedUpd *>(P.seedsTmp + ((size_t)slot * P.nseeds + seedI))->state = 0;
                 P.tmin[(size_t)slot * P.nseeds + seedI] = stable ? T_INF : 0u;
             }
             active = false;
@@ -506,28 +516,11 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
         }
     }
     USTAMP();   // 1: seed record + window gather + ordered depth list
-    sumX = row_sum_exact_f32(sumX); sumY = row_sum_exact_f32(sumY); sumI = row_sum_exact_f32(sumI); cnt = row_sum_i32(cnt);   // (integer-valued: exact in any order)
+    sumX = row_sum_i32(sumX); sumY = row_sum_i32(sumY); sumI = row_sum_i32(sumI); cnt = row_sum_i32(cnt);
     __builtin_amdgcn_wave_barrier();
-    // what this update changes of the seed record (the record itself is read again for the final stores: 12 registers less through the gather above,
-    // where the kernel's register count peaks)
-    float tInt = 0, tX = 0, tY = 0;
-    int tR = 0, tG = 0, tB = 0;
-    bool tStable = false, aborted = false;
     const bool depthLoop = active && cnt != 0 && nd > 0;   // (uniform over the seed's 16 lanes)
-    if (l == 0 && active) {
-        if (cnt == 0) {  // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable
-            atomicMin(&P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)], seedI);
-            aborted = true;
-        } else {
-            const float sumIntensityNum = (float)cnt;
-            const float sumIntensity = (float)sumI / sumIntensityNum, mX = (float)sumX / sumIntensityNum, mY = (float)sumY / sumIntensityNum;
-            const float preIntensity = S.meanIntensity, preX = S.x, preY = S.y;
-            tInt = sumIntensity; tX = mX; tY = mY;
-            vec3b(P, F, mY, mX, tR, tG, tB);
-            const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
-            tStable = updateDiff < 0.2;
-        }
-    }
+    if (l == 0 && active && cnt == 0)   // `return`: ends the chunk (:473-474); the seed itself stays as it is, unstable (kb_commit_seeds)
+        atomicMin(&P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)], seedI);
     // ---- mean depth and its Huber refinement (:486-512): the sequential sums as rotating chains (above); everything per seed is uniform over its
     // 16 lanes and lives in registers -- no LDS, no atomics, no barriers in the Newton loop ----
     const int ndL = depthLoop ? nd : 0;                 // a seed without a depth loop contributes empty lists
@@ -581,31 +574,9 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
     }
     USTAMP();   // 3: Newton steps
     if (active && l == 0) {
-        const size_t si = (size_t)slot * P.nseeds + seedI;
-        if (aborted) {
-            P.seeds[si].stable = 0; P.arec[si].stable = 0u; P.seedsTmp[si]._pad = 0; P.tmin[si] = 0u;
-        } else {
-            // the 64-byte record as four 16-byte words (nobody else writes it): words 0-1 x, y; 10-11 meanDepth, meanIntensity; 12-14 r, g, b;
-            // 15 the bytes fused | stable << 8 | use << 16 | _pad << 24.  The old record goes to seedsTmp[] marked _pad = 2 (so the commit pass can
-            // restore it when the chunk turns out to have ended earlier), the new one in place.
-            static_assert(sizeof(msl_seed) == 64 && offsetof(msl_seed, meanDepth) == 40 && offsetof(msl_seed, r) == 48 && offsetof(msl_seed, stable) == 61, "msl_seed layout");
-            const uint4 *src = reinterpret_cast<const uint4 *>(P.seeds + si);
-            uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
-            uint4 *tmp = reinterpret_cast<uint4 *>(P.seedsTmp + si);
-            tmp[0] = w0; tmp[1] = w1; tmp[2] = w2; tmp[3] = make_uint4(w3.x, w3.y, w3.z, (w3.w & 0x00FFFFFFu) | 0x02000000u);
-            const float tDepth = depthLoop ? meanDepth : 0.0f;   // no valid depth among the seed's pixels: 0 (:489-490)
-            w0.x = __float_as_uint(tX); w0.y = __float_as_uint(tY);
-            w2.z = __float_as_uint(tDepth); w2.w = __float_as_uint(tInt);
-            w3.x = (unsigned)tR; w3.y = (unsigned)tG; w3.z = (unsigned)tB;
-            w3.w = (w3.w & 0x00FF00FFu) | (tStable ? 0x100u : 0u);
-            uint4 *dst = reinterpret_cast<uint4 *>(P.seeds + si);
-            dst[0] = w0; dst[1] = w1; dst[2] = w2; dst[3] = w3;
-            P.tmin[si] = tStable ? T_INF : 0u;
-            AssignRec a;
-            a.x = tX; a.y = tY; a.meanIntensity = tInt; a.stable = tStable ? 1u : 0u;
-            a.invDepth = tDepth > 0 ? 1.0 / (double)tDepth : -1.0; a._pad = 0;
-            P.arec[si] = a;
-        }
+        SeedUpd U;
+        U.state = cnt == 0 ? 1 : 2; U.cnt = cnt; U.sumI = sumI; U.sumX = sumX; U.sumY = sumY; U.depthLoop = depthLoop ? 1 : 0; U.meanDepth = meanDepth;
+        *reinterpret_cast<SeedUpd *>(P.seedsTmp + ((size_t)slot * P.nseeds + seedI)) = U;
     }
 #ifdef MSL_FUSE_STAMPS
     USTAMP();   // 4: stores
@@ -617,26 +588,51 @@ __global__ __launch_bounds__(256) void kb_update_seeds(SfDev P, int it, int nSlo
 }
 
 
-// kb_commit_seeds: the chunk-abort rule.  Normally nothing to do (no chunk ended early); otherwise a seed that was processed
-// although its chunk had already ended gets its old record back, unstable ("values untouched", :473-474).
-// The rule can never fire: a used seed (lattice position spX < W / 8, spY < H / 8) always owns the pixel at its lattice
-// centre (8 spX + 4, 8 spY + 4).  That pixel is free (what `use` means, :541-545); its ONLY updatePixels candidate is this seed
-// (|8 c + 4 - x| < 8 holds for c = spX alone when x mod 8 == 4, :384-389); pass 0 assigns it with cost 0 < 1e6 whatever intensity / depth
-// are; no later pass can move it; and it lies inside the clipped window updateSeeds counts.  So the owned-pixel count is >= 1 and the
-// restore path is kept for fidelity only (property-tested on adversarial inputs in the CPU suite).
+// kb_commit_seeds: the per-seed end of updateSeedsKernel (:475-515), one thread per seed: means, colour fetch, stability test, the new seed record, t(s)
+// and the AssignRec, from the sums kb_update_seeds left (SeedUpd) -- and the chunk-abort rule: a seed without a single owned pixel ends its chunk
+// (`return`, :473-474), so the seeds BEHIND it in the chunk stay as they are, unstable.  That rule can never fire: a used seed (lattice position
+// spX < W / 8, spY < H / 8) always owns the pixel at its lattice centre (8 spX + 4, 8 spY + 4).  That pixel is free (what `use` means, :541-545); its
+// ONLY updatePixels candidate is this seed (|8 c + 4 - x| < 8 holds for c = spX alone when x mod 8 == 4, :384-389); pass 0 assigns it with cost
+// 0 < 1e6 whatever intensity / depth are; no later pass can move it; and it lies inside the clipped window updateSeeds counts.  So the owned-pixel
+// count is >= 1 and the abort path is kept for fidelity only (property-tested on adversarial inputs in the CPU suite).
 __global__ __launch_bounds__(256) void kb_commit_seeds(SfDev P, int it) {
     const int slot = blockIdx.y;
     const int seedI = blockIdx.x * 256 + threadIdx.x;
     if (seedI >= P.nseeds) return;
     if (seedI == 0) P.wlCount[slot] = 0;   // the next pixel pass rebuilds the relaxation worklist
-    if (seedI < P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)]) return;
     const size_t si = (size_t)slot * P.nseeds + seedI;
-    if (P.seedsTmp[si]._pad != 2) return;   // skipped, or the seed that ended the chunk: already as it should be
-    msl_seed out = P.seedsTmp[si];
-    out.stable = 0; out._pad = 0;
-    P.seeds[si] = out;
-    P.tmin[si] = 0u;
-    P.arec[si] = assign_rec(out);
+    const SeedUpd U = *reinterpret_cast<const SeedUpd *>(P.seedsTmp + si);
+    if (U.state == 0) return;   // skipped (unused or stable): already as it should be
+    const int abortAt = P.chunkAbort[(slot * 2 + (it & 1)) * 16 + seed_chunk(seedI, P.nseeds)];   // first seed of the chunk without a pixel (0x7FFFFFFF: none)
+    if (U.state == 1 || seedI > abortAt) {   // the seed that ended the chunk, or one behind it: values untouched, unstable
+        P.seeds[si].stable = 0; P.arec[si].stable = 0u; P.tmin[si] = 0u;
+        return;
+    }
+    const FrameDev &F = P.frames[slot];
+    // the 64-byte record as four 16-byte words (nobody else writes it): words 0-1 x, y; 10-11 meanDepth, meanIntensity; 12-14 r, g, b;
+    // 15 the bytes fused | stable << 8 | use << 16 | _pad << 24
+    static_assert(sizeof(msl_seed) == 64 && offsetof(msl_seed, meanDepth) == 40 && offsetof(msl_seed, r) == 48 && offsetof(msl_seed, stable) == 61, "msl_seed layout");
+    uint4 *rec = reinterpret_cast<uint4 *>(P.seeds + si);
+    const uint4 w0o = rec[0], w2o = rec[2], w3o = rec[3];
+    const float sumIntensityNum = (float)U.cnt;
+    const float sumIntensity = (float)U.sumI / sumIntensityNum, mX = (float)U.sumX / sumIntensityNum, mY = (float)U.sumY / sumIntensityNum;
+    const float preIntensity = __uint_as_float(w2o.w), preX = __uint_as_float(w0o.x), preY = __uint_as_float(w0o.y);
+    int tR = 0, tG = 0, tB = 0;
+    vec3b(P, F, mY, mX, tR, tG, tB);
+    const float updateDiff = fabsf(preIntensity - sumIntensity) + fabsf(preX - mX) + fabsf(preY - mY);
+    const bool tStable = updateDiff < 0.2;
+    const float tDepth = U.depthLoop ? U.meanDepth : 0.0f;   // no valid depth among the seed's pixels: 0 (:489-490)
+    uint4 w0 = w0o, w2 = w2o, w3 = w3o;
+    w0.x = __float_as_uint(mX); w0.y = __float_as_uint(mY);
+    w2.z = __float_as_uint(tDepth); w2.w = __float_as_uint(sumIntensity);
+    w3.x = (unsigned)tR; w3.y = (unsigned)tG; w3.z = (unsigned)tB;
+    w3.w = (w3.w & 0x00FF00FFu) | (tStable ? 0x100u : 0u);
+    rec[0] = w0; rec[2] = w2; rec[3] = w3;
+    P.tmin[si] = tStable ? T_INF : 0u;
+    AssignRec a;
+    a.x = mX; a.y = mY; a.meanIntensity = sumIntensity; a.stable = tStable ? 1u : 0u;
+    a.invDepth = tDepth > 0 ? 1.0 / (double)tDepth : -1.0; a._pad = 0;
+    P.arec[si] = a;
 }
 
 // kb_seed_plane: calculateNorms (:775-803) fused per seed, 16 lanes per seed, 4 seeds per wave/workgroup.
