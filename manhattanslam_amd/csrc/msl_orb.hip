@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void k_fast(OrbDev P) {
         if (m) {
             unsigned base = 0;
             if ((tid & 63) == 0) base = atomicAdd(&s_cnt[2], (unsigned)__popcll(m));
-            base = __shfl(base, 0, 64);
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, 0);
             if (cand) s_list[base + __popcll(m & ((1ull << (tid & 63)) - 1ull))] = (unsigned short)i;
         }
     }
@@ -1011,11 +1011,9 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P) {
                 m01 += v * val;
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            m10 += __shfl_xor(m10, d, 64);
-            m01 += __shfl_xor(m01, d, 64);
-        }
+        // wave totals in the VALU (DPP row scan + row broadcasts, msl_common.h) instead of six rounds of ds_bpermute per sum; integer sums: any order
+        m10 = __builtin_amdgcn_readlane((int)wave_incl_scan((unsigned)m10), 63);
+        m01 = __builtin_amdgcn_readlane((int)wave_incl_scan((unsigned)m01), 63);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
     const float factorPI = (float)(M_PI / 180.f);
@@ -1032,9 +1030,10 @@ __global__ __launch_bounds__(256) void k_describe(OrbDev P) {
         const int t0 = s_blurp[wv][(r0 + 18) * BW + c0 + 20], t1 = s_blurp[wv][(r1 + 18) * BW + c1 + 20];
         nib |= (t0 < t1 ? 1u : 0u) << j;
     }
-    unsigned w = nib | (__shfl_down(nib, 1, 64) << 4);
-    w |= __shfl_down(w, 2, 64) << 8;
-    w |= __shfl_down(w, 4, 64) << 16;
+    // lane 8 q collects the nibbles of lanes 8 q .. 8 q + 7 (inside one DPP row): row_shl:n hands lane i the value of lane i + n
+    unsigned w = nib | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)nib, 0x101, 0xF, 0xF, true) << 4);
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x102, 0xF, 0xF, true) << 8;
+    w |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)w, 0x104, 0xF, 0xF, true) << 16;
     msl_keypoint *kp = P.kps + (size_t)frame * P.outCap + outIdx;
     uint32_t *dsc = (uint32_t *)(P.desc + ((size_t)frame * P.outCap + outIdx) * 32);
     if ((lane & 7) == 0) dsc[lane >> 3] = w;
