@@ -775,18 +775,23 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
             }
         }
         unsigned vm = 0;   // bit 4 m + e: pixel e of the quad in iteration m is a valid-depth pixel of the seed
+        // Branch-free (sixteen per-lane branches per wave otherwise; one or two waves per SIMD cannot hide their bubbles): the two squares of `dist` are the
+        // same products whichever pixel of a column / row they are computed for, so each is evaluated once per column and once per row of the lane's quads.
+        float xd2[4], yd2[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const float xDiff = (xb + 4 * cq + e) - S.x; xd2[e] = xDiff * xDiff; }
+#pragma unroll
+        for (int m = 0; m < 4; m++) { const float yDiff = (yb + 4 * m + rq) - S.y; yd2[m] = yDiff * yDiff; }
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int i = xb + 4 * cq + e, jrow = yb + 4 * m + rq;
                 const int pixelIndex = jrow * P.W + i;
-                if (inRange && pixelIndex >= 0 && pixelIndex < P.npx && idq[m].v[e] == seedI) {
-                    const float xDiff = i - S.x, yDiff = jrow - S.y;
-                    const float dist = xDiff * xDiff + yDiff * yDiff;
-                    if (dist > maxDist) maxDist = dist;
-                    if (dq[m].v[e] >= DEPTH_005_F) vm |= 1u << (4 * m + e);   // `> 0.05` (:686)
-                }
+                const bool own = inRange & (pixelIndex >= 0) & (pixelIndex < P.npx) & (idq[m].v[e] == seedI);   // (`&`: no short-circuit branch around the compare of the loaded index)
+                const float dist = xd2[e] + yd2[m];   // xDiff * xDiff + yDiff * yDiff (:680-683)
+                maxDist = (own & (dist > maxDist)) ? dist : maxDist;
+                vm |= ((own & (dq[m].v[e] >= DEPTH_005_F)) ? 1u : 0u) << (4 * m + e);   // `> 0.05` (:686)
             }
         nvalid = __popc(vm);
         SECTION_STAMP();   // 1a: window loads arrived, ownership tests
