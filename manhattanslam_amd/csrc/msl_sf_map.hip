@@ -618,7 +618,11 @@ __device__ __forceinline__ void fuse_body(const FuseArgs &P, const FuseFrame &F,
 }
 
 template <bool DEFER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fuse(FuseArgs P, FuseFrame F, int nSubHint) {   // by value: kernarg -> SGPRs; 8 waves / SIMD = 64 VGPRs
+// Register budget (round 6): at 8 waves per SIMD a wave has 80 scalar registers (800 per SIMD / 8 less the trap handler's 16) and the kernel spilled 41 of them to
+// lanes of a VGPR: 147 v_readlane / v_writelane instructions, a fifth of its VALU count.  A minimum of 6 waves lets the compiler use 106 SGPRs: no spills, 59 VGPRs
+// (the wave still fits the 64-register holes the frame-batched kernels leave), 7 waves per SIMD by the scalar file.  15.5 -> 15.0 us by rocprofv3 beside the
+// (faster, round 6) superpixel stage, config 3 +1.2 %, front end +- 0; measured before the superpixel stage was trimmed: +- 0 everywhere.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fuse(FuseArgs P, FuseFrame F, int nSubHint) {   // by value: kernarg -> SGPRs
     __builtin_amdgcn_s_setprio(3);   // the map chain is sequential per keyframe: issue ahead of the batched kernels' waves
     if (DEFER) {
         if (blockIdx.x == 0) fuse_body<DEFER, true>(P, F, nSubHint, 0u, (int)gridDim.x - 1);   // workgroup 0: the spawn wave (its own instantiation: what it
