@@ -844,7 +844,6 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs P, int mode) {
     unsigned cnt = 0;
     unsigned long long emit = 0, emitHi = 0;   // bit j: seed s0 + j spawns a surfel (emit: j < 64; emitHi: 64 <= j < 128)
     const msl_surfel *cand = P.cand;
-    const bool pf = blockIdx.x == 0 || mode == 1;   // the workgroup that will emit (steady state / host-vector mode)
     const bool aligned4 = (P.nseeds & 3) == 0 && ((reinterpret_cast<size_t>(candOk) | reinterpret_cast<size_t>(fused)) & 3) == 0;
     // all flag words of the thread in ONE round trip: 8 words each for <= 32 seeds per thread (640 x 480: 19), 24 words for <= 96 (1280 x 960: 76 --
     // round 3 walked the seeds beyond the 64th one by one, two dependent byte loads each, and the kernel took 30 us at that size)
@@ -893,17 +892,19 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs P, int mode) {
             }
         }
     }
-    // The continuing workgroup of the steady-state path is workgroup 0: it fetches its first two candidate surfels now, so
-    // that this round trip overlaps the scans below instead of following them.
-    msl_surfel e0, e1;
-    memset(&e0, 0, sizeof(e0)); memset(&e1, 0, sizeof(e1));
-    if (pf && emit) {
-        e0 = cand[s0 + __builtin_ctzll(emit)];
-        const unsigned long long m1 = emit & (emit - 1);
-        if (m1) e1 = cand[s0 + __builtin_ctzll(m1)];
-    }
     const long long nblk = (n + SUB_ITEMS - 1) / SUB_ITEMS;   // sub-block partials written by k_fuse
     const long long nWg = nblk;   // k_fuse waves (blockUpd entries): one per sub-block
+    // The prefetched updated counts are folded into ONE register here, as soon as the flag words have been consumed (they were requested before
+    // them, so they have arrived): 32 registers that stayed live down to the continuation otherwise -- the kernel's register count decides how soon a
+    // workgroup of this latency-critical launch finds room on a CU that the frame-batched kernels fill.  Round 6: 182 -> 87 VGPRs with this and without
+    // the prefetch of the thread's first two candidate surfels into registers (51 registers, for a round trip that only keyframes with new surfels
+    // pay): k_compact 12.2 -> 9.1 us in the timed region (its time alone is unchanged), config 3 +2 %, moving camera 14.8 -> 16.1 k frames/s.
+    unsigned updPart = 0;
+#pragma unroll
+    for (int q = 0; q < NBU; q++) {
+        const long long c = TILE * q + 4 * threadIdx.x;
+        updPart += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
+    }
     s_raw[threadIdx.x] = du;
     if (threadIdx.x == 0) { s_upd = 0; s_fallback = 0; s_nzChunks = 0; }
     __syncthreads();
@@ -997,12 +998,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs P, int mode) {
     // ================= continuation: one workgroup =================
     // updated count
     {
-        unsigned u = 0;
-#pragma unroll
-        for (int q = 0; q < NBU; q++) {
-            const long long c = TILE * q + 4 * threadIdx.x;
-            u += (c < nWg ? bu[q].x : 0u) + (c + 1 < nWg ? bu[q].y : 0u) + (c + 2 < nWg ? bu[q].z : 0u) + (c + 3 < nWg ? bu[q].w : 0u);
-        }
+        unsigned u = updPart;
         for (long long c2 = (long long)NBU * TILE + threadIdx.x; c2 < nWg; c2 += blockDim.x) u += P.blockUpd[c2];
         u = wave_incl_scan(u);                                   // one LDS atomic per wave instead of 256 on one address
         if ((threadIdx.x & 63) == 63 && u) atomicAdd(&s_upd, u);
@@ -1019,13 +1015,7 @@ __global__ __launch_bounds__(256) void k_compact(CompactArgs P, int mode) {
             if (place)                              // new surfel k -> k-th largest deleted slot while any remain, else appended
                 store_surfel(P.map, k < D ? (long long)DL(D - 1 - k) : n + (k - D), e);   // (SurfelMapping.cpp:372-384)
         };
-        unsigned long long m = emit;
-        for (int j = 0; m; j++, m &= m - 1) {
-            const int i = s0 + __builtin_ctzll(m);
-            if (pf && j == 0) emit_one(e0);
-            else if (pf && j == 1) emit_one(e1);
-            else emit_one(cand[i]);
-        }
+        for (unsigned long long m = emit; m; m &= m - 1) emit_one(cand[s0 + __builtin_ctzll(m)]);
         for (unsigned long long mh = emitHi; mh; mh &= mh - 1) emit_one(cand[s0 + 64 + __builtin_ctzll(mh)]);
         for (int i = s0 + 128; i < s1; i++)
             if (candOk[i] && !fused[i]) emit_one(cand[i]);
