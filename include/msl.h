@@ -392,6 +392,8 @@ MSL_API int msl_match_descriptor_distance(int device, const uint8_t *a32, const 
  * generateSuperPixels() of all keyframes of a batch runs frame-batched on a second stream and overlaps the
  * per-keyframe map stage of the previous batch.  n_frames <= the capacity set below (default 1). */
 MSL_API int msl_sf_set_batch_capacity(msl_sf *h, int max_frames) MSL_NOEXCEPT;
+/* (All surfel entry points: the rows of ONE image must span less than 4 GB -- stride * rows < 2^32 bytes for gray, depth and membership images alike;
+ * otherwise MSL_ERR_INVALID.  The kernels address an image with 32-bit byte offsets.) */
 MSL_API int msl_sf_fuse_resident_batch(msl_sf *h, int n_frames, const int32_t *refs, const uint8_t *gray,
                                        size_t gray_stride, size_t gray_frame_stride, const float *depth,
                                        size_t depth_stride, size_t depth_frame_stride, const int32_t *member,

@@ -126,6 +126,31 @@ def test_strided_images(oracle):
     g.close()
 
 
+def test_rows_spanning_4gb_are_refused():
+    """The kernels address an image with 32-bit byte offsets (round 6): a row stride that makes the rows of ONE image span 4 GB or more is refused
+    with MSL_ERR_INVALID before anything is launched (include/msl.h); nothing is read through the pointers."""
+    import ctypes as C
+    import torch
+    from manhattanslam_amd import SurfelFusion, synth
+    from manhattanslam_amd._lib import lib, MSL_MEM_DEVICE
+    I = synth.TUM1
+    sf = SurfelFusion(640, 480, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+    sf.set_batch_capacity(1)
+    g = torch.zeros((480, 640), dtype=torch.uint8, device="cuda"); d = torch.zeros((480, 640), dtype=torch.float32, device="cuda")
+    m = torch.zeros((240, 320), dtype=torch.int32, device="cuda")
+    refs = np.zeros(1, np.int32); pose = np.eye(4, dtype=np.float32).T.reshape(-1).copy()
+    def call(gs, ds, ms):
+        return lib.msl_sf_fuse_resident_batch(sf._h, 1, refs.ctypes.data_as(C.c_void_p), C.c_void_p(g.data_ptr()), C.c_size_t(gs), C.c_size_t(0),
+                                              C.c_void_p(d.data_ptr()), C.c_size_t(ds), C.c_size_t(0), C.c_void_p(m.data_ptr()), C.c_size_t(ms), C.c_size_t(0),
+                                              MSL_MEM_DEVICE, pose.ctypes.data_as(C.c_void_p))
+    big = (1 << 32) // 480 + 4
+    assert call(big, 4 * 640, 4 * 320) != 0          # gray rows span >= 4 GB
+    assert call(640, big & ~3, 4 * 320) != 0         # depth rows
+    assert call(640, 4 * 640, ((1 << 32) // 240 + 8) & ~3) != 0   # membership rows
+    assert call(640, 4 * 640, 4 * 320) == 0          # the same images with their real strides
+    sf.sync(); sf.close()
+
+
 def test_icl_negative_fy_and_empty_map(oracle):
     from manhattanslam_amd import synth, SURFEL_DTYPE
     g, o = _mk(synth.ICL)
