@@ -782,6 +782,58 @@ def streaming(args, cfg, grays, depths, member, poses, smap, W, H, intr, kfe, F,
                               "h2d_gbs": round(h2d16 * fps16 / 1e9, 2),
                               "note": "the same passes with the depth images as raw uint16 (5000 per metre) through msl_sf_fuse_resident_batch_d16: converted on "
                                       "the device as float(raw) * factor (src/Frame.cc:96-97), 2 instead of 4 depth bytes per pixel over PCIe"}
+    if do_sf and do_orb and kfe == 1:
+        # ONE upload of the gray image for both consumers (msl_sf_staged_gray + msl_orb_wait_event, round 6): the surfel thread enqueues its host-image batch,
+        # hands the staged device images and their "uploaded" event to the ORB thread of that batch, and lets the extraction of batch k return before it
+        # enqueues batch k + 2 (the staging set of batch k is then overwritten)
+        import queue
+
+        def run_shared(npass):
+            qs = [queue.Queue() for _ in orbs]
+            done = [threading.Event() for _ in range(npass * nsub)]
+
+            def sf_w():
+                i = 0
+                for _ in range(npass):
+                    sf.map_restore()
+                    for sb in range(nsub):
+                        if i >= 2:
+                            done[i - 2].wait()
+                        sf.fuse_resident_batch(np.arange(sb * nkf, (sb + 1) * nkf), g_np[sb * B:], d16_np[sb * B:], m_np, kf_poses[sb],
+                                               device=False, member_shared=True, frame_step=kfe, depth_factor=d16_factor)
+                        qs[sb % len(orbs)].put((i, sb) + sf.staged_gray())
+                        i += 1
+                sf.sync()
+                for q in qs:
+                    q.put(None)
+
+            def orb_w(which):
+                ex = orbs[which]
+                while True:
+                    item = qs[which].get()
+                    if item is None:
+                        return
+                    i, sb, p, rs, fs, ev = item
+                    ex.wait_event(ev)
+                    ex.extract_batch_shared(p, rs, fs, h_kps[sb * B * cap * 28:], h_desc[sb * B * cap * 32:], h_n[sb * B:], B, W, H)
+                    done[i].set()
+
+            th = [threading.Thread(target=sf_w)] + [threading.Thread(target=orb_w, args=(i,)) for i in range(len(orbs))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+
+        h_n[:] = 0
+        run_shared(2)
+        t0 = time.perf_counter()
+        run_shared(npass)
+        fps_sh = npass * F / (time.perf_counter() - t0)
+        h2d_sh = W * H + 2 * W * H
+        res["raw_depth16_shared_gray"] = {"value_streaming": round(fps_sh, 1), "fraction_of_resident": round(fps_sh / resident_value, 3), "h2d_bytes_per_frame": int(h2d_sh),
+                                          "h2d_gbs": round(h2d_sh * fps_sh / 1e9, 2), "keypoints_per_frame": round(int(h_n.sum()) / F, 1),
+                                          "note": "raw 16-bit depth and ONE upload of the gray image for both handles: the ORB extractor reads the images the surfel "
+                                                  "batch staged on the device (msl_sf_staged_gray + msl_orb_wait_event + msl_orb_extract_batch with MSL_MEM_DEVICE input)"}
     for ex in orbs:
         ex.close()
     if do_sf:

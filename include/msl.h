@@ -135,6 +135,8 @@ MSL_API int msl_orb_extract(msl_orb *h, const uint8_t *gray, int width, int heig
  * frame f are written at kps + f*cap, desc32 + f*cap*32, n_out[f].  in_mem/out_mem say whether
  * the input / the three output pointers are host or device memory.  With device outputs the
  * call is asynchronous on the handle's stream: use msl_orb_sync() before reading. */
+/* The extractor's stream waits for a hipEvent_t (e.g. the one msl_sf_staged_gray returns) before anything enqueued after this call. */
+MSL_API int msl_orb_wait_event(msl_orb *h, void *hip_event) MSL_NOEXCEPT;
 MSL_API int msl_orb_extract_batch(msl_orb *h, const uint8_t *gray, int n_frames, int width,
                                   int height, size_t row_stride, size_t frame_stride,
                                   msl_mem in_mem, msl_keypoint *kps, uint8_t *desc32, int cap,
@@ -412,6 +414,15 @@ MSL_API int msl_sf_fuse_resident_batch_d16(msl_sf *h, int n_frames, const int32_
 MSL_API int msl_sf_last_counters(msl_sf *h, int64_t counters[5]) MSL_NOEXCEPT;
 MSL_API int msl_sf_sync(msl_sf *h) MSL_NOEXCEPT;
 MSL_API int msl_sf_set_stream(msl_sf *h, void *hip_stream) MSL_NOEXCEPT;
+/* ONE upload of the gray image for both consumers (round 6).  Tracking::GrabImageRGBD hands the same gray frame to the ORB extractor (Frame
+ * constructor, src/Frame.cc:103) and, for keyframes, to the surfel fusion (src/SurfelMapping.cpp:160-166); with host images each handle would copy it
+ * over PCIe.  After msl_sf_fuse_resident_batch[_d16] with MSL_MEM_HOST images, msl_sf_staged_gray returns the device address of the gray images that
+ * call staged (frame f at *gray_dev + f * *frame_stride, rows *row_stride bytes apart) and a hipEvent_t, owned by the handle, that completes when
+ * their copy has.  msl_orb_wait_event makes the extractor's stream wait for such an event; msl_orb_extract_batch(..., MSL_MEM_DEVICE, ...) then reads
+ * the images in place.  The staged images stay valid until the SECOND next host-image batch is enqueued on the surfel handle: the caller lets the
+ * extraction of batch k return before it enqueues batch k + 2 (msl_orb_extract_batch with host outputs is synchronous).  MSL_ERR_INVALID when the
+ * handle's last batch had no host images. */
+MSL_API int msl_sf_staged_gray(msl_sf *h, const uint8_t **gray_dev, size_t *row_stride, size_t *frame_stride, void **uploaded_event) MSL_NOEXCEPT;
 
 
 #ifdef __cplusplus

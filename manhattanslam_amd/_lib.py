@@ -96,6 +96,8 @@ SIGNATURES = {
     "msl_sf_last_counters": (_i, [_vp, _vp]),
     "msl_sf_sync": (_i, [_vp]),
     "msl_sf_set_stream": (_i, [_vp, _vp]),
+    "msl_sf_staged_gray": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "msl_orb_wait_event": (_i, [_vp, _vp]),
     "msl_orb_debug_stamps": (_i, [_vp, _vp, _i]),
     "msl_sf_debug_seeds": (_i, [_vp, _vp]),
     "msl_sf_debug_index": (_i, [_vp, _vp]),

@@ -1522,6 +1522,15 @@ int msl_orb_set_stream(msl_orb *h, void *hip_stream) noexcept {
     } MSL_ABI_CATCH_INT
 }
 
+int msl_orb_wait_event(msl_orb *h, void *hip_event) noexcept {
+    try {
+    if (!h || !hip_event) return MSL_ERR_INVALID;
+    MSL_HIP_TRY(hipSetDevice(h->device));
+    MSL_HIP_TRY(hipStreamWaitEvent(h->stream, (hipEvent_t)hip_event, 0));   // (the side stream forks from this one inside every call)
+    return MSL_OK;
+    } MSL_ABI_CATCH_INT
+}
+
 int msl_orb_sync(msl_orb *h) noexcept {
     try {
     if (!h) return MSL_ERR_INVALID;

@@ -41,6 +41,7 @@ struct msl_sf {
     hipEvent_t evPre[2] = {nullptr, nullptr}, evMap[2] = {nullptr, nullptr}, evCopy[2] = {nullptr, nullptr};
     bool evMapValid[2] = {false, false}, evCopyValid[2] = {false, false}, evPreValid[2] = {false, false};
     unsigned long long batchNo = 0;
+    int stagedSet = -1; size_t stagedGs = 0;   // slot set / row stride of the gray images the last host-image batch staged (msl_sf_staged_gray); -1: none
     int lastSlot = 0;
     // per-slot device buffers
     FrameDev *d_frames = nullptr; FrameDev *h_frames = nullptr;  // pinned host staging [slots]
@@ -325,6 +326,7 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
         h->kfEnq += (unsigned long long)n;
     }
     const int set = (int)(h->batchNo & 1), slot0 = set * h->maxBatch;
+    if (mem != MSL_MEM_HOST) h->stagedSet = -1;
     hipStream_t sp = h->preStream, sm = h->mapStream;
     if (h->evMapValid[set] && sp != sm) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evMap[set], 0));   // the set's previous user is done
     D.gstride = gs; D.gbytes = gs * (size_t)(H - 1) + W; D.dstride = ds / 4; D.mstride = ms / 4;
@@ -383,10 +385,9 @@ int run_batch(msl_sf *h, int n, const int32_t *refs, const uint8_t *gray, size_t
             sp_launch_depth_u16(sc, h->d_depth16 + (size_t)slot0 * h->depth16Cap, d16s, h->depth16Cap, (float *)((uint8_t *)h->d_depth + (size_t)slot0 * h->depthCap),
                                 h->depthCap / 4, W, H, n, depthFactor);
         h->prof.end(sc);
-        if (sc != sp) {
-            MSL_HIP_TRY(hipEventRecord(h->evH2D[set], sc));
-            MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evH2D[set], 0));
-        }
+        MSL_HIP_TRY(hipEventRecord(h->evH2D[set], sc));   // (always: msl_sf_staged_gray hands it to other handles)
+        if (sc != sp) MSL_HIP_TRY(hipStreamWaitEvent(sp, h->evH2D[set], 0));
+        h->stagedSet = set; h->stagedGs = gs;
     }
     if (d16 && mem != MSL_MEM_HOST) {   // device-resident raw depth: converted into the handle's float slots on the superpixel stream
         const size_t slots = 2 * (size_t)h->maxBatch;
@@ -597,6 +598,16 @@ void msl_sf_destroy(msl_sf *h) noexcept {
     if (h->ownStreams) { if (h->preStream) (void)hipStreamDestroy(h->preStream); if (h->mapStream) (void)hipStreamDestroy(h->mapStream); }
     delete h;
     } MSL_ABI_CATCH_VOID
+}
+
+int msl_sf_staged_gray(msl_sf *h, const uint8_t **gray_dev, size_t *row_stride, size_t *frame_stride, void **uploaded_event) noexcept {
+    try {
+    if (!h || !gray_dev || !row_stride || !frame_stride || !uploaded_event) return MSL_ERR_INVALID;
+    if (h->stagedSet < 0 || !h->d_gray) { set_error("msl_sf_staged_gray: the last batch had no host images"); return MSL_ERR_INVALID; }
+    *gray_dev = h->d_gray + (size_t)h->stagedSet * (size_t)h->maxBatch * h->grayCap;
+    *row_stride = h->stagedGs; *frame_stride = h->grayCap; *uploaded_event = (void *)h->evH2D[h->stagedSet];
+    return MSL_OK;
+    } MSL_ABI_CATCH_INT
 }
 
 int msl_sf_set_stream(msl_sf *h, void *hip_stream) noexcept {

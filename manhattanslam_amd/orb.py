@@ -125,6 +125,16 @@ class ORBextractor:
                                         MSL_MEM_HOST, ptr(kps), ptr(desc), self.capacity, ptr(n_out),
                                         MSL_MEM_HOST), "msl_orb_extract_batch")
 
+    def wait_event(self, hip_event):
+        """The extractor's stream waits for a hipEvent_t (e.g. the one SurfelFusion.staged_gray returns) before the calls that follow."""
+        check(lib.msl_orb_wait_event(self._h, C.c_void_p(hip_event)), "msl_orb_wait_event")
+
+    def extract_batch_shared(self, gray_dev, row_stride, frame_stride, kps, desc, n_out, n_frames, width, height):
+        """Device images in (an address, e.g. the surfel handle's staged gray images), host buffers out (numpy views); synchronous."""
+        check(lib.msl_orb_extract_batch(self._h, C.c_void_p(gray_dev), n_frames, width, height, row_stride, frame_stride,
+                                        MSL_MEM_DEVICE, ptr(kps), ptr(desc), self.capacity, ptr(n_out),
+                                        MSL_MEM_HOST), "msl_orb_extract_batch")
+
     def sync(self):
         check(lib.msl_orb_sync(self._h), "msl_orb_sync")
 

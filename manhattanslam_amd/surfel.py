@@ -142,6 +142,13 @@ class SurfelFusion:
                                              4 * mw, 0 if member_shared else 4 * km * mw * mh,
                                              MSL_MEM_DEVICE if device else MSL_MEM_HOST, ptr(poses)), "msl_sf_fuse_resident_batch")
 
+    def staged_gray(self):
+        """(device address, row stride, frame stride, hipEvent_t) of the gray images the last host-image batch staged (msl_sf_staged_gray): ONE upload
+        for the ORB extractor as well (ORBextractor.wait_event + extract_batch_shared)."""
+        p, rs, fs, ev = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_void_p()
+        check(lib.msl_sf_staged_gray(self._h, C.byref(p), C.byref(rs), C.byref(fs), C.byref(ev)), "msl_sf_staged_gray")
+        return p.value, rs.value, fs.value, ev.value
+
     def counters(self):
         c = np.zeros(5, np.int64)
         check(lib.msl_sf_last_counters(self._h, ptr(c)), "msl_sf_last_counters")

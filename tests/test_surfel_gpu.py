@@ -989,3 +989,44 @@ def test_batched_compaction_patterns(oracle, n, shares, tail_heavy, same_view):
         o.fuse_map(14 + k, f[0], f[1], f[2], f[3])
     assert_surfels_close(g.map_download(), o.map_get(), "second batch")
     g.close()
+
+
+def test_one_gray_upload_for_both_handles(oracle):
+    """msl_sf_staged_gray + msl_orb_wait_event (round 6): the ORB extractor reads the gray images a host-image surfel batch staged on the device -- one
+    upload for both consumers.  Keypoints and descriptors equal those of the same frames uploaded by the extractor itself, batch after batch (both slot
+    sets of the surfel handle, the second batch enqueued while the first one's map stage still runs); strided rows; and the call refuses a handle whose
+    last batch had device images."""
+    import torch
+    from manhattanslam_amd import ORBextractor, SurfelFusion, synth, SURFEL_DTYPE
+    from manhattanslam_amd._lib import MslError
+    W, H, I = 640, 480, synth.TUM1
+    sf = SurfelFusion(W, H, I["fx"], I["fy"], I["cx"], I["cy"], 30.0, 0.5)
+    sf.set_batch_capacity(4); sf.map_reserve(200_000)
+    sf.map_upload(synth.surfel_map_dense(100_000, ref=0).astype(SURFEL_DTYPE))
+    ex = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=4)
+    ref = ORBextractor(1000, 1.2, 8, 20, 7, max_width=W, max_height=H, max_batch=4)
+    cap = ex.capacity
+    frames = [synth.surfel_frame(k, variant="B" if k % 3 == 1 else "A") for k in range(8)]
+    grays = np.ascontiguousarray(synth.orb_frames(8, w=W, h=H))   # textured images: ~1000 keypoints per frame (the surfel stage takes any gray image)
+    depths = np.stack([f[1] for f in frames]); member = frames[0][2]
+    for b in range(2):
+        sl = slice(4 * b, 4 * b + 4)
+        sf.fuse_resident_batch(list(range(4 * b, 4 * b + 4)), grays[sl], depths[sl], member, [frames[j][3] for j in range(4 * b, 4 * b + 4)], member_shared=True)
+        p, rs, fs, ev = sf.staged_gray()
+        assert rs == W and fs >= W * H
+        kps = np.zeros(4 * cap * 28, np.uint8); desc = np.zeros(4 * cap * 32, np.uint8); n = np.zeros(4, np.int32)
+        ex.wait_event(ev)
+        ex.extract_batch_shared(p, rs, fs, kps, desc, n, 4, W, H)
+        kps2 = np.zeros_like(kps); desc2 = np.zeros_like(desc); n2 = np.zeros(4, np.int32)
+        ref.extract_batch_host(np.ascontiguousarray(grays[sl]), kps2, desc2, n2, 4, W, H)
+        assert n.tolist() == n2.tolist() and n.min() > 100
+        for f in range(4):
+            assert kps[f * cap * 28:(f * cap + n[f]) * 28].tobytes() == kps2[f * cap * 28:(f * cap + n[f]) * 28].tobytes()
+            assert desc[f * cap * 32:(f * cap + n[f]) * 32].tobytes() == desc2[f * cap * 32:(f * cap + n[f]) * 32].tobytes()
+    sf.sync()
+    # device images: nothing staged
+    dg, dd, dm = torch.from_numpy(grays[:4].copy()).cuda(), torch.from_numpy(depths[:4].copy()).cuda(), torch.from_numpy(member.copy()).cuda()
+    sf.fuse_resident_batch([8, 9, 10, 11], dg, dd, dm, [frames[j][3] for j in range(4)], device=True, member_shared=True)
+    with pytest.raises(MslError):
+        sf.staged_gray()
+    sf.sync(); sf.close(); ex.close(); ref.close()
