@@ -829,37 +829,53 @@ __global__ __launch_bounds__(256) void k_blur(OrbDev P) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < (BT_H + 6) * (BT_W / 4); i += 256) {
-        const int r = i / (BT_W / 4), j = i - r * (BT_W / 4);
+    // Row pass with v_dot4_u32_u8 (round 6): the seven taps of an output are two dot products of four staged bytes each -- the 8-byte window that starts
+    // one byte behind the output's first staged byte, cut out of the thread's three dwords with v_alignbyte -- instead of twelve byte extractions and ten
+    // multiply / adds per output.  A thread computes the same four columns of TWO consecutive staged rows and stores them as one dword per column,
+    // {row 2 p, row 2 p + 1}: the column pass then takes two taps per v_dot2_u32_u16.  Integer arithmetic throughout: the same sums as before.
+    constexpr unsigned TAPS_LO = (unsigned)GK0 | ((unsigned)GK1 << 8) | ((unsigned)GK2 << 16) | ((unsigned)GK3 << 24);   // staged bytes k + 1 .. k + 4
+    constexpr unsigned TAPS_HI = (unsigned)GK2 | ((unsigned)GK1 << 8) | ((unsigned)GK0 << 16);                           // staged bytes k + 5 .. k + 7
+    auto row4 = [&](int r, int j, unsigned (&o)[4]) {
         const unsigned *p = reinterpret_cast<const unsigned *>(s_in) + r * (IP / 4) + j;
         const unsigned w0 = p[0], w1 = p[1], w2 = p[2];
-        const int bb[12] = {(int)(w0 & 255), (int)((w0 >> 8) & 255), (int)((w0 >> 16) & 255), (int)(w0 >> 24),
-                            (int)(w1 & 255), (int)((w1 >> 8) & 255), (int)((w1 >> 16) & 255), (int)(w1 >> 24),
-                            (int)(w2 & 255), (int)((w2 >> 8) & 255), (int)((w2 >> 16) & 255), (int)(w2 >> 24)};
-        unsigned o[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)   // output column 4 j + k reads staged bytes 4 j + k + 1 .. + 7
-            o[k] = (unsigned)(GK0 * (bb[k + 1] + bb[k + 7]) + GK1 * (bb[k + 2] + bb[k + 6]) + GK2 * (bb[k + 3] + bb[k + 5]) + GK3 * bb[k + 4]);
-        uint2 pk; pk.x = o[0] | (o[1] << 16); pk.y = o[2] | (o[3] << 16);
-        *reinterpret_cast<uint2 *>(&s_row[r * BT_W + 4 * j]) = pk;
+        o[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), TAPS_HI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), TAPS_LO, 0u, false), false);
+        o[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), TAPS_HI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), TAPS_LO, 0u, false), false);
+        o[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), TAPS_HI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), TAPS_LO, 0u, false), false);
+        o[3] = __builtin_amdgcn_udot4(w2, TAPS_HI, __builtin_amdgcn_udot4(w1, TAPS_LO, 0u, false), false);   // output column 4 j + k reads staged bytes 4 j + k + 1 .. + 7
+    };
+    static_assert((BT_H + 6) % 2 == 0, "whole row pairs");
+    unsigned *const s_pair = reinterpret_cast<unsigned *>(s_row);   // [(BT_H + 6) / 2][BT_W]: low half = row 2 p, high half = row 2 p + 1 (row sums <= 65535)
+    for (int i = tid; i < ((BT_H + 6) / 2) * (BT_W / 4); i += 256) {
+        const int rp = i / (BT_W / 4), j = i - rp * (BT_W / 4);
+        unsigned oa[4], ob[4];
+        row4(2 * rp, j, oa); row4(2 * rp + 1, j, ob);
+        uint4 pk; pk.x = oa[0] | (ob[0] << 16); pk.y = oa[1] | (ob[1] << 16); pk.z = oa[2] | (ob[2] << 16); pk.w = oa[3] | (ob[3] << 16);
+        *reinterpret_cast<uint4 *>(&s_pair[rp * BT_W + 4 * j]) = pk;
     }
     __syncthreads();
     uint8_t *out = P.blur + (size_t)frame * P.blurStride + D.boff;
+    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
     for (int i = tid; i < BT_H * (BT_W / 4); i += 256) {
         const int r = i / (BT_W / 4), j = i - r * (BT_W / 4);
         const int x = tx0 + 4 * j, y = ty0 + r;
         if (x >= D.w || y >= D.h) continue;
-        int acc[4] = {0, 0, 0, 0};
-        constexpr int K7[7] = {GK0, GK1, GK2, GK3, GK2, GK1, GK0};
-#pragma unroll
-        for (int k = 0; k < 7; k++) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(&s_row[(r + k) * BT_W + 4 * j]);
-            acc[0] += K7[k] * (int)(q.x & 0xFFFFu); acc[1] += K7[k] * (int)(q.x >> 16);
-            acc[2] += K7[k] * (int)(q.y & 0xFFFFu); acc[3] += K7[k] * (int)(q.y >> 16);
-        }
-        unsigned res = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) res |= (unsigned)min((acc[k] + 32768) >> 16, 255) << (8 * k);
+        // output row r = staged rows r .. r + 6 with the taps K0 K1 K2 K3 K2 K1 K0: four row pairs from pair r / 2 on; an even r starts on a pair
+        // (taps K0 K1 | K2 K3 | K2 K1 | K0 0), an odd r in the middle of one (0 K0 | K1 K2 | K3 K2 | K1 K0)
+        const bool odd = r & 1;
+        const unsigned t0 = odd ? ((unsigned)GK0 << 16) : ((unsigned)GK0 | ((unsigned)GK1 << 16));
+        const unsigned t1 = odd ? ((unsigned)GK1 | ((unsigned)GK2 << 16)) : ((unsigned)GK2 | ((unsigned)GK3 << 16));
+        const unsigned t2 = odd ? ((unsigned)GK3 | ((unsigned)GK2 << 16)) : ((unsigned)GK2 | ((unsigned)GK1 << 16));
+        const unsigned t3 = odd ? ((unsigned)GK1 | ((unsigned)GK0 << 16)) : (unsigned)GK0;
+        const uint4 *q = reinterpret_cast<const uint4 *>(&s_pair[(r >> 1) * BT_W + 4 * j]);
+        const uint4 q0 = q[0], q1 = q[BT_W / 4], q2 = q[2 * (BT_W / 4)], q3 = q[3 * (BT_W / 4)];
+        auto col = [&](unsigned a0, unsigned a1, unsigned a2, unsigned a3) -> unsigned {
+            unsigned acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a0), __builtin_bit_cast(u16x2, t0), 32768u, false);   // (acc + 32768) >> 16
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a1), __builtin_bit_cast(u16x2, t1), acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a2), __builtin_bit_cast(u16x2, t2), acc, false);
+            acc = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a3), __builtin_bit_cast(u16x2, t3), acc, false);
+            return min(acc >> 16, 255u);
+        };
+        const unsigned res = col(q0.x, q1.x, q2.x, q3.x) | (col(q0.y, q1.y, q2.y, q3.y) << 8) | (col(q0.z, q1.z, q2.z, q3.z) << 16) | (col(q0.w, q1.w, q2.w, q3.w) << 24);
         uint8_t *dst = out + (size_t)y * D.pitch + x;
         if (x + 3 < D.w) __builtin_memcpy(dst, &res, 4);
         else
