@@ -145,13 +145,22 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
     const int L = P.nlevels;
     PyrRange rx = P.pyrX[ti], ry = P.pyrY[tj];   // level 0: the input region
     int sx0 = rx.needLo, sy0 = ry.needLo, sw = rx.needHi - rx.needLo, sh = ry.needHi - ry.needLo;
+    int spitch = (sw + 3) & ~3;   // row pitch of the level held in the source buffer: the input region is staged with whole dwords (round 6: four bytes per load --
+                                  // the byte-wise loop was 40 trips of a 64-bit address computation and one byte per thread), later levels are packed (pitch = width)
     {
         int pitch;
         const uint8_t *img = level_ptr(P, frame, 0, pitch);
-        const unsigned m = ((1u << 22) + sw - 1) / sw;   // exact floor(i / sw) for i < 2^15, sw < 2^7 (regions are ~100 px wide)
-        for (int i = threadIdx.x; i < sw * sh; i += 256) {
-            const int r = (int)(((unsigned long long)(unsigned)i * m) >> 22), c = i - r * sw;
-            s_pyr[i] = img[(size_t)(sy0 + r) * pitch + sx0 + c];
+        const int nw = spitch >> 2, imgW = P.lv[0].w;
+        const unsigned m = ((1u << 22) + nw - 1) / nw;   // exact floor(i / nw) for i < 2^15, nw < 2^7
+        for (int i = threadIdx.x; i < nw * sh; i += 256) {
+            const int r = (int)__umulhi((unsigned)i << 10, m), q = i - r * nw;   // (i m) >> 22
+            const int x = sx0 + 4 * q;
+            const uint8_t *src = img + (unsigned)((sy0 + r) * pitch + x);
+            unsigned v = 0;
+            if (x + 3 < imgW) __builtin_memcpy(&v, src, 4);   // (bytes beyond the region but inside the image row: staged, never read)
+            else
+                for (int e = 0; e < 4 && x + e < imgW; e++) v |= (unsigned)src[e] << (8 * e);
+            reinterpret_cast<unsigned *>(s_pyr)[i] = v;
         }
     }
     __syncthreads();
@@ -164,10 +173,10 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
         uint8_t *out = P.pyr + (size_t)frame * P.pyrStride + D.off;
         const unsigned m = ((1u << 22) + dw - 1) / dw;
         for (int i = threadIdx.x; i < dw * dh; i += 256) {
-            const int r = (int)(((unsigned long long)(unsigned)i * m) >> 22), c = i - r * dw;
+            const int r = (int)__umulhi((unsigned)i << 10, m), c = i - r * dw;   // (i m) >> 22 without the 64-bit product
             const int dx = dx0 + c, dy = dy0 + r;
             const ResizeTap tx = P.taps[D.xtabOff + dx], ty = P.taps[D.ytabOff + dy];
-            const uint8_t *r0 = src + (ty.s0 - sy0) * sw - sx0, *r1 = src + (ty.s1 - sy0) * sw - sx0;
+            const uint8_t *r0 = src + (ty.s0 - sy0) * spitch - sx0, *r1 = src + (ty.s1 - sy0) * spitch - sx0;
             const int h0 = r0[tx.s0] * tx.c0 + r0[tx.s1] * tx.c1;
             const int h1 = r1[tx.s0] * tx.c0 + r1[tx.s1] * tx.c1;
             int v = (((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256) void k_pyramid(OrbDev P) {
             dst[i] = (uint8_t)v;
             if (dx >= rx.ownLo && dx < rx.ownHi && dy >= ry.ownLo && dy < ry.ownHi) out[(size_t)dy * D.pitch + dx] = (uint8_t)v;
         }
-        sx0 = dx0; sy0 = dy0; sw = dw; sh = dh;
+        sx0 = dx0; sy0 = dy0; sw = dw; sh = dh; spitch = dw;
         __syncthreads();
     }
 }
@@ -1265,7 +1274,7 @@ int build_geometry(msl_orb *h, int W, int H) {
         size_t b0 = 0, b1 = 0;
         bool ok = true;
         for (int l = 0; l < L; l++) {
-            const size_t a = (size_t)ex[l] * ey[l];
+            const size_t a = (size_t)(l == 0 ? (ex[l] + 3) & ~3 : ex[l]) * ey[l];   // (k_pyramid stages the input region with a dword pitch)
             if (l & 1) b1 = std::max(b1, a); else b0 = std::max(b0, a);
             if (l >= 1 && (D.lv[l].w < TX || D.lv[l].h < TY)) ok = false;
         }
