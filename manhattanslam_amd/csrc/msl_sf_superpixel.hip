@@ -920,34 +920,49 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
     const int r0 = ca == 0 ? 1 : 0, r1 = ca <= 1 ? 2 : 1, r2 = ca <= 2 ? 3 : 2;
     const int c0 = cb == 0 ? 1 : 0, c1 = cb <= 1 ? 2 : 1, c2 = cb <= 2 ? 3 : 2;
     const int tRounds = rows_max_i32(active ? (ninl + 15) >> 4 : 0);   // (ninl and active are uniform inside a group of 16 lanes)
+    // The centred points (`points[i] -= sum`, :107-111, once in the reference) of the first RREG rounds stay in registers through the five steps: the
+    // loops re-read and re-centred every point from the LDS in every step (three reads and three subtractions per point and step, and an LDS round trip
+    // per round that one or two waves per SIMD do not hide); rounds beyond RREG (lists longer than 96 points) still do.
+    constexpr int RREG = 6;
+    float cpx[RREG], cpy[RREG], cpz[RREG];
+#pragma unroll
+    for (int t = 0; t < RREG; t++) {
+        const int o = l + 16 * t, oc = (active && o < ninl) ? o : 0;
+        cpx[t] = cpy[t] = cpz[t] = 0.0f;
+        if (t < tRounds) { cpx[t] = pX[oc] - sumX; cpy[t] = pY[oc] - sumY; cpz[t] = pZ[oc] - sumZ; }
+    }
     for (int gnI = 0; gnI < 5; gnI++) {
         double J0 = 0, J1 = 0, J2 = 0, J3 = 0;
         unsigned mask = 0;
-        if (active) {
-#pragma unroll 1   // (not unrolled: 128 instead of 130 VGPRs = 3 x 128 per SIMD, which leaves room for two 64-register k_fuse waves instead of one)
-            for (int t = 0; t < tRounds; t++) {   // (a wave-uniform bound: the longest inlier list of the four seeds, typically 4-6 of the 16 rounds)
-                // Branch-free for the common case (every point inside the Huber band): a lane without a point in this round, or whose point is outside
-                // the band, adds +0.0 to its four sums -- exact: a sum that starts at +0.0 never becomes -0.0 -- with the coordinates replaced by zeros
-                // BEFORE the products (a NaN / infinite coordinate of a point outside the band must not reach them).  The nested per-lane branches
-                // of the literal form cost four taken branches per round, which one or two waves per SIMD cannot hide.  Points outside the band take the
-                // reference's two tail cases behind ONE wave-uniform test.
-                const int o = l + 16 * t;
-                const bool has = o < ninl;
-                const int oc = has ? o : 0;
-                const float px = pX[oc] - sumX, py = pY[oc] - sumY, pz = pZ[oc] - sumZ;
-                const float residual = px * nx + py * ny + pz * nz + nb;
-                const bool inb = has && in_huber_band(residual);
-                mask |= (inb ? 1u : 0u) << t;
-                const float r2 = inb ? 2 * residual : 0.0f;
-                const float qx = inb ? px : 0.0f, qy = inb ? py : 0.0f, qz = inb ? pz : 0.0f;
-                J0 += r2 * qx; J1 += r2 * qy; J2 += r2 * qz; J3 += r2;
-                if (__builtin_expect(__ballot(has && !inb) != 0ull, 0)) {
-                    if (has && residual >= HUBER_RANGE_F) {
-                        J0 += HUBER_RANGE * px; J1 += HUBER_RANGE * py; J2 += HUBER_RANGE * pz; J3 += HUBER_RANGE;
-                    } else if (has && residual <= -HUBER_RANGE_F) {
-                        J0 += -1 * HUBER_RANGE * px; J1 += -1 * HUBER_RANGE * py; J2 += -1 * HUBER_RANGE * pz; J3 += -1 * HUBER_RANGE;
-                    }
+        // One round of the Jacobian.  Branch-free for the common case (every point inside the Huber band): a lane without a point in this round, or whose
+        // point is outside the band, adds +0.0 to its four sums -- exact: a sum that starts at +0.0 never becomes -0.0 -- with the coordinates replaced by
+        // zeros BEFORE the products (a NaN / infinite coordinate of a point outside the band must not reach them).  The nested per-lane branches of the
+        // literal form cost four taken branches per round, which one or two waves per SIMD cannot hide.  Points outside the band take the reference's two
+        // tail cases behind ONE wave-uniform test.
+        auto jstep = [&](int t, float px, float py, float pz) {
+            const bool has = l + 16 * t < ninl;
+            const float residual = px * nx + py * ny + pz * nz + nb;
+            const bool inb = has && in_huber_band(residual);
+            mask |= (inb ? 1u : 0u) << t;
+            const float r2 = inb ? 2 * residual : 0.0f;
+            const float qx = inb ? px : 0.0f, qy = inb ? py : 0.0f, qz = inb ? pz : 0.0f;
+            J0 += r2 * qx; J1 += r2 * qy; J2 += r2 * qz; J3 += r2;
+            if (__builtin_expect(__ballot(has && !inb) != 0ull, 0)) {
+                if (has && residual >= HUBER_RANGE_F) {
+                    J0 += HUBER_RANGE * px; J1 += HUBER_RANGE * py; J2 += HUBER_RANGE * pz; J3 += HUBER_RANGE;
+                } else if (has && residual <= -HUBER_RANGE_F) {
+                    J0 += -1 * HUBER_RANGE * px; J1 += -1 * HUBER_RANGE * py; J2 += -1 * HUBER_RANGE * pz; J3 += -1 * HUBER_RANGE;
                 }
+            }
+        };
+        if (active) {
+#pragma unroll
+            for (int t = 0; t < RREG; t++)
+                if (t < tRounds) jstep(t, cpx[t], cpy[t], cpz[t]);   // (a wave-uniform bound: the longest inlier list of the four seeds, typically 4-6 of the 16 rounds)
+#pragma unroll 1
+            for (int t = RREG; t < tRounds; t++) {
+                const int o = l + 16 * t, oc = o < ninl ? o : 0;
+                jstep(t, pX[oc] - sumX, pY[oc] - sumY, pZ[oc] - sumZ);
             }
         }
         J0 = group_sum_d(J0); J1 = group_sum_d(J1); J2 = group_sum_d(J2); J3 = group_sum_d(J3);
@@ -957,15 +972,20 @@ __global__ __launch_bounds__(64) void kb_seed_plane(SfDev P, int nSlots) {
         if (__ballot(diffGroups != 0)) {
             double H00 = 0, H01 = 0, H02 = 0, H03 = 0, H11 = 0, H12 = 0, H13 = 0, H22 = 0, H23 = 0, H33 = 0;
             if (active && diffGroups) {
-#pragma unroll 1
-                for (int t = 0; t < tRounds; t++) {   // (branch-free like the Jacobian loop: a lane without an in-band point in this round adds zeros)
+                auto hstep = [&](int t, float rx, float ry, float rz) {   // (branch-free like the Jacobian: a lane without an in-band point in this round adds zeros)
                     const bool inb = (mask >> t) & 1u;
-                    const int oc = inb ? l + 16 * t : 0;
-                    const float rx = pX[oc] - sumX, ry = pY[oc] - sumY, rz = pZ[oc] - sumZ;
                     const float px = inb ? rx : 0.0f, py = inb ? ry : 0.0f, pz = inb ? rz : 0.0f;
                     H00 += 2 * px * px; H01 += 2 * px * py; H02 += 2 * px * pz; H03 += 2 * px;
                     H11 += 2 * py * py; H12 += 2 * py * pz; H13 += 2 * py;
                     H22 += 2 * pz * pz; H23 += 2 * pz; H33 += inb ? 2.0 : 0.0;
+                };
+#pragma unroll
+                for (int t = 0; t < RREG; t++)
+                    if (t < tRounds) hstep(t, cpx[t], cpy[t], cpz[t]);
+#pragma unroll 1
+                for (int t = RREG; t < tRounds; t++) {
+                    const int oc = ((mask >> t) & 1u) ? l + 16 * t : 0;
+                    hstep(t, pX[oc] - sumX, pY[oc] - sumY, pZ[oc] - sumZ);
                 }
             }
             H00 = group_sum_d(H00); H01 = group_sum_d(H01); H02 = group_sum_d(H02); H03 = group_sum_d(H03);
@@ -1189,14 +1209,16 @@ void sp_launch_stage(KernelProfiler &prof, hipStream_t sp, const SfDev &P, int n
         else MSL_SF_LAUNCH(prof, SK_UPDATE_SEEDS, sp, kb_update_seeds<false>, dim3(xcd_grid((P.nseeds + 15) / 16, n)), dim3(256), P, it, n);
         MSL_SF_LAUNCH(prof, SK_COMMIT_SEEDS, sp, kb_commit_seeds, seedGrid, dim3(256), P, it);
     }
-    // 6 KB of (unused) dynamic LDS cap the kernel at 7 waves per CU (it could run 10).  Measured on the whole front end, alternating runs on one
+    // 4 KB of (unused) dynamic LDS cap the kernel at 8 waves per CU (it could run 10; 6 KB = 7 waves until the end of round 6).  Measured on the whole front end, alternating runs on one
     // box -- round 3: 11 waves 19.6 k frames/s, 10 waves 20.6-20.9 k, 9 waves 21.0-21.1 k, 8 waves 21.3-21.5 k, 7 waves 20.3-20.9 k; round 5,
     // beside the slimmer kb_update_seeds: 10 waves 21.9 k, 9 waves 23.1-23.3 k, 8 waves 22.8-23.1 k, 7 waves 23.3-23.5 k, 6 waves 22.8 k, 5 waves
     // 22.5 k.  The kernel alone is no slower with fewer waves (its waves are VALU-latency bound), and the wave slots, registers and LDS it leaves
     // go to the ORB kernels and to the map stage that run beside it.
     // round 6, after the per-seed epilogue moved to kb_seed_finish (88 VGPRs, 339 us per launch at this cap): 10 waves per CU 281 us / 21.9 k frames/s, 8 waves
     // 306 us / 23.2-23.4 k, 7 waves 339 us / 24.0-24.2 k, 6 waves 384 us / 23.9 k -- the sweet spot did not move
-    constexpr unsigned planePad = 6144;
+    // ... and again with the centred points of the Gauss-Newton steps in registers (156 VGPRs: two waves fill a SIMD's budget more evenly than 7 per CU did): 10 waves
+    // per CU 268 us / 26.2 k frames/s but config 3 30.5 k, **8 waves 291 us / 25.8 k / config 3 31.5 k**, 7 waves 321 us / 25.1 k / 30.9 k, 6 waves 361 us / 24.5 k / 29.9 k
+    constexpr unsigned planePad = 4096;
     if ((W % SP) >= 1 && (W % SP) <= 3) MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<true>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     else MSL_SF_LAUNCH_LDS(prof, SK_SEED_PLANE, sp, kb_seed_plane<false>, dim3(xcd_grid(((P.spW + 1) / 2) * ((P.spH + 1) / 2), n)), dim3(64), planePad, P, n);
     hipLaunchKernelGGL(kb_seed_finish, seedGrid, dim3(256), 0, sp, P);
